@@ -1,0 +1,234 @@
+"""Minimal GGUF v3 reader / writer in numpy.
+
+Host-side utility: metadata inspection and writing synthetic Llama-family GGUFs (tests, bench).  The product
+loader that feeds the GPU is the C++ one in csrc/gguf.cpp; this module mirrors the same on-disk format
+(reference: cpp/ggml/src/ggml.c:20753-21260 reader, :21485-21990 writer; type ids ggml.h:360-375,
+KV value types ggml.h:2257-2272, default alignment 32 ggml.h:251).
+"""
+import struct
+import numpy as np
+
+GGUF_MAGIC = b"GGUF"
+GGUF_VERSION = 3
+DEFAULT_ALIGNMENT = 32
+
+# ggml tensor types we care about: id -> (block_elems, block_bytes)
+GGML_TYPES = {
+    0: (1, 4),        # F32
+    1: (1, 2),        # F16
+    12: (256, 144),   # Q4_K
+    13: (256, 176),   # Q5_K
+    14: (256, 210),   # Q6_K
+}
+F32, F16, Q4_K, Q5_K, Q6_K = 0, 1, 12, 13, 14
+TYPE_NAMES = {0: "F32", 1: "F16", 12: "Q4_K", 13: "Q5_K", 14: "Q6_K"}
+
+# gguf KV value types
+T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64 = range(13)
+_SCALAR_FMT = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i", T_F32: "<f",
+               T_BOOL: "<?", T_U64: "<Q", T_I64: "<q", T_F64: "<d"}
+
+
+def tensor_nbytes(ttype, shape):
+    be, bb = GGML_TYPES[ttype]
+    n = int(np.prod(shape))
+    assert shape[0] % be == 0, "row length must be a multiple of the block size"
+    return n // be * bb
+
+
+class GGUFReader:
+    """Parses header, KV pairs and tensor infos; tensor data are numpy views into a memory map."""
+
+    def __init__(self, path):
+        self.path = path
+        self.mm = np.memmap(path, dtype=np.uint8, mode="r")
+        buf = self.mm
+        self.o = 0
+        assert bytes(buf[0:4]) == GGUF_MAGIC, "not a GGUF file"
+        self.o = 4
+        self.version = self._rd("<I")
+        n_tensors = self._rd("<Q")
+        n_kv = self._rd("<Q")
+        self.kv = {}
+        for _ in range(n_kv):
+            key = self._rd_str()
+            vt = self._rd("<I")
+            self.kv[key] = self._rd_val(vt)
+        self.alignment = int(self.kv.get("general.alignment", DEFAULT_ALIGNMENT))
+        infos = []
+        for _ in range(n_tensors):
+            name = self._rd_str()
+            nd = self._rd("<I")
+            shape = [self._rd("<Q") for _ in range(nd)]       # ggml order: shape[0] = row length
+            ttype = self._rd("<I")
+            off = self._rd("<Q")
+            infos.append((name, shape, ttype, off))
+        self.data_offset = (self.o + self.alignment - 1) // self.alignment * self.alignment
+        self.tensors = {}
+        for name, shape, ttype, off in infos:
+            nb = tensor_nbytes(ttype, shape)
+            start = self.data_offset + off
+            self.tensors[name] = dict(shape=shape, type=ttype, data=self.mm[start:start + nb])
+
+    def _rd(self, fmt):
+        v = struct.unpack_from(fmt, self.mm, self.o)[0]
+        self.o += struct.calcsize(fmt)
+        return v
+
+    def _rd_str(self):
+        n = self._rd("<Q")
+        s = bytes(self.mm[self.o:self.o + n]).decode("utf-8", errors="replace")
+        self.o += n
+        return s
+
+    def _rd_val(self, vt):
+        if vt == T_STR:
+            return self._rd_str()
+        if vt == T_ARR:
+            et = self._rd("<I")
+            n = self._rd("<Q")
+            if et == T_STR:
+                return [self._rd_str() for _ in range(n)]
+            fmt = _SCALAR_FMT[et]
+            sz = struct.calcsize(fmt)
+            arr = np.frombuffer(self.mm, dtype=np.dtype(fmt[1:]).newbyteorder("<"), count=n, offset=self.o).copy()
+            self.o += sz * n
+            return arr
+        return self._rd(_SCALAR_FMT[vt])
+
+
+class GGUFWriter:
+    def __init__(self):
+        self.kv = []          # (key, type, value)
+        self.tensors = []     # (name, shape(ggml order), type, bytes ndarray)
+
+    def add_u32(self, k, v): self.kv.append((k, T_U32, int(v)))
+    def add_i32(self, k, v): self.kv.append((k, T_I32, int(v)))
+    def add_f32(self, k, v): self.kv.append((k, T_F32, float(v)))
+    def add_str(self, k, v): self.kv.append((k, T_STR, str(v)))
+    def add_bool(self, k, v): self.kv.append((k, T_BOOL, bool(v)))
+    def add_arr_str(self, k, v): self.kv.append((k, T_ARR, (T_STR, list(v))))
+    def add_arr(self, k, et, v): self.kv.append((k, T_ARR, (et, list(v))))
+
+    def add_tensor(self, name, shape, ttype, data):
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        assert data.size == tensor_nbytes(ttype, shape), (name, data.size, tensor_nbytes(ttype, shape))
+        self.tensors.append((name, list(shape), ttype, data))
+
+    @staticmethod
+    def _s(s):
+        b = s.encode("utf-8")
+        return struct.pack("<Q", len(b)) + b
+
+    def write(self, path):
+        out = bytearray()
+        out += GGUF_MAGIC + struct.pack("<I", GGUF_VERSION) + struct.pack("<Q", len(self.tensors)) + struct.pack("<Q", len(self.kv))
+        for k, t, v in self.kv:
+            out += self._s(k) + struct.pack("<I", t)
+            if t == T_STR:
+                out += self._s(v)
+            elif t == T_ARR:
+                et, items = v
+                out += struct.pack("<I", et) + struct.pack("<Q", len(items))
+                for it in items:
+                    out += self._s(it) if et == T_STR else struct.pack(_SCALAR_FMT[et], it)
+            else:
+                out += struct.pack(_SCALAR_FMT[t], v)
+        off = 0
+        offs = []
+        for name, shape, ttype, data in self.tensors:
+            out += self._s(name) + struct.pack("<I", len(shape))
+            for d in shape:
+                out += struct.pack("<Q", d)
+            out += struct.pack("<I", ttype) + struct.pack("<Q", off)
+            offs.append(off)
+            off += (data.size + DEFAULT_ALIGNMENT - 1) // DEFAULT_ALIGNMENT * DEFAULT_ALIGNMENT
+        pad = (-len(out)) % DEFAULT_ALIGNMENT
+        out += b"\0" * pad
+        with open(path, "wb") as f:
+            f.write(out)
+            for (name, shape, ttype, data) in self.tensors:
+                f.write(data.tobytes())
+                f.write(b"\0" * ((-data.size) % DEFAULT_ALIGNMENT))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# synthetic K-quant tensors: random but well-formed blocks (finite f16 scales), for throughput / parity runs
+# ---------------------------------------------------------------------------------------------------------
+def random_kquant_tensor(ttype, row_len, n_rows, rng, amp=1.0):
+    """Random raw blocks of type `ttype` for an [n_rows, row_len] matrix whose dequantised values are roughly
+    zero-mean with standard deviation ~ amp / sqrt(row_len)."""
+    be, bb = GGML_TYPES[ttype]
+    nblk = n_rows * (row_len // be)
+    blk = rng.integers(0, 256, size=(nblk, bb), dtype=np.uint8)
+    sigma = amp / np.sqrt(row_len)
+    if ttype in (Q4_K, Q5_K):
+        # w = d*sc*q - dmin*m ; q in [0,15]/[0,31], sc,m in [0,63]
+        qmax = 15.0 if ttype == Q4_K else 31.0
+        d = (sigma / (32.0 * qmax * 0.3)) * rng.uniform(0.5, 1.5, size=nblk)
+        dmin = d * qmax * 0.5 * rng.uniform(0.8, 1.2, size=nblk)
+        blk[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+        blk[:, 2:4] = dmin.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    elif ttype == Q6_K:
+        d = (sigma / (64.0 * 18.0)) * rng.uniform(0.5, 1.5, size=nblk)
+        blk[:, 208:210] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    else:
+        raise ValueError(ttype)
+    return blk.reshape(-1)
+
+
+def q4_k_m_type(name, il, n_layer):
+    """Tensor type under llama.cpp's Q4_K_M recipe for the tensors we use (reference: llama.cpp:15442-15444,
+    :15547-15555, :15603-15610, use_more_bits :15466-15480; SURVEY §8 header)."""
+    more = il < n_layer // 8 or il >= 7 * n_layer // 8 or (il - n_layer // 8) % 3 == 2
+    if name == "output":
+        return Q6_K
+    if name in ("attn_v", "ffn_down"):
+        return Q6_K if more else Q4_K
+    return Q4_K
+
+
+def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K):
+    """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks."""
+    rng = np.random.default_rng(seed)
+    type_fn = type_fn or (lambda name, il: q4_k_m_type(name, il, L))
+    hd = E // H
+    w = GGUFWriter()
+    w.add_str("general.architecture", "llama")
+    w.add_str("general.name", "booster-amd-synthetic")
+    w.add_u32("llama.context_length", n_ctx_train)
+    w.add_u32("llama.embedding_length", E)
+    w.add_u32("llama.block_count", L)
+    w.add_u32("llama.feed_forward_length", F)
+    w.add_u32("llama.attention.head_count", H)
+    w.add_u32("llama.attention.head_count_kv", Hkv)
+    w.add_f32("llama.attention.layer_norm_rms_epsilon", eps)
+    w.add_u32("llama.rope.dimension_count", hd)
+    w.add_f32("llama.rope.freq_base", theta)
+    w.add_u32("llama.vocab_size", V)
+    w.add_str("tokenizer.ggml.model", "no_vocab")
+
+    def norm():
+        return (1.0 + 0.1 * rng.standard_normal(E)).astype(np.float32)
+
+    w.add_tensor("token_embd.weight", [E, V], embd_type, random_kquant_tensor(embd_type, E, V, rng, amp=np.sqrt(E)))
+    w.add_tensor("output_norm.weight", [E], F32, norm())
+    t = type_fn("output", 0)
+    w.add_tensor("output.weight", [E, V], t, random_kquant_tensor(t, E, V, rng, amp=3.0))
+    if rope_freqs:
+        ff = np.ones(hd // 2, np.float32)
+        ff[hd // 4:] = 1.0 + 7.0 * np.arange(hd // 2 - hd // 4, dtype=np.float32) / (hd // 4)
+        w.add_tensor("rope_freqs.weight", [hd // 2], F32, ff)
+    for il in range(L):
+        p = "blk.%d." % il
+        w.add_tensor(p + "attn_norm.weight", [E], F32, norm())
+        for nm, rows, cols, amp in (("attn_q", E, E, 2.0), ("attn_k", Hkv * hd, E, 2.0), ("attn_v", Hkv * hd, E, 1.0),
+                                    ("attn_output", E, E, 1.0)):
+            t = type_fn(nm, il)
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, random_kquant_tensor(t, cols, rows, rng, amp))
+        w.add_tensor(p + "ffn_norm.weight", [E], F32, norm())
+        for nm, rows, cols, amp in (("ffn_gate", F, E, 1.5), ("ffn_up", F, E, 1.5), ("ffn_down", E, F, 1.0)):
+            t = type_fn(nm, il)
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, random_kquant_tensor(t, cols, rows, rng, amp))
+    w.write(path)
