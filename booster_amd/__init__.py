@@ -1,0 +1,184 @@
+"""booster_amd — Python host side above the C-ABI of libbooster_amd.so (include/bamd.h, include/booster_bridge.h).
+
+The reference's host language is Go (pkg/server, cgo); Go is not in this image, so this thin ctypes layer plays
+the host role for tests, bench and multi-process layer split.  It contains NO compute: every number comes out
+of the HIP library, and loading fails loudly if that library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbooster_amd.so")
+_lib = None
+
+F32, F16, Q4_K, Q5_K, Q6_K = 0, 1, 12, 13, 14
+
+
+class BamdError(RuntimeError):
+    pass
+
+
+def lib():
+    """The HIP library.  No fallback: a missing .so is an error (run `python -m booster_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BamdError("libbooster_amd.so is not built (python -m booster_amd.build); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cf, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+        L.bamd_last_error.restype = C.c_char_p
+        L.bamd_model_load.restype = vp; L.bamd_model_load.argtypes = [C.c_char_p, ci, ci, ci, ci, ci]
+        L.bamd_model_free.argtypes = [vp]
+        for n in ("bamd_model_n_vocab", "bamd_model_n_embd", "bamd_model_n_layer", "bamd_model_n_ctx_train"):
+            getattr(L, n).argtypes = [vp]
+        L.bamd_model_weight_bytes.restype = i64; L.bamd_model_weight_bytes.argtypes = [vp]
+        L.bamd_model_tensor_raw.restype = i64; L.bamd_model_tensor_raw.argtypes = [vp, C.c_char_p, vp, i64]
+        L.bamd_context_new.restype = vp; L.bamd_context_new.argtypes = [vp, ci]
+        L.bamd_context_free.argtypes = [vp]
+        L.bamd_n_ctx.argtypes = [vp]
+        L.bamd_kv_cache_clear.argtypes = [vp]
+        L.bamd_decode.argtypes = [vp, vp, ci, ci]
+        L.bamd_get_logits.restype = C.POINTER(C.c_float); L.bamd_get_logits.argtypes = [vp]
+        L.bamd_generate_greedy.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_float)]
+        L.bamd_stage_step.argtypes = [vp, C.c_int32, ci, vp, vp, ci, ci, vp]
+        L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+        L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
+        L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
+        L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp]
+        L.bamd_op_ffn_gate_up.argtypes = [ci, vp, vp, ci, ci, vp, vp, cf, vp]
+        L.bamd_op_get_row.argtypes = [ci, vp, ci, ci, ci, vp]
+        L.bamd_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.bamd_op_rope_row.argtypes = [ci, ci, cf, cf, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise BamdError(lib().bamd_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().bamd_device_count()
+
+
+class Model:
+    """llama_model analogue: one layer-split stage of a GGUF Llama model resident on one GPU."""
+
+    def __init__(self, path, device=0, layer_first=0, layer_last=-1, with_embd=True, with_output=True):
+        self.h = lib().bamd_model_load(os.fsencode(path), device, layer_first, layer_last, int(with_embd), int(with_output))
+        if not self.h:
+            raise BamdError(lib().bamd_last_error().decode())
+        self.n_vocab = lib().bamd_model_n_vocab(self.h)
+        self.n_embd = lib().bamd_model_n_embd(self.h)
+        self.n_layer = lib().bamd_model_n_layer(self.h)
+        self.weight_bytes = lib().bamd_model_weight_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().bamd_model_free(self.h)
+            self.h = None
+
+
+class Context:
+    """llama_context analogue (KV cache + scratch + device-side step state)."""
+
+    def __init__(self, model, n_ctx):
+        self.model = model
+        self.h = lib().bamd_context_new(model.h, n_ctx)
+        if not self.h:
+            raise BamdError(lib().bamd_last_error().decode())
+        self.n_ctx = n_ctx
+
+    def close(self):
+        if self.h:
+            lib().bamd_context_free(self.h)
+            self.h = None
+
+    def decode(self, tokens, n_past):
+        """llama_decode(llama_batch_get_one(tokens, n, n_past, 0)); returns the last token's logits."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        if lib().bamd_decode(self.h, _p(t), t.size, n_past) != 0:
+            raise BamdError(lib().bamd_last_error().decode())
+        return np.ctypeslib.as_array(lib().bamd_get_logits(self.h), shape=(self.model.n_vocab,)).copy()
+
+    def generate_greedy(self, n_past, n_steps):
+        out = np.zeros(n_steps + 1, np.int32)
+        ms = C.c_float(0)
+        _chk(lib().bamd_generate_greedy(self.h, n_past, n_steps, _p(out), C.byref(ms)))
+        return out, float(ms.value)
+
+    def last_logits(self):
+        return np.ctypeslib.as_array(lib().bamd_get_logits(self.h), shape=(self.model.n_vocab,)).copy()
+
+    def profile_step(self, pos):
+        launches = np.zeros(3, np.int32); ms = np.zeros(3, np.float64); nbytes = np.zeros(3, np.float64)
+        _chk(lib().bamd_profile_step(self.h, pos, _p(launches), _p(ms), _p(nbytes)))
+        return launches, ms, nbytes
+
+    def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr):
+        _chk(lib().bamd_stage_step(self.h, int(token), int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits), int(prefill_mode), stream_ptr))
+
+    def stage_argmax(self, stream_ptr):
+        t = C.c_int32(0)
+        _chk(lib().bamd_stage_argmax(self.h, stream_ptr, C.byref(t)))
+        return int(t.value)
+
+
+# ---- op-level wrappers (parity tests) ------------------------------------------------------------------------
+def op_quantize_q8_K(x, norm_w=None, eps=0.0):
+    x = np.ascontiguousarray(x, np.float32)
+    w = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
+    out = np.zeros(x.size // 256 * 292, np.uint8)
+    _chk(lib().bamd_op_quantize_q8_K(_p(x), x.size, _p(w), eps, _p(out)))
+    return out
+
+
+def op_mul_mat_vec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None):
+    w_raw = np.ascontiguousarray(w_raw, np.uint8)
+    x = np.ascontiguousarray(x, np.float32)
+    nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
+    res = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    y = np.zeros(nrows, np.float32)
+    _chk(lib().bamd_op_mul_mat_vec(ttype, _p(w_raw), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y)))
+    return y
+
+
+def op_ffn_gate_up(ttype, wg_raw, wu_raw, nrows, k, x, norm_w=None, eps=0.0):
+    wg_raw = np.ascontiguousarray(wg_raw, np.uint8); wu_raw = np.ascontiguousarray(wu_raw, np.uint8)
+    x = np.ascontiguousarray(x, np.float32)
+    nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
+    y = np.zeros(nrows, np.float32)
+    _chk(lib().bamd_op_ffn_gate_up(ttype, _p(wg_raw), _p(wu_raw), nrows, k, _p(x), _p(nw), eps, _p(y)))
+    return y
+
+
+def op_get_row(ttype, w_raw, nrows, k, row):
+    w_raw = np.ascontiguousarray(w_raw, np.uint8)
+    y = np.zeros(k, np.float32)
+    _chk(lib().bamd_op_get_row(ttype, _p(w_raw), nrows, k, row, _p(y)))
+    return y
+
+
+def op_rope_row(pos, n_dims, freq_base, freq_scale=1.0, freq_factors=None):
+    row = np.zeros(n_dims, np.float32)
+    ff = None if freq_factors is None else np.ascontiguousarray(freq_factors, np.float32)
+    _chk(lib().bamd_op_rope_row(pos, n_dims, freq_base, freq_scale, _p(ff), _p(row)))
+    return row
+
+
+def op_attention(q, k, v, k_cache, v_cache_t, rope_row, H, Hkv, hd, n_ctx, pos, prefill_mode=False, want_probs=False):
+    q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+    rope_row = np.ascontiguousarray(rope_row, np.float32)
+    assert k_cache.dtype == np.uint16 and v_cache_t.dtype == np.uint16 and k_cache.flags.c_contiguous and v_cache_t.flags.c_contiguous
+    out = np.zeros(H * hd, np.float32)
+    probs = np.zeros(n_ctx, np.float32) if want_probs else None
+    _chk(lib().bamd_op_attention(_p(q), _p(k), _p(v), _p(k_cache), _p(v_cache_t), _p(rope_row), H, Hkv, hd, n_ctx, pos, int(prefill_mode),
+                                 _p(out), _p(probs)))
+    return (out, probs) if want_probs else out

@@ -1,0 +1,604 @@
+// bamd_engine.cpp — model runtime of libbooster_amd.so: GGUF -> HBM (wave-stream repack), KV cache, the fixed
+// Llama decode pipeline as a static launch sequence / hipGraph, and the level-1 C-ABI of include/bamd.h.
+//
+// Replaces, for general.architecture = "llama" only, what the reference does in cpp/src/llama.cpp
+// (llama_load_model_from_file :16539, llm_load_tensors :5899, llama_new_context_with_model :16592,
+// llama_kv_cache_init :2926, build_llama :8781, llama_decode_internal :14537) and cpp/ggml/src/ggml-backend.c
+// (graph split / scheduling) with one static pipeline: 6 kernels per layer, activations never leave HBM/LDS,
+// the step's control state (position, KV length, token) lives on the device.
+#include "../../include/bamd.h"
+#include "bamd_formats.h"
+#include "bamd_gguf.h"
+#include "bamd_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(const std::string & m) { g_err = m; return 1; }
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
+#define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
+
+extern "C" __attribute__((visibility("default"))) const char * bamd_last_error(void) { return g_err.c_str(); }
+
+// -------------------------------------------------------------------------------------------------------
+// RoPE table on the host — ggml_rope_cache_init / rope_yarn / ggml_rope_yarn_corr_dims (ggml.c:13994-14041).
+// cos/sin come from the host libm exactly like the reference's CPU path; the device only looks them up.
+// -------------------------------------------------------------------------------------------------------
+static float rope_yarn_ramp(const float low, const float high, const int i0) {
+    const float y = (i0 / 2 - low) / fmaxf(0.001f, high - low);
+    return 1 - fminf(1, fmaxf(0, y));
+}
+static float rope_corr_dim(int n_dims, int n_ctx_orig, float n_rot, float base) {
+    return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(base));
+}
+static void rope_row(float * cache, int32_t pos, int n_dims, float freq_base, float freq_scale, const float * freq_factors,
+                     float ext_factor, float attn_factor, int n_ctx_orig, float beta_fast, float beta_slow) {
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    float corr_dims[2];
+    {
+        const float start = floorf(rope_corr_dim(n_dims, n_ctx_orig, beta_fast, freq_base));
+        const float end = ceilf(rope_corr_dim(n_dims, n_ctx_orig, beta_slow, freq_base));
+        corr_dims[0] = start > 0 ? start : 0;
+        corr_dims[1] = end < n_dims - 1 ? end : n_dims - 1;
+    }
+    float theta = (float) pos;
+    for (int i0 = 0; i0 < n_dims; i0 += 2) {
+        const float ff = freq_factors ? freq_factors[i0 / 2] : 1.0f;
+        const float theta_extrap = theta / ff;
+        const float theta_interp = freq_scale * theta_extrap;
+        float th = theta_interp, mscale = attn_factor;
+        if (ext_factor != 0.0f) {
+            const float ramp_mix = rope_yarn_ramp(corr_dims[0], corr_dims[1], i0) * ext_factor;
+            th = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
+            mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+        }
+        cache[i0 + 0] = cosf(th) * mscale;
+        cache[i0 + 1] = sinf(th) * mscale;
+        theta *= theta_scale;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------
+struct DevMat {                      // one quantised matrix resident in HBM
+    void * stream = nullptr;         // wave-stream records (matmul operand)
+    void * raw = nullptr;            // GGUF layout (kept only for token_embd: row gather)
+    int type = 0, nrows = 0, K = 0;
+    size_t bytes = 0;
+};
+struct DevLayer {
+    float * attn_norm = nullptr, * ffn_norm = nullptr;
+    DevMat wq, wk, wv, wo, wg, wu, wd;
+};
+
+struct bamd_model {
+    int device = 0;
+    int E = 0, H = 0, Hkv = 0, hd = 0, L = 0, F = 0, V = 0, n_ctx_train = 0, n_rot = 0;
+    float eps = 1e-5f, rope_theta = 10000.f, rope_freq_scale = 1.f;
+    int layer_first = 0, layer_last = 0;
+    bool with_embd = true, with_output = true;
+    std::vector<float> rope_freqs;   // host copy (optional)
+    std::vector<DevLayer> layers;    // [layer_last - layer_first]
+    DevMat tok_embd, output;
+    float * out_norm = nullptr;
+    int64_t weight_bytes = 0;
+    int n_cu = 256;
+    std::unique_ptr<GgufFile> file;  // stays mapped (bamd_model_tensor_raw)
+    std::vector<void *> allocs;
+};
+
+struct bamd_context {
+    bamd_model * m = nullptr;
+    int n_ctx = 0;
+    std::vector<unsigned short *> kc, vc;
+    float * rope = nullptr;
+    float * x = nullptr, * x2 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr, * scores = nullptr;
+    float * logits = nullptr;        // device
+    float * logits_host = nullptr;   // pinned
+    bamd_step_state * st = nullptr;
+    int32_t * forced = nullptr; int forced_cap = 0;
+    int32_t * out_tokens = nullptr; int out_cap = 0;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t graph = nullptr;
+    std::vector<void *> allocs;
+};
+
+static int dev_alloc(std::vector<void *> & keep, void ** p, size_t bytes) {
+    HIPC(hipMalloc(p, bytes ? bytes : 16));
+    keep.push_back(*p);
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int bamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { g_err = "hipGetDeviceCount failed (no HIP device?)"; return -1; }
+    return n;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_backend_init(void) { return bamd_device_count(); }
+
+// upload one matrix: raw bytes -> (optional raw copy) + wave-stream repack on the device
+static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool keep_raw, bool want_stream, void * staging, hipStream_t s) {
+    if (t->ne.size() != 2) return fail("tensor " + t->name + ": expected 2 dims");
+    d.type = t->type; d.K = (int) t->ne[0]; d.nrows = (int) t->ne[1]; d.bytes = t->nbytes;
+    if (want_stream) {
+        if (!bamd_is_kquant(d.type)) return fail("tensor " + t->name + ": only Q4_K/Q5_K/Q6_K matrices are supported on the matmul path");
+        if (d.K % 256 || d.nrows % 8) return fail("tensor " + t->name + ": shape not a multiple of (256, 8)");
+    }
+    void * rawdev = staging;
+    if (keep_raw) { if (dev_alloc(m->allocs, &d.raw, t->nbytes)) return 1; rawdev = d.raw; }
+    HIPC(hipMemcpyAsync(rawdev, t->data, t->nbytes, hipMemcpyHostToDevice, s));
+    if (want_stream) {
+        if (dev_alloc(m->allocs, &d.stream, t->nbytes)) return 1;
+        bamd_launch_repack(rawdev, d.stream, d.type, d.nrows, d.K, s);
+        m->weight_bytes += (int64_t) t->nbytes;
+    }
+    HIPC(hipStreamSynchronize(s));     // staging buffer is reused by the next tensor
+    return 0;
+}
+static int upload_f32(bamd_model * m, const GgufTensor * t, float ** p, int n, hipStream_t s) {
+    if (!t) return fail("missing norm tensor");
+    if (t->type != BAMD_F32 || (int) t->ne[0] != n) return fail("tensor " + t->name + ": expected f32[" + std::to_string(n) + "]");
+    if (dev_alloc(m->allocs, (void **) p, (size_t) n * 4)) return 1;
+    HIPC(hipMemcpyAsync(*p, t->data, (size_t) n * 4, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+static int model_load_impl(bamd_model * m, const char * path, int device, int lf, int ll, int with_embd, int with_output) {
+    int ndev = bamd_device_count();
+    if (ndev <= 0) return fail("no HIP device available: libbooster_amd has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("bad device index");
+    HIPC(hipSetDevice(device));
+    m->device = device;
+    { hipDeviceProp_t p; HIPC(hipGetDeviceProperties(&p, device)); m->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+    m->file.reset(new GgufFile());
+    std::string err;
+    if (!m->file->open(path, err)) return fail(err);
+    GgufFile & g = *m->file;
+    std::string arch;
+    if (!g.get_str("general.architecture", arch) || arch != "llama") return fail("general.architecture must be \"llama\" (got \"" + arch + "\")");
+    uint32_t u;
+    if (!g.get_u32("llama.embedding_length", u)) return fail("missing llama.embedding_length"); m->E = (int) u;
+    if (!g.get_u32("llama.block_count", u)) return fail("missing llama.block_count"); m->L = (int) u;
+    if (!g.get_u32("llama.feed_forward_length", u)) return fail("missing llama.feed_forward_length"); m->F = (int) u;
+    if (!g.get_u32("llama.attention.head_count", u)) return fail("missing llama.attention.head_count"); m->H = (int) u;
+    m->Hkv = m->H; if (g.get_u32("llama.attention.head_count_kv", u)) m->Hkv = (int) u;
+    if (!g.get_f32("llama.attention.layer_norm_rms_epsilon", m->eps)) return fail("missing llama.attention.layer_norm_rms_epsilon");
+    m->n_ctx_train = 2048; if (g.get_u32("llama.context_length", u)) m->n_ctx_train = (int) u;
+    m->hd = m->E / m->H;
+    m->n_rot = m->hd; if (g.get_u32("llama.rope.dimension_count", u)) m->n_rot = (int) u;
+    if (m->n_rot != m->hd) return fail("llama.rope.dimension_count != n_embd/n_head is not supported");
+    g.get_f32("llama.rope.freq_base", m->rope_theta);
+    {   // linear RoPE scaling (llama.cpp:4600-4640): freq_scale = 1/factor; YaRN is out of scope
+        std::string st; float factor = 0.f;
+        if (g.get_str("llama.rope.scaling.type", st) && st != "none" && st != "linear") return fail("rope scaling type \"" + st + "\" not supported");
+        if (g.get_f32("llama.rope.scaling.factor", factor) && factor != 0.f && st == "linear") m->rope_freq_scale = 1.0f / factor;
+    }
+    if (m->H % m->Hkv) return fail("n_head % n_head_kv != 0");
+    const int gq = m->H / m->Hkv;
+    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return fail("GQA ratio must be 1, 2, 4 or 8");
+    if (m->hd % 32 || m->hd > 256) return fail("head dim must be a multiple of 32 and <= 256");
+    if (m->E % 256 || m->F % 256) return fail("n_embd and n_ff must be multiples of 256");
+    if (ll < 0 || ll > m->L) ll = m->L;
+    if (lf < 0 || lf > ll) return fail("bad layer range");
+    m->layer_first = lf; m->layer_last = ll; m->with_embd = with_embd != 0; m->with_output = with_output != 0;
+
+    const GgufTensor * te = g.tensor("token_embd.weight");
+    if (!te) return fail("missing token_embd.weight");
+    m->V = (int) te->ne[1];
+    if (const GgufTensor * rf = g.tensor("rope_freqs.weight")) {
+        if (rf->type != BAMD_F32 || (int) rf->ne[0] < m->hd / 2) return fail("bad rope_freqs.weight");
+        m->rope_freqs.assign((const float *) rf->data, (const float *) rf->data + m->hd / 2);
+    }
+    hipStream_t s; HIPC(hipStreamCreate(&s));
+    size_t stage_bytes = 0;
+    for (auto & t : g.tensors) stage_bytes = std::max(stage_bytes, t.nbytes);
+    void * staging = nullptr; HIPC(hipMalloc(&staging, stage_bytes));
+    int rc = 0;
+    do {
+        if (m->with_embd) { if ((rc = upload_mat(m, te, m->tok_embd, true, false, staging, s))) break; }
+        if (m->with_output) {
+            if ((rc = upload_f32(m, g.tensor("output_norm.weight"), &m->out_norm, m->E, s))) break;
+            const GgufTensor * to = g.tensor("output.weight");
+            if (!to) to = te;                                              // tied embeddings, llama.cpp:6070-6076
+            if ((rc = upload_mat(m, to, m->output, false, true, staging, s))) break;
+        }
+        m->layers.resize((size_t) (ll - lf));
+        for (int il = lf; il < ll && !rc; ++il) {
+            DevLayer & ly = m->layers[(size_t) (il - lf)];
+            const std::string p = "blk." + std::to_string(il) + ".";
+            if ((rc = upload_f32(m, g.tensor(p + "attn_norm.weight"), &ly.attn_norm, m->E, s))) break;
+            if ((rc = upload_f32(m, g.tensor(p + "ffn_norm.weight"), &ly.ffn_norm, m->E, s))) break;
+            struct { const char * n; DevMat * d; } mats[] = { { "attn_q", &ly.wq }, { "attn_k", &ly.wk }, { "attn_v", &ly.wv }, { "attn_output", &ly.wo },
+                                                              { "ffn_gate", &ly.wg }, { "ffn_up", &ly.wu }, { "ffn_down", &ly.wd } };
+            for (auto & mm : mats) {
+                const GgufTensor * t = g.tensor(p + mm.n + ".weight");
+                if (!t) { rc = fail("missing tensor " + p + mm.n + ".weight"); break; }
+                if ((rc = upload_mat(m, t, *mm.d, false, true, staging, s))) break;
+            }
+            if (rc) break;
+            if (ly.wq.nrows != m->E || ly.wq.K != m->E || ly.wk.nrows != m->Hkv * m->hd || ly.wv.nrows != m->Hkv * m->hd || ly.wo.nrows != m->E ||
+                ly.wg.nrows != m->F || ly.wu.nrows != m->F || ly.wd.nrows != m->E || ly.wd.K != m->F) { rc = fail("layer " + std::to_string(il) + ": unexpected tensor shapes"); break; }
+            if (ly.wg.type != ly.wu.type) { rc = fail("ffn_gate and ffn_up must share one quantisation type"); break; }
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(staging);
+    hipStreamDestroy(s);
+    return rc;
+}
+
+extern "C" __attribute__((visibility("default"))) bamd_model * bamd_model_load(const char * path, int device, int layer_first, int layer_last, int with_embd, int with_output) {
+    bamd_model * m = new bamd_model();
+    if (model_load_impl(m, path, device, layer_first, layer_last, with_embd, with_output)) { bamd_model_free(m); return nullptr; }
+    return m;
+}
+extern "C" __attribute__((visibility("default"))) void bamd_model_free(bamd_model * m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    for (void * p : m->allocs) hipFree(p);
+    delete m;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_model_n_vocab(const bamd_model * m) { return m->V; }
+extern "C" __attribute__((visibility("default"))) int bamd_model_n_embd(const bamd_model * m) { return m->E; }
+extern "C" __attribute__((visibility("default"))) int bamd_model_n_layer(const bamd_model * m) { return m->L; }
+extern "C" __attribute__((visibility("default"))) int bamd_model_n_ctx_train(const bamd_model * m) { return m->n_ctx_train; }
+extern "C" __attribute__((visibility("default"))) int64_t bamd_model_weight_bytes(const bamd_model * m) { return m->weight_bytes; }
+extern "C" __attribute__((visibility("default"))) int64_t bamd_model_tensor_raw(const bamd_model * m, const char * name, void * dst, int64_t cap) {
+    const GgufTensor * t = m->file->tensor(name);
+    if (!t) { g_err = std::string("no tensor ") + name; return -1; }
+    if ((int64_t) t->nbytes > cap) return (int64_t) t->nbytes;
+    memcpy(dst, t->data, t->nbytes);
+    return (int64_t) t->nbytes;
+}
+
+// -------------------------------------------------------------------------------------------------------
+static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
+    HIPC(hipSetDevice(m->device));
+    c->m = m; c->n_ctx = n_ctx;
+    if (n_ctx < 32 || n_ctx % 32) return fail("n_ctx must be a positive multiple of 32");
+    HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int nl = (int) m->layers.size(), Ekv = m->Hkv * m->hd;
+    c->kc.resize((size_t) nl); c->vc.resize((size_t) nl);
+    const size_t kvb = (size_t) n_ctx * Ekv * 2;
+    for (int i = 0; i < nl; ++i) {                                   // llama_kv_cache_init :2926-3026 — zero-initialised
+        if (dev_alloc(c->allocs, (void **) &c->kc[(size_t) i], kvb) || dev_alloc(c->allocs, (void **) &c->vc[(size_t) i], kvb)) return 1;
+        HIPC(hipMemsetAsync(c->kc[(size_t) i], 0, kvb, c->stream)); HIPC(hipMemsetAsync(c->vc[(size_t) i], 0, kvb, c->stream));
+    }
+    {   // RoPE table for every position (host libm, like the reference), uploaded once
+        std::vector<float> tab((size_t) n_ctx * m->hd);
+        for (int p = 0; p < n_ctx; ++p)
+            rope_row(tab.data() + (size_t) p * m->hd, p, m->hd, m->rope_theta, m->rope_freq_scale, m->rope_freqs.empty() ? nullptr : m->rope_freqs.data(),
+                     0.0f, 1.0f, m->n_ctx_train, 32.0f, 1.0f);
+        if (dev_alloc(c->allocs, (void **) &c->rope, tab.size() * 4)) return 1;
+        HIPC(hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (dev_alloc(c->allocs, (void **) &c->x, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->x2, (size_t) m->E * 4) ||
+        dev_alloc(c->allocs, (void **) &c->q, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->k, (size_t) Ekv * 4) ||
+        dev_alloc(c->allocs, (void **) &c->v, (size_t) Ekv * 4) || dev_alloc(c->allocs, (void **) &c->att, (size_t) m->E * 4) ||
+        dev_alloc(c->allocs, (void **) &c->h, (size_t) m->F * 4) || dev_alloc(c->allocs, (void **) &c->scores, (size_t) m->H * n_ctx * 4) ||
+        dev_alloc(c->allocs, (void **) &c->logits, (size_t) m->V * 4) || dev_alloc(c->allocs, (void **) &c->st, sizeof(bamd_step_state))) return 1;
+    HIPC(hipMemsetAsync(c->st, 0, sizeof(bamd_step_state), c->stream));
+    HIPC(hipMemsetAsync(c->logits, 0, (size_t) m->V * 4, c->stream));
+    HIPC(hipHostMalloc((void **) &c->logits_host, (size_t) m->V * 4));
+    c->forced_cap = 4096; c->out_cap = n_ctx + 8;
+    if (dev_alloc(c->allocs, (void **) &c->forced, (size_t) c->forced_cap * 4) || dev_alloc(c->allocs, (void **) &c->out_tokens, (size_t) c->out_cap * 4)) return 1;
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) bamd_context * bamd_context_new(bamd_model * m, int n_ctx) {
+    bamd_context * c = new bamd_context();
+    if (context_init(c, m, n_ctx)) { bamd_context_free(c); return nullptr; }
+    return c;
+}
+extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_context * c) {
+    if (!c) return;
+    if (c->m) hipSetDevice(c->m->device);
+    if (c->graph) hipGraphExecDestroy(c->graph);
+    for (void * p : c->allocs) hipFree(p);
+    if (c->logits_host) hipHostFree(c->logits_host);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_n_ctx(const bamd_context * c) { return c->n_ctx; }
+extern "C" __attribute__((visibility("default"))) void bamd_kv_cache_clear(bamd_context * c) { (void) c; /* llama_kv_cache_clear resets cell metadata only; positions are passed per call here */ }
+
+// -------------------------------------------------------------------------------------------------------
+// the static per-token pipeline
+// -------------------------------------------------------------------------------------------------------
+struct StepTimer {                 // optional per-launch HIP-event timing (bamd_profile_step)
+    bool on = false;
+    std::vector<hipEvent_t> ev; std::vector<int> cls; std::vector<double> bytes;
+    void begin(hipStream_t s, int c, double b) { if (!on) return; hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, s); ev.push_back(a); cls.push_back(c); bytes.push_back(b); }
+    void end(hipStream_t s) { if (!on) return; hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, s); ev.push_back(b); }
+};
+
+static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.stream; sg.out = out; sg.type = d.type; sg.nrows = d.nrows; }
+
+// enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
+static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm) {
+    bamd_model * m = c->m;
+    const int gq = m->H / m->Hkv;
+    const int tiles = std::min(std::max(c->n_ctx / 64, 1), 32);
+    for (size_t il = 0; il < m->layers.size(); ++il) {
+        const DevLayer & ly = m->layers[il];
+        bamd_mv_args a; memset(&a, 0, sizeof a);
+        // 1. q,k,v = W{q,k,v} . Q8_K(rms_norm(x) * attn_norm)          (llama.cpp:8810-8835)
+        seg_of(a.seg[0], ly.wq, c->q); seg_of(a.seg[1], ly.wk, c->k); seg_of(a.seg[2], ly.wv, c->v); a.nseg = 3;
+        a.x = c->x; a.normw = ly.attn_norm; a.eps = m->eps; a.K = m->E;
+        if (tm) tm->begin(s, 0, (double) (ly.wq.bytes + ly.wk.bytes + ly.wv.bytes));
+        bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_STORE, m->n_cu, s);
+        if (tm) tm->end(s);
+        // 2. RoPE, KV store, softmax(QK^T) V                               (llama.cpp:8837-8849, :8318-8353)
+        bamd_attn_args t; memset(&t, 0, sizeof t);
+        t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.out = c->att;
+        t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
+        if (tm) tm->begin(s, 1, 0.0);
+        if (bamd_launch_attention(t, gq, tiles, s)) return fail("attention launch: unsupported head configuration");
+        if (tm) tm->end(s);
+        // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x;
+        if (tm) tm->begin(s, 0, (double) ly.wo.bytes);
+        bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
+        if (tm) tm->end(s);
+        // 4. h = silu(Wg . a) * (Wu . a),  a = Q8_K(rms_norm(x2) * ffn_norm)  (llama.cpp:8869-8885)
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wg, c->h); seg_of(a.seg[1], ly.wu, c->h); a.nseg = 2; a.x = c->x2; a.normw = ly.ffn_norm; a.eps = m->eps; a.K = m->E;
+        if (tm) tm->begin(s, 0, (double) (ly.wg.bytes + ly.wu.bytes));
+        bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_SILU_MUL, m->n_cu, s);
+        if (tm) tm->end(s);
+        // 5. x = x2 + Wd . Q8_K(h)                                          (llama.cpp:8885, :8902)
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wd, c->x); a.nseg = 1; a.x = c->h; a.K = m->F; a.res = c->x2;
+        if (tm) tm->begin(s, 0, (double) ly.wd.bytes);
+        bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
+        if (tm) tm->end(s);
+    }
+    return 0;
+}
+static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
+    bamd_model * m = c->m;
+    bamd_mv_args a; memset(&a, 0, sizeof a);
+    seg_of(a.seg[0], m->output, c->logits); a.nseg = 1; a.x = c->x; a.normw = m->out_norm; a.eps = m->eps; a.K = m->E; a.best_key = &c->st->best_key;
+    if (tm) tm->begin(s, 0, (double) m->output.bytes);
+    bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_ARGMAX, m->n_cu, s);
+    if (tm) tm->end(s);
+}
+static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStream_t s) {
+    bamd_model * m = c->m;
+    bamd_launch_step_begin(c->st, c->forced, n_forced, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, do_embed, s);
+}
+
+static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_key) {
+    bamd_step_state h; memset(&h, 0, sizeof h);
+    h.pos_base = pos_base; h.n_ctx = c->n_ctx;
+    if (keep_key) {
+        // keep best_key (the arg-max of the previous lm_head): rewrite only the leading fields
+        HIPC(hipMemcpyAsync(c->st, &h, offsetof(bamd_step_state, best_key), hipMemcpyHostToDevice, s));
+    } else HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past) {
+    bamd_model * m = c->m;
+    if (!m->with_embd || !m->with_output) { fail("bamd_decode needs a stage that owns embedding and output"); return 1; }
+    if (n_tokens < 1 || n_tokens > c->forced_cap) { fail("n_tokens out of range"); return 1; }
+    if (n_past < 0 || n_past + n_tokens > c->n_ctx) { fail("context overflow"); return 1; }
+    if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
+    hipStream_t s = c->stream;
+    if (hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s) != hipSuccess) { fail("H2D tokens"); return 1; }
+    if (set_state(c, n_past, s, false)) return 1;
+    const int prefill_mode = n_tokens > 1;
+    for (int t = 0; t < n_tokens; ++t) {
+        enqueue_begin(c, n_tokens, 1, s);
+        if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
+        if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);       // n_outputs = 1: last token only (llama.cpp:14580-14593)
+    }
+    if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) { return c->logits_host; }
+
+static int build_graph(bamd_context * c) {
+    hipStream_t s = c->stream;
+    hipGraph_t g = nullptr;
+    HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue_begin(c, 0, 1, s);
+    int rc = enqueue_layers(c, 0, s, nullptr);
+    enqueue_lm_head(c, s, nullptr);
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * out_tokens, float * elapsed_ms) {
+    bamd_model * m = c->m;
+    if (!m->with_embd || !m->with_output) return fail("bamd_generate_greedy needs a stage that owns embedding and output");
+    if (n_steps < 1 || n_past < 1 || n_past + n_steps > c->n_ctx || n_steps + 1 > c->out_cap) return fail("bad n_past / n_steps");
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = c->stream;
+    if (!c->graph && build_graph(c)) return 1;
+    if (set_state(c, n_past, s, true)) return 1;
+    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, s));
+    for (int t = 0; t < n_steps; ++t) HIPC(hipGraphLaunch(c->graph, s));
+    HIPC(hipEventRecord(e1, s));
+    enqueue_begin(c, 0, 0, s);                                        // flush the last arg-max into out_tokens
+    HIPC(hipMemcpyAsync(out_tokens, c->out_tokens, (size_t) (n_steps + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+// ---- layer-split stage ---------------------------------------------------------------------------------
+extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_context * c, int32_t token, int pos, const void * hidden_in_dev, void * hidden_out_dev,
+                               int want_logits, int prefill_mode, void * hip_stream) {
+    bamd_model * m = c->m;
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
+    // state for exactly this token: pos_base = pos, step = 0, one forced token
+    bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx;
+    HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(c->forced, &token, 4, hipMemcpyHostToDevice, s));
+    if (m->with_embd) enqueue_begin(c, 1, 1, s);
+    else {
+        // no embedding on this stage: still advance the device state (pos, n_kv), then take the hidden state
+        bamd_launch_step_begin(c->st, c->forced, 1, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, s);
+        HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
+    if (m->with_output) { if (want_logits) enqueue_lm_head(c, s, nullptr); }
+    else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token) {
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    bamd_step_state h;
+    HIPC(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    *token = (int32_t) (0xffffffffu - (uint32_t) (h.best_key & 0xffffffffull));
+    return 0;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------------
+extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
+    bamd_model * m = c->m;
+    if (!m->with_embd || !m->with_output) return fail("profile needs a full single-stage model");
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = c->stream;
+    int32_t tok = 1;
+    HIPC(hipMemcpyAsync(c->forced, &tok, 4, hipMemcpyHostToDevice, s));
+    if (set_state(c, pos, s, false)) return 1;
+    StepTimer tm; tm.on = true;
+    tm.begin(s, 2, 0.0); enqueue_begin(c, 1, 1, s); tm.end(s);
+    if (enqueue_layers(c, 0, s, &tm)) return 1;
+    enqueue_lm_head(c, s, &tm);
+    HIPC(hipStreamSynchronize(s));
+    for (int i = 0; i < 3; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
+    const int n_kv = std::min(c->n_ctx, (pos + 1 + 31) / 32 * 32);
+    for (size_t i = 0; i < tm.cls.size(); ++i) {
+        float t = 0.f; hipEventElapsedTime(&t, tm.ev[2 * i], tm.ev[2 * i + 1]);
+        const int k = tm.cls[i];
+        launches[k] += 1; ms[k] += t;
+        bytes[k] += k == 1 ? (double) n_kv * m->Hkv * m->hd * 2 * 2 : tm.bytes[i];
+    }
+    for (auto e : tm.ev) hipEventDestroy(e);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// op-level entry points (host in / host out): thin wrappers that run the SAME kernels on device 0
+// -------------------------------------------------------------------------------------------------------
+struct Tmp {
+    std::vector<void *> p;
+    ~Tmp() { for (void * x : p) hipFree(x); }
+    void * up(const void * h, size_t n) { void * d = nullptr; if (hipMalloc(&d, n ? n : 16) != hipSuccess) return nullptr; p.push_back(d); if (h && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) return nullptr; return d; }
+};
+static int need_device() {
+    if (bamd_device_count() <= 0) return fail("no HIP device available: libbooster_amd has no CPU fallback");
+    HIPC(hipSetDevice(0));
+    return 0;
+}
+static int n_cu0() { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 256; return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+
+extern "C" __attribute__((visibility("default"))) int bamd_op_quantize_q8_K(const float * x, int64_t k, const float * norm_w, float eps, void * out_blocks) {
+    if (need_device()) return 1;
+    if (k <= 0 || k % 256) return fail("k must be a positive multiple of 256");
+    Tmp t; const size_t ob = (size_t) (k / 256) * 292;
+    float * dx = (float *) t.up(x, (size_t) k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr; void * dout = t.up(nullptr, ob);
+    if (!dx || !dout || (norm_w && !dw)) return fail("device alloc/copy failed");
+    HIPC(hipMemset(dout, 0, ob));
+    bamd_launch_quantize_q8k_test(dx, dw, eps, (int) k, norm_w != nullptr, dout, nullptr);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(out_blocks, dout, ob, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int op_matvec(int type, const void * wA, const void * wB, int nrows, int k, const float * x, const float * norm_w, float eps,
+                     const float * residual, float * y, int epi) {
+    if (need_device()) return 1;
+    if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0 || nrows % 8) return fail("bad type/shape");
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
+    void * rawA = t.up(wA, wb), * strA = t.up(nullptr, wb), * rawB = nullptr, * strB = nullptr;
+    if (wB) { rawB = t.up(wB, wb); strB = t.up(nullptr, wb); }
+    float * dx = (float *) t.up(x, (size_t) k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr;
+    float * dres = residual ? (float *) t.up(residual, (size_t) nrows * 4) : nullptr; float * dy = (float *) t.up(nullptr, (size_t) nrows * 4);
+    unsigned long long * key = (unsigned long long *) t.up(nullptr, 8);
+    if (!rawA || !strA || !dx || !dy || !key || (wB && (!rawB || !strB)) || (norm_w && !dw) || (residual && !dres)) return fail("device alloc/copy failed");
+    HIPC(hipMemset(key, 0, 8));
+    bamd_launch_repack(rawA, strA, type, nrows, k, nullptr);
+    if (wB) bamd_launch_repack(rawB, strB, type, nrows, k, nullptr);
+    bamd_mv_args a; memset(&a, 0, sizeof a);
+    a.seg[0].w = strA; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows; a.nseg = 1;
+    if (wB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
+    a.x = dx; a.normw = dw; a.eps = eps; a.K = k; a.res = dres; a.best_key = key;
+    bamd_launch_matvec(a, norm_w ? BAMD_PRO_NORM : BAMD_PRO_PLAIN, epi, n_cu0(), nullptr);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(y, dy, (size_t) nrows * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
+                                   const float * residual, float * y) {
+    return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE);
+}
+extern "C" __attribute__((visibility("default"))) int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
+                                   float eps, float * y) {
+    return op_matvec(type, wg_raw, wu_raw, nrows, k, x, norm_w, eps, nullptr, y, BAMD_EPI_SILU_MUL);
+}
+extern "C" __attribute__((visibility("default"))) int bamd_op_get_row(int type, const void * w_raw, int nrows, int k, int row, float * y) {
+    if (need_device()) return 1;
+    if (row < 0 || row >= nrows) return fail("row out of range");
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
+    void * raw = t.up(w_raw, wb); float * dy = (float *) t.up(nullptr, (size_t) k * 4);
+    bamd_step_state h; memset(&h, 0, sizeof h); h.n_ctx = 32;
+    bamd_step_state * st = (bamd_step_state *) t.up(&h, sizeof h);
+    int32_t * forced = (int32_t *) t.up(&row, 4); int32_t * outt = (int32_t *) t.up(nullptr, 64);
+    if (!raw || !dy || !st || !forced || !outt) return fail("device alloc/copy failed");
+    bamd_launch_step_begin(st, forced, 1, outt, raw, type, k, nrows, dy, 1, nullptr);
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(y, dy, (size_t) k * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_op_rope_row(int pos, int n_dims, float freq_base, float freq_scale, const float * freq_factors, float * row) {
+    rope_row(row, pos, n_dims, freq_base, freq_scale, freq_factors, 0.0f, 1.0f, 8192, 32.0f, 1.0f);
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const float * q, const float * k, const float * v, uint16_t * k_cache, uint16_t * v_cache_t,
+                                 const float * rope_row_h, int H, int Hkv, int hd, int n_ctx, int pos, int prefill_mode, float * out,
+                                 float * probs_h0) {
+    if (need_device()) return 1;
+    if (pos < 0 || pos >= n_ctx || n_ctx % 32 || H % Hkv) return fail("bad attention shape");
+    Tmp t; const int Ekv = Hkv * hd; const size_t kvb = (size_t) n_ctx * Ekv * 2;
+    std::vector<float> rope((size_t) n_ctx * hd, 0.f);
+    memcpy(rope.data() + (size_t) pos * hd, rope_row_h, (size_t) hd * 4);
+    bamd_step_state h; memset(&h, 0, sizeof h); h.pos = pos; h.n_ctx = n_ctx; h.n_kv = std::min(n_ctx, std::max(32, (pos + 1 + 31) / 32 * 32));
+    bamd_attn_args a; memset(&a, 0, sizeof a);
+    a.st = (bamd_step_state *) t.up(&h, sizeof h);
+    a.q = (float *) t.up(q, (size_t) H * hd * 4); a.k = (float *) t.up(k, (size_t) Ekv * 4); a.v = (float *) t.up(v, (size_t) Ekv * 4);
+    a.kc = (unsigned short *) t.up(k_cache, kvb); a.vc = (unsigned short *) t.up(v_cache_t, kvb);
+    a.rope = (float *) t.up(rope.data(), rope.size() * 4); a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
+    if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.out) return fail("device alloc/copy failed");
+    a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
+    if (bamd_launch_attention(a, H / Hkv, std::min(std::max(n_ctx / 64, 1), 32), nullptr)) return fail("unsupported head configuration");
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(out, a.out, (size_t) H * hd * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(k_cache, a.kc, kvb, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(v_cache_t, a.vc, kvb, hipMemcpyDeviceToHost));
+    if (probs_h0) HIPC(hipMemcpy(probs_h0, a.scores, (size_t) h.n_kv * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,131 @@
+// bamd_gguf.cpp — see bamd_gguf.h
+#include "bamd_gguf.h"
+#include "bamd_formats.h"
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+enum { T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64 };
+
+struct Cursor {
+    const uint8_t * p; const uint8_t * end; bool ok = true;
+    template <typename T> T rd() {
+        T v{};
+        if (p + sizeof(T) > end) { ok = false; return v; }
+        memcpy(&v, p, sizeof(T)); p += sizeof(T); return v;
+    }
+    std::string str() {
+        uint64_t n = rd<uint64_t>();
+        if (!ok || p + n > end) { ok = false; return std::string(); }
+        std::string s((const char *) p, (size_t) n); p += n; return s;
+    }
+};
+
+size_t scalar_size(uint32_t t) {
+    switch (t) {
+        case T_U8: case T_I8: case T_BOOL: return 1;
+        case T_U16: case T_I16: return 2;
+        case T_U32: case T_I32: case T_F32: return 4;
+        case T_U64: case T_I64: case T_F64: return 8;
+    }
+    return 0;
+}
+
+bool read_scalar(Cursor & c, uint32_t t, GgufValue & v) {
+    switch (t) {
+        case T_U8:   v.u = c.rd<uint8_t>();  v.i = (int64_t) v.u; v.f = (double) v.u; break;
+        case T_I8:   v.i = c.rd<int8_t>();   v.u = (uint64_t) v.i; v.f = (double) v.i; break;
+        case T_U16:  v.u = c.rd<uint16_t>(); v.i = (int64_t) v.u; v.f = (double) v.u; break;
+        case T_I16:  v.i = c.rd<int16_t>();  v.u = (uint64_t) v.i; v.f = (double) v.i; break;
+        case T_U32:  v.u = c.rd<uint32_t>(); v.i = (int64_t) v.u; v.f = (double) v.u; break;
+        case T_I32:  v.i = c.rd<int32_t>();  v.u = (uint64_t) v.i; v.f = (double) v.i; break;
+        case T_F32:  v.f = c.rd<float>();    v.i = (int64_t) v.f; v.u = (uint64_t) v.i; break;
+        case T_BOOL: v.b = c.rd<uint8_t>() != 0; v.u = v.b; v.i = v.b; break;
+        case T_U64:  v.u = c.rd<uint64_t>(); v.i = (int64_t) v.u; v.f = (double) v.u; break;
+        case T_I64:  v.i = c.rd<int64_t>();  v.u = (uint64_t) v.i; v.f = (double) v.i; break;
+        case T_F64:  v.f = c.rd<double>();   v.i = (int64_t) v.f; v.u = (uint64_t) v.i; break;
+        default: return false;
+    }
+    return c.ok;
+}
+}  // namespace
+
+GgufFile::~GgufFile() {
+    if (map_) munmap((void *) map_, size_);
+    if (fd_ >= 0) close(fd_);
+}
+
+bool GgufFile::open(const std::string & path, std::string & err) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) { err = "cannot open " + path; return false; }
+    struct stat st;
+    if (fstat(fd_, &st) != 0) { err = "fstat failed"; return false; }
+    size_ = (size_t) st.st_size;
+    void * m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+    if (m == MAP_FAILED) { err = "mmap failed"; map_ = nullptr; return false; }
+    map_ = (const uint8_t *) m;
+    Cursor c{map_, map_ + size_};
+    if (size_ < 24 || memcmp(map_, "GGUF", 4) != 0) { err = "not a GGUF file"; return false; }
+    c.p += 4;
+    version = c.rd<uint32_t>();
+    if (version < 2 || version > 3) { err = "unsupported GGUF version"; return false; }
+    const uint64_t n_tensors = c.rd<uint64_t>(), n_kv = c.rd<uint64_t>();
+    for (uint64_t k = 0; k < n_kv && c.ok; ++k) {
+        std::string key = c.str();
+        GgufValue v; v.type = c.rd<uint32_t>();
+        if (v.type == T_STR) v.s = c.str();
+        else if (v.type == T_ARR) {
+            v.arr_type = c.rd<uint32_t>(); v.arr_n = c.rd<uint64_t>();
+            if (v.arr_type == T_STR) {
+                v.arr_s.reserve((size_t) v.arr_n);
+                for (uint64_t i = 0; i < v.arr_n && c.ok; ++i) v.arr_s.push_back(c.str());
+            } else {
+                const size_t sz = scalar_size(v.arr_type);
+                if (!sz || c.p + sz * v.arr_n > c.end) { err = "bad array in KV " + key; return false; }
+                v.arr_data = c.p; c.p += sz * v.arr_n;
+            }
+        } else if (!read_scalar(c, v.type, v)) { err = "bad KV type for " + key; return false; }
+        kv[key] = std::move(v);
+    }
+    if (!c.ok) { err = "truncated GGUF header"; return false; }
+    { uint32_t a; if (get_u32("general.alignment", a) && a) alignment = a; }
+    tensors.resize((size_t) n_tensors);
+    for (auto & t : tensors) {
+        t.name = c.str();
+        const uint32_t nd = c.rd<uint32_t>();
+        if (nd > 4) { err = "bad n_dims"; return false; }
+        for (uint32_t d = 0; d < nd; ++d) t.ne.push_back((int64_t) c.rd<uint64_t>());
+        t.type = (int) c.rd<uint32_t>();
+        t.offset = c.rd<uint64_t>();
+    }
+    if (!c.ok) { err = "truncated GGUF tensor table"; return false; }
+    const size_t meta = (size_t) (c.p - map_);
+    const size_t data_off = (meta + alignment - 1) / alignment * alignment;
+    for (size_t i = 0; i < tensors.size(); ++i) {
+        auto & t = tensors[i];
+        int64_t rows = 1; for (size_t d = 1; d < t.ne.size(); ++d) rows *= t.ne[d];
+        const bool known = t.type == BAMD_F32 || t.type == BAMD_F16 || bamd_is_kquant(t.type);
+        t.nbytes = known ? bamd_row_bytes(t.type, t.ne.empty() ? 0 : t.ne[0]) * (size_t) rows : 0;
+        if (data_off + t.offset + t.nbytes > size_) { err = "tensor " + t.name + " out of file bounds"; return false; }
+        t.data = map_ + data_off + t.offset;
+        index_[t.name] = i;
+    }
+    return true;
+}
+
+const GgufValue * GgufFile::find(const std::string & key) const { auto it = kv.find(key); return it == kv.end() ? nullptr : &it->second; }
+bool GgufFile::get_u32(const std::string & key, uint32_t & v) const {
+    const GgufValue * x = find(key); if (!x || x->type == T_STR || x->type == T_ARR) return false; v = (uint32_t) x->u; return true;
+}
+bool GgufFile::get_f32(const std::string & key, float & v) const {
+    const GgufValue * x = find(key); if (!x || x->type == T_STR || x->type == T_ARR) return false; v = (float) x->f; return true;
+}
+bool GgufFile::get_str(const std::string & key, std::string & v) const {
+    const GgufValue * x = find(key); if (!x || x->type != T_STR) return false; v = x->s; return true;
+}
+const GgufTensor * GgufFile::tensor(const std::string & name) const {
+    auto it = index_.find(name); return it == index_.end() ? nullptr : &tensors[it->second];
+}

@@ -1,0 +1,47 @@
+// bamd_kernels.h — host-visible launch interface of bamd_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { BAMD_PRO_PLAIN = 0, BAMD_PRO_NORM = 1 };
+enum { BAMD_EPI_STORE = 0, BAMD_EPI_ADD = 1, BAMD_EPI_SILU_MUL = 2, BAMD_EPI_ARGMAX = 3 };
+
+// device-resident decode state: lets a whole decode step (and a captured hipGraph of it) run without host input
+struct bamd_step_state {
+    int32_t pos_base;              // position of the token of step 0
+    int32_t step;                  // steps begun so far
+    int32_t pos, n_kv, token;      // this step: position, padded KV length (llama.cpp:14693-14701), token id
+    int32_t n_ctx;
+    int32_t n_out;                 // arg-max tokens appended to out_tokens so far
+    int32_t pad_;
+    unsigned long long best_key;   // arg-max key of the last lm_head (0 = none)
+};
+
+struct bamd_mv_seg { const void * w; float * out; int type; int nrows; };
+struct bamd_mv_args {
+    bamd_mv_seg seg[3]; int nseg;
+    const float * x;               // f32 activation [K]
+    const float * normw;           // RMSNorm weight (BAMD_PRO_NORM)
+    float eps; int K;
+    const float * res;             // residual (BAMD_EPI_ADD), indexed like seg[0].out
+    unsigned long long * best_key; // BAMD_EPI_ARGMAX
+};
+
+struct bamd_attn_args {
+    const bamd_step_state * st;
+    const float * q, * k, * v;     // f32 [H*hd], [Hkv*hd], [Hkv*hd] of this token (pre-RoPE)
+    unsigned short * kc, * vc;     // f16 caches of this layer: K [n_ctx][Hkv*hd], V^T [Hkv*hd][n_ctx]
+    const float * rope;            // [n_ctx][hd] (cos,sin) pairs
+    float * scores;                // [H][n_ctx] scratch: scores, then probabilities
+    float * out;                   // [H*hd]
+    int hd, Hkv, n_ctx;
+    float kq_scale;
+    int prefill_mode;              // 1: KQ with the T>1 semantics of the reference (q -> f16, ggml_vec_dot_f16)
+};
+
+void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K, hipStream_t s);
+void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s);
+void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipStream_t s);
+void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
+                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s);
+int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);

@@ -1,0 +1,102 @@
+/* bamd.h — C-ABI of libbooster_amd.so, level 1: the model-runtime calls that Booster's bridge makes.
+ *
+ * This is the layer the reference's cpp/bridge.cpp and cpp/janus.cpp call through cpp/include/llama.h
+ * (SURVEY.md §8b "below the boundary"); every entry point names the llama.h function it replaces.  Plain C
+ * types only: pointers are HOST pointers unless the name says `dev`.  All functions return 0 on success or a
+ * non-zero error code unless documented otherwise; bamd_last_error() gives the message.  There is NO CPU
+ * fallback: without a usable MI355X-class HIP device every compute entry point fails loudly.
+ *
+ * The nine cgo symbols of cpp/bridge.h are declared in booster_bridge.h and implemented on top of this.
+ */
+#ifndef BAMD_H
+#define BAMD_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bamd_model   bamd_model;
+typedef struct bamd_context bamd_context;
+
+/* ggml tensor type ids, as stored in GGUF (cpp/ggml/include/ggml.h:360-375) */
+enum { BAMD_TYPE_F32 = 0, BAMD_TYPE_F16 = 1, BAMD_TYPE_Q4_K = 12, BAMD_TYPE_Q5_K = 13, BAMD_TYPE_Q6_K = 14 };
+
+const char * bamd_last_error(void);
+
+/* llama_backend_init (llama.h) / ggml_backend_cuda_get_device_count (ggml-cuda.h:30): number of HIP devices, <0 on error */
+int bamd_backend_init(void);
+int bamd_device_count(void);
+
+/* llama_load_model_from_file (cpp/src/llama.cpp:16539).  Loads layers [layer_first, layer_last) of a GGUF Llama
+ * model onto HIP device `device` (layer_last < 0: all).  with_embd / with_output say whether this stage owns the
+ * token-embedding lookup and output_norm + lm_head (layer split: first / last stage — llama.cpp:5932-5969). */
+bamd_model * bamd_model_load(const char * gguf_path, int device, int layer_first, int layer_last, int with_embd, int with_output);
+void         bamd_model_free(bamd_model * m);                           /* llama_free_model */
+int          bamd_model_n_vocab(const bamd_model * m);                  /* llama_n_vocab */
+int          bamd_model_n_embd(const bamd_model * m);                   /* llama_n_embd */
+int          bamd_model_n_layer(const bamd_model * m);                  /* llama_n_layer (whole model) */
+int          bamd_model_n_ctx_train(const bamd_model * m);              /* llama_n_ctx_train */
+int64_t      bamd_model_weight_bytes(const bamd_model * m);             /* bytes of matmul weights resident on this stage */
+/* copy back the GGUF-layout bytes of one resident tensor (testing / oracle cross-checks); returns bytes or <0 */
+int64_t      bamd_model_tensor_raw(const bamd_model * m, const char * name, void * dst, int64_t cap);
+
+/* llama_new_context_with_model (llama.cpp:16592): f16 KV cache for n_ctx positions, scratch, RoPE table. */
+bamd_context * bamd_context_new(bamd_model * m, int n_ctx);
+void           bamd_context_free(bamd_context * c);                     /* llama_free */
+int            bamd_n_ctx(const bamd_context * c);                      /* llama_n_ctx */
+void           bamd_kv_cache_clear(bamd_context * c);                   /* llama_kv_cache_clear (llama.cpp:3230) */
+
+/* llama_decode(ctx, llama_batch_get_one(tokens, n_tokens, n_past, 0)) (llama.cpp:18517, :14537).
+ * Processes the tokens at positions n_past.. with the reference's semantics for a micro-batch of n_tokens
+ * (n_tokens > 1: attention scores use the f16-rounded q of the reference's T>1 path) and leaves the logits of
+ * the LAST token for bamd_get_logits.  Returns 0, or 1 on failure like llama_decode. */
+int           bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past);
+const float * bamd_get_logits(bamd_context * c);                        /* llama_get_logits: host, n_vocab floats */
+
+/* Greedy decode entirely on the device: n_steps single-token steps starting at position n_past; step 0 consumes
+ * the arg-max of the logits left by the previous bamd_decode/bamd_generate_greedy call.  out_tokens receives
+ * n_steps+1 ids: the token fed to each step, then the arg-max after the last step.  One hipGraph per step,
+ * no host round trip between steps.  *elapsed_ms (optional) = HIP-event time of the n_steps steps. */
+int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * out_tokens, float * elapsed_ms);
+
+/* ---- layer-split stage interface (one process per GPU; hidden state moves between stages) ---- */
+/* Run this stage's layers on one token.  hidden_in_dev: f32 [n_embd] device pointer (ignored on the first
+ * stage, which embeds `token`); hidden_out_dev: f32 [n_embd] device pointer (ignored on the last stage, which
+ * computes logits + arg-max instead).  Work is enqueued on `hip_stream` (a hipStream_t, may be NULL) and NOT
+ * synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
+int bamd_stage_step(bamd_context * c, int32_t token, int pos, const void * hidden_in_dev, void * hidden_out_dev,
+                    int want_logits, int prefill_mode, void * hip_stream);
+/* arg-max token of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
+int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token);
+
+/* ---- measurement -------------------------------------------------------------------------------------- */
+/* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.
+ * classes: 0 matvec (all weight streaming), 1 attention (qk+softmax+pv), 2 step-begin/other.
+ * For each class: launches[], ms[] (sum of durations), bytes[] (algorithmic bytes: weight records streamed /
+ * KV bytes read).  Arrays must hold 3 entries. */
+int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes);
+
+/* ---- op-level entry points (parity tests call the kernels through these; host pointers in, host out) ---- */
+/* quantize_row_q8_K (ggml-quants.c:3593) of norm_w ? rms_norm(x)*norm_w : x ; out = k/256 block_q8_K (292 B each) */
+int bamd_op_quantize_q8_K(const float * x, int64_t k, const float * norm_w, float eps, void * out_blocks);
+/* y[nrows] = W . Q8_K(act) (+ residual), W = GGUF-layout blocks [nrows][k] of `type`  (ggml_compute_forward_mul_mat, ggml.c:12277) */
+int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
+                        const float * residual, float * y);
+/* y[nrows] = silu(Wg . a) * (Wu . a)  (llm_build_ffn LLM_FFN_SILU/LLM_FFN_PAR, llama.cpp:7960-8085) */
+int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
+                        float eps, float * y);
+/* one row of a GGUF matrix dequantised (ggml_compute_forward_get_rows_q, ggml.c:13186) */
+int bamd_op_get_row(int type, const void * w_raw, int nrows, int k, int row, float * y);
+/* single-token attention of one layer (llm_build_kv, llama.cpp:8318): ropes q/k with the table row `pos`, stores
+ * k/v (f16) into the caches, returns out[H*hd]; caches are host arrays in the reference's layouts and are updated. */
+int bamd_op_attention(const float * q, const float * k, const float * v, uint16_t * k_cache, uint16_t * v_cache_t,
+                      const float * rope_row, int H, int Hkv, int hd, int n_ctx, int pos, int prefill_mode, float * out,
+                      float * probs_h0);
+/* RoPE (cos,sin) table row as built on the host for position pos (ggml_rope_cache_init, ggml.c:14017) */
+int bamd_op_rope_row(int pos, int n_dims, float freq_base, float freq_scale, const float * freq_factors, float * row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,35 @@
+"""CPU: numpy GGUF reader/writer (host utility) — round trip and the reference-written fixture."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from booster_amd import gguf
+
+
+def test_read_reference_written_file():
+    r = gguf.GGUFReader(os.path.join(GOLDEN, "tiny_a.gguf"))
+    assert r.kv["general.architecture"] == "llama"
+    assert r.kv["llama.embedding_length"] == 512 and r.kv["llama.block_count"] == 2
+    t = r.tensors["blk.0.attn_v.weight"]
+    assert t["type"] == gguf.Q6_K and t["shape"] == [512, 128] and t["data"].size == 128 * 2 * 210
+    assert r.tensors["blk.1.attn_v.weight"]["type"] == gguf.Q5_K
+    assert r.tensors["output_norm.weight"]["data"].view(np.float32).shape == (512,)
+
+
+def test_writer_roundtrip(tmp_path):
+    p = str(tmp_path / "syn.gguf")
+    gguf.write_synthetic_llama(p, E=256, H=2, Hkv=1, L=3, F=512, V=64, seed=5, rope_freqs=True)
+    r = gguf.GGUFReader(p)
+    assert r.kv["llama.attention.head_count_kv"] == 1 and r.kv["tokenizer.ggml.model"] == "no_vocab"
+    assert len(r.tensors) == 3 + 1 + 3 * 9
+    assert r.tensors["output.weight"]["type"] == gguf.Q6_K
+    assert r.tensors["blk.2.ffn_down.weight"]["shape"] == [512, 256]
+    assert abs(float(r.kv["llama.rope.freq_base"]) - 500000.0) < 1e-3
+
+
+def test_q4_k_m_recipe():
+    # 8B: 16 of 32 layers carry Q6_K attn_v / ffn_down (SURVEY §8 header)
+    n = sum(gguf.q4_k_m_type("ffn_down", il, 32) == gguf.Q6_K for il in range(32))
+    assert n == 16
+    assert gguf.q4_k_m_type("attn_q", 0, 32) == gguf.Q4_K and gguf.q4_k_m_type("output", 0, 32) == gguf.Q6_K

@@ -1,0 +1,177 @@
+"""GPU: every HIP kernel, called through the C-ABI (include/bamd.h bamd_op_*), against the CPU oracle on the same
+seeded inputs.  Integer/byte results and f32 results alike must be BIT-IDENTICAL (the kernels restate the
+reference's AVX2 operation order), so every comparison is on the raw bits."""
+import numpy as np
+import pytest
+
+from booster_amd.gguf import random_kquant_tensor
+
+pytestmark = pytest.mark.gpu
+TYPES = [12, 13, 14]
+BB = {12: 144, 13: 176, 14: 210}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits(a, b, what=""):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    bad = np.flatnonzero(bits(a) != bits(b))
+    assert bad.size == 0, "%s: %d/%d elements differ, first at %d: %r vs %r" % (what, bad.size, a.size, bad[0], a.flat[bad[0]], b.flat[bad[0]])
+
+
+@pytest.mark.parametrize("K", [256, 768, 4096, 14336])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 80.0])
+def test_quantize_q8_K(bamd, po, K, scale):
+    rng = np.random.default_rng(K)
+    x = (rng.standard_normal(K) * scale).astype(np.float32)
+    if K >= 768:
+        x[256:512] = 0.0                                   # all-zero block
+    x[3] = -np.abs(x).max() * 2                            # negative extremum
+    x[700 % K] = x[(700 % K) - 1] = np.float32(1.25)       # ties
+    got = bamd.op_quantize_q8_K(x)
+    want = po.quantize_q8_K(x)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("K", [512, 4096])
+def test_rmsnorm_quantize(bamd, po, K):
+    rng = np.random.default_rng(K + 1)
+    for trial in range(4):
+        x = (rng.standard_normal(K) * 10 ** rng.uniform(-2, 2)).astype(np.float32)
+        w = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+        eps = 1e-5
+        got = bamd.op_quantize_q8_K(x, norm_w=w, eps=eps)
+        y = po.rms_norm(x, eps) * w
+        assert np.array_equal(got, po.quantize_q8_K(y.astype(np.float32)))
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (4096, 512), (14336, 64)])
+def test_mul_mat_vec(bamd, po, t, K, rows):
+    rng = np.random.default_rng(1000 * t + K)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = (rng.standard_normal(K) * 3).astype(np.float32)
+    got = bamd.op_mul_mat_vec(t, W, rows, K, x)
+    want = po.mul_mat_q(t, W, rows, K, x)[0]
+    assert_bits(got, want, "mul_mat_vec type %d K %d" % (t, K))
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_mul_mat_vec_kats(bamd, kats, t):
+    """reference-quantised weights + the reference's own dot products (committed fixture)"""
+    name = {12: "q4_K", 13: "q5_K", 14: "q6_K"}[t]
+    for K in (256, 768, 4096):
+        key = "%s_K%d" % (name, K)
+        blocks, x, dots = kats[key + "_blocks"], kats[key + "_x"], kats[key + "_dots"]
+        got = bamd.op_mul_mat_vec(t, blocks, dots.size, K, x)
+        assert_bits(got, dots, key)
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_mul_mat_vec_norm_residual(bamd, po, t):
+    K, rows = 1024, 256
+    rng = np.random.default_rng(77 + t)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = rng.standard_normal(K).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    res = rng.standard_normal(rows).astype(np.float32)
+    got = bamd.op_mul_mat_vec(t, W, rows, K, x, norm_w=w, eps=1e-5, residual=res)
+    a = (po.rms_norm(x, 1e-5) * w).astype(np.float32)
+    want = po.mul_mat_q(t, W, rows, K, a)[0] + res
+    assert_bits(got, want, "norm+residual")
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024)])
+def test_ffn_gate_up(bamd, po, t, K, rows):
+    rng = np.random.default_rng(5 * t + K)
+    Wg = random_kquant_tensor(t, K, rows, rng, amp=4.0)
+    Wu = random_kquant_tensor(t, K, rows, rng, amp=4.0)
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    got = bamd.op_ffn_gate_up(t, Wg, Wu, rows, K, x, norm_w=w, eps=1e-5)
+    a = (po.rms_norm(x, 1e-5) * w).astype(np.float32)
+    g = po.mul_mat_q(t, Wg, rows, K, a)[0]
+    u = po.mul_mat_q(t, Wu, rows, K, a)[0]
+    L = po.lib()
+    want = np.array([L.bo_v_silu(float(v)) for v in g], np.float32) * u
+    assert_bits(got, want, "ffn gate/up")
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_get_row(bamd, po, t):
+    K, rows = 768, 24
+    rng = np.random.default_rng(t)
+    W = random_kquant_tensor(t, K, rows, rng)
+    rb = K // 256 * BB[t]
+    for row in (0, 7, 23):
+        got = bamd.op_get_row(t, W, rows, K, row)
+        assert_bits(got, po.dequantize(t, W[row * rb:(row + 1) * rb], K), "get_row")
+
+
+def test_rope_row(bamd, po):
+    ff = (1 + np.arange(64) / 16.0).astype(np.float32)
+    for pos in (0, 1, 127, 2047, 8191):
+        for theta in (500000.0, 10000.0):
+            assert_bits(bamd.op_rope_row(pos, 128, theta), po.rope_cache(pos, 128, theta))
+            assert_bits(bamd.op_rope_row(pos, 128, theta, 1.0, ff), po.rope_cache(pos, 128, theta, 1.0, ff))
+
+
+def oracle_attention(po, q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill):
+    """llm_build_kv for one token with the oracle's primitives; updates kc/vc (numpy uint16) in place."""
+    import ctypes as C
+    L = po.lib()
+    q = q.copy(); k = k.copy()
+    for h in range(H):
+        L.bo_rope_apply(q[h * hd:].ctypes.data_as(C.c_void_p), rope.ctypes.data_as(C.c_void_p), hd)
+    for h in range(Hkv):
+        L.bo_rope_apply(k[h * hd:].ctypes.data_as(C.c_void_p), rope.ctypes.data_as(C.c_void_p), hd)
+    Ekv = Hkv * hd
+    kc[pos * Ekv:(pos + 1) * Ekv] = k.astype(np.float16).view(np.uint16)
+    vc.reshape(Ekv, n_ctx)[:, pos] = v.astype(np.float16).view(np.uint16)
+    n_kv = min(n_ctx, max(32, (pos + 1 + 31) // 32 * 32))
+    mask = np.where(np.arange(n_kv) <= pos, 0.0, -np.inf).astype(np.float32)
+    out = np.zeros(H * hd, np.float32)
+    probs0 = None
+    gq = H // Hkv
+    for h in range(H):
+        hk = h // gq
+        qh = np.ascontiguousarray(q[h * hd:(h + 1) * hd])
+        s = np.zeros(n_kv, np.float32)
+        q16 = qh.astype(np.float16).view(np.uint16)
+        for i in range(n_kv):
+            krow = np.ascontiguousarray(kc[i * Ekv + hk * hd: i * Ekv + (hk + 1) * hd])
+            if prefill:
+                s[i] = L.bo_vec_dot_f16(hd, krow.ctypes.data_as(C.c_void_p), q16.ctypes.data_as(C.c_void_p))
+            else:
+                s[i] = L.bo_dot_f16_f32_tinyblas(krow.ctypes.data_as(C.c_void_p), qh.ctypes.data_as(C.c_void_p), hd)
+        p = po.soft_max(s, mask, np.float32(1.0) / np.sqrt(np.float32(hd)))
+        if h == 0:
+            probs0 = p
+        for d in range(hd):
+            vrow = np.ascontiguousarray(vc.reshape(Ekv, n_ctx)[hk * hd + d, :n_kv])
+            out[h * hd + d] = L.bo_dot_f16_f32_tinyblas(vrow.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), n_kv)
+    return out, probs0
+
+
+@pytest.mark.parametrize("H,Hkv,hd", [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 32)])
+@pytest.mark.parametrize("prefill", [False, True])
+def test_attention(bamd, po, H, Hkv, hd, prefill):
+    n_ctx = 256
+    rng = np.random.default_rng(H * 100 + hd + prefill)
+    Ekv = Hkv * hd
+    for pos in (0, 5, 31, 32, 100, 255):
+        kc = (rng.standard_normal(n_ctx * Ekv) * 0.7).astype(np.float16).view(np.uint16).copy()
+        vc = rng.standard_normal(Ekv * n_ctx).astype(np.float16).view(np.uint16).copy()
+        q = (rng.standard_normal(H * hd) * 2).astype(np.float32)
+        k = rng.standard_normal(Ekv).astype(np.float32)
+        v = rng.standard_normal(Ekv).astype(np.float32)
+        rope = po.rope_cache(pos, hd, 500000.0)
+        kc2, vc2 = kc.copy(), vc.copy()
+        want, wprobs = oracle_attention(po, q, k, v, kc2, vc2, rope, H, Hkv, hd, n_ctx, pos, prefill)
+        got, gprobs = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill, want_probs=True)
+        assert np.array_equal(kc, kc2) and np.array_equal(vc, vc2), "KV store differs at pos %d" % pos
+        assert_bits(gprobs[:wprobs.size], wprobs, "softmax pos %d" % pos)
+        assert_bits(got, want, "attention out pos %d" % pos)
