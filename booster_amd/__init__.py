@@ -26,6 +26,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise BamdError("libbooster_amd.so is not built (python -m booster_amd.build); there is no CPU fallback")
+        # PyTorch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both own the GPU, and the
+        # first one loaded wins the SONAME.  Import torch first so that both sides share torch's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, ci, cf, i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
         L.bamd_last_error.restype = C.c_char_p

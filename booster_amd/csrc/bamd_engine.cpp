@@ -449,7 +449,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
                                int want_logits, int prefill_mode, void * hip_stream) {
     bamd_model * m = c->m;
     HIPC(hipSetDevice(m->device));
-    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
     // state for exactly this token: pos_base = pos, step = 0, one forced token
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx;
@@ -467,7 +467,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token) {
-    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->stream;
+    hipStream_t s = (hipStream_t) hip_stream;
     bamd_step_state h;
     HIPC(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));

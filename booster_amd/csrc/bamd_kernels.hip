@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, c
             st->n_kv = n_kv;
             st->step = step + 1;
         }
-        st->best_key = 0ull;
+        if (do_embed) st->best_key = 0ull;                   // a flush-only call leaves the key for the next generate call
         tok_s = tok;
     }
     __syncthreads();

@@ -63,8 +63,8 @@ int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * ou
 /* ---- layer-split stage interface (one process per GPU; hidden state moves between stages) ---- */
 /* Run this stage's layers on one token.  hidden_in_dev: f32 [n_embd] device pointer (ignored on the first
  * stage, which embeds `token`); hidden_out_dev: f32 [n_embd] device pointer (ignored on the last stage, which
- * computes logits + arg-max instead).  Work is enqueued on `hip_stream` (a hipStream_t, may be NULL) and NOT
- * synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
+ * computes logits + arg-max instead).  Work is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream)
+ * and NOT synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
 int bamd_stage_step(bamd_context * c, int32_t token, int pos, const void * hidden_in_dev, void * hidden_out_dev,
                     int want_logits, int prefill_mode, void * hip_stream);
 /* arg-max token of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
