@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s, Llama-3-8B Q4_K_M shapes, greedy batch-1 decode (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one decoded token through the whole hot path (32 layers + lm_head + arg-max), weights and KV cache
+resident in HBM, token feedback on the device.  Synthetic GGUF with the exact tensor names / shapes / K-quant types
+of Llama-3-8B Q4_K_M (random blocks), 128-token prompt, n_ctx 512.
+
+N = 1: the whole model on one GPU, K steps replayed from one hipGraph per step.
+N > 1: Booster's `gpus:` layer split (llama.cpp:5932-5969), one process per GPU: rank r owns a contiguous layer
+       range, its KV slice, (rank 0) the embedding, (last rank) output_norm + lm_head.  The f32 hidden state
+       [n_embd] moves with ONE RCCL send/recv per boundary (torch.distributed, backend nccl = RCCL over xGMI); the
+       arg-max token returns from the last rank to rank 0 with one more send/recv.  N sequences are kept in flight
+       (pipeline over independent requests — Booster's pods), so every GPU streams its weight slice continuously:
+       per-GPU work is fixed as N grows ("weak").  The single-sequence (latency-bound) rate is reported beside it.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the quantised mat-vec, all weight streaming):
+achieved = algorithmic weight bytes per launch / mean launch duration, measured here with HIP events around every
+launch of an eager step.  `cpu_baseline` times the oracle (a port of the reference CPU path) on this box's host
+cores on a bounded sample (2 of 32 layers + lm_head, extrapolated), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG_8B = dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, theta=500000.0, eps=1e-5, n_ctx_train=8192)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+N_PROMPT, N_CTX = 128, 512
+KV_BYTES_PER_POS = 2 * 32 * 8 * 128 * 2
+
+
+def model_path():
+    for d in ("/dev/shm", "/tmp"):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            try:
+                st = os.statvfs(d)
+                if st.f_bavail * st.f_frsize > 7 << 30:
+                    return os.path.join(d, "bamd_llama3_8b_q4_k_m_synth.gguf")
+            except OSError:
+                pass
+    return "/tmp/bamd_llama3_8b_q4_k_m_synth.gguf"
+
+
+def ensure_model(path, rank):
+    from booster_amd import gguf
+    done = path + ".done"
+    if rank == 0 and not os.path.exists(done):
+        t0 = time.time()
+        gguf.write_synthetic_llama(path, seed=7, reuse_layers=True, **CFG_8B)
+        open(done, "w").write("ok")
+        sys.stderr.write("[bench] wrote %s (%.1f GB) in %.1f s\n" % (path, os.path.getsize(path) / 1e9, time.time() - t0))
+    return path
+
+
+def split_layers(L, n):
+    """Booster's gpus: semantic with equal weights (llama.cpp:5954-5958: upper_bound over the cumulative split)."""
+    cuts = [int(round(L * (i + 1) / n)) for i in range(n)]
+    first = [0] + cuts[:-1]
+    return list(zip(first, cuts))
+
+
+def cpu_baseline(path, nthreads):
+    """The oracle (port of the reference CPU path) on a bounded sample: decode steps through the first 1 and 2 layers
+    + lm_head, extrapolated to 32 layers.  Checker code only — never part of the measured GPU path."""
+    from oracle import pyoracle as po
+    from booster_amd.gguf import GGUFReader
+    r = GGUFReader(path)
+    times = {}
+    for nl in (1, 2):
+        m = po.OracleModel(r, n_layers=nl)
+        c = po.OracleContext(m, 64, nthreads=nthreads)
+        c.decode([13], 0)                                 # touch pages / warm caches
+        t0 = time.perf_counter()
+        reps = 3
+        for i in range(reps):
+            c.decode([(7919 * i + 13) % CFG_8B["V"]], 1 + i)
+        times[nl] = (time.perf_counter() - t0) / reps
+        c.close()
+    per_layer = max(times[2] - times[1], 1e-9)
+    head = max(times[1] - per_layer, 0.0)
+    t_tok = head + CFG_8B["L"] * per_layer
+    return dict(value=round(1.0 / t_tok, 4), unit="tokens/s", cores=nthreads, kind="port",
+                sample="oracle (C restatement of the reference CPU path, %d OpenMP threads): 3 decode steps each through 1 and 2 of 32 "
+                       "layers + lm_head of the same GGUF; per-layer %.1f ms, lm_head+embed %.1f ms, extrapolated to 32 layers"
+                       % (nthreads, per_layer * 1e3, head * 1e3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    import torch
+    import booster_amd
+    from booster_amd import build as bbuild
+    if rank == 0:
+        bbuild.build()
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        assert world == N, "launch with torch.distributed.run --nproc-per-node %d" % N
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    path = model_path()
+    ensure_model(path, rank)
+    if dist is not None:
+        dist.barrier()
+    steps, warmup = args.steps, args.warmup
+    assert N_PROMPT + warmup + steps + 2 <= N_CTX, "steps + warmup must fit n_ctx=%d after the %d-token prompt" % (N_CTX, N_PROMPT)
+    prompt = [(7919 * i + 13) % CFG_8B["V"] for i in range(N_PROMPT)]
+    result = {}
+
+    if N == 1:
+        t0 = time.time()
+        m = booster_amd.Model(path, device=0)
+        ctx = booster_amd.Context(m, N_CTX)
+        sys.stderr.write("[bench] model resident: %.3f GB of matmul weights, load %.1f s\n" % (m.weight_bytes / 1e9, time.time() - t0))
+        ctx.decode(prompt, 0)                                              # prefill (untimed)
+        n_past = N_PROMPT
+        if warmup > 0:
+            ctx.generate_greedy(n_past, warmup); n_past += warmup
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks, ev_ms = ctx.generate_greedy(n_past, steps)                   # K hipGraph replays, no host round trips
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_past += steps
+        tok_s = steps / dt
+        # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length
+        L_, MS_, B_ = np.zeros(3), np.zeros(3), np.zeros(3)
+        for i in range(4):
+            l, ms, b = ctx.profile_step(n_past - 1)
+            L_ += l; MS_ += ms; B_ += b
+        mv_bytes_per_launch = B_[0] / L_[0]
+        mv_ms_per_launch = MS_[0] / L_[0]
+        achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
+        n_kv_avg = N_PROMPT + warmup + steps / 2.0
+        bytes_per_token = m.weight_bytes + KV_BYTES_PER_POS * n_kv_avg
+        result = dict(
+            value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
+            config=dict(workload="Llama-3-8B Q4_K_M shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
+                                 "128-token prompt, n_ctx 512, n_kv %d..%d" % (N_PROMPT + warmup, n_past),
+                        parallelism="single GPU", graph_event_ms_per_step=round(ev_ms / steps, 4),
+                        bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
+                        time_split_ms_per_token=dict(matvec=round(MS_[0] / 4, 4), attention=round(MS_[1] / 4, 4), other=round(MS_[2] / 4, 4)),
+                        launches_per_token=int(L_.sum() / 4)),
+            roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                          traffic=None, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
+                          bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
+        )
+        if not args.no_cpu_baseline:
+            try:
+                try:
+                    ncpu = len(os.sched_getaffinity(0))
+                except AttributeError:
+                    ncpu = os.cpu_count() or 1
+                result["cpu_baseline"] = cpu_baseline(path, max(1, min(ncpu, 32)))
+            except Exception as e:      # the checker must never take the bench down
+                result["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=0, kind="port", sample="failed: %r" % (e,))
+        ctx.close(); m.close()
+    else:
+        from booster_amd import pipeline
+        result = pipeline.run_layer_split_bench(path, CFG_8B, N, rank, local, prompt, N_CTX, warmup, steps, dist, torch)
+
+    if rank == 0:
+        out = dict(metric="decode tokens/sec Llama-3-8B Q4_K_M", value=result.pop("value"), unit="tokens/s", n_gpus=N, steps=steps,
+                   warmup=warmup, ms_per_step=result.pop("ms_per_step"), higher_is_better=True, scaling=result.pop("scaling"),
+                   vs_baseline=None, dtype="int8xint4/6 dot -> f32 (Q4_K/Q6_K weights x Q8_K activations), f16 KV", data="synthetic")
+        out.update(result)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

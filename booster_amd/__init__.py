@@ -51,8 +51,9 @@ def lib():
         L.bamd_stage_step.argtypes = [vp, C.c_int32, ci, vp, vp, ci, ci, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
+        L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
-        L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp]
+        L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp, ci]
         L.bamd_op_ffn_gate_up.argtypes = [ci, vp, vp, ci, ci, vp, vp, cf, vp]
         L.bamd_op_get_row.argtypes = [ci, vp, ci, ci, ci, vp]
         L.bamd_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
@@ -137,6 +138,12 @@ class Context:
         return int(t.value)
 
 
+def bench_matvec(ttype, nrows, k, pro=0, epi=0, mode=0, iters=200):
+    us = C.c_float(0)
+    _chk(lib().bamd_bench_matvec(ttype, nrows, k, pro, epi, mode, iters, C.byref(us)))
+    return float(us.value)
+
+
 # ---- op-level wrappers (parity tests) ------------------------------------------------------------------------
 def op_quantize_q8_K(x, norm_w=None, eps=0.0):
     x = np.ascontiguousarray(x, np.float32)
@@ -146,13 +153,13 @@ def op_quantize_q8_K(x, norm_w=None, eps=0.0):
     return out
 
 
-def op_mul_mat_vec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None):
+def op_mul_mat_vec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, mode=0):
     w_raw = np.ascontiguousarray(w_raw, np.uint8)
     x = np.ascontiguousarray(x, np.float32)
     nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
     res = None if residual is None else np.ascontiguousarray(residual, np.float32)
     y = np.zeros(nrows, np.float32)
-    _chk(lib().bamd_op_mul_mat_vec(ttype, _p(w_raw), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y)))
+    _chk(lib().bamd_op_mul_mat_vec(ttype, _p(w_raw), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y), mode))
     return y
 
 
@@ -179,12 +186,12 @@ def op_rope_row(pos, n_dims, freq_base, freq_scale=1.0, freq_factors=None):
     return row
 
 
-def op_attention(q, k, v, k_cache, v_cache_t, rope_row, H, Hkv, hd, n_ctx, pos, prefill_mode=False, want_probs=False):
+def op_attention(q, k, v, k_cache, v_cache_t, rope_row, H, Hkv, hd, n_ctx, pos, prefill_mode=False, want_probs=False, long_path=False):
     q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
     rope_row = np.ascontiguousarray(rope_row, np.float32)
     assert k_cache.dtype == np.uint16 and v_cache_t.dtype == np.uint16 and k_cache.flags.c_contiguous and v_cache_t.flags.c_contiguous
     out = np.zeros(H * hd, np.float32)
     probs = np.zeros(n_ctx, np.float32) if want_probs else None
-    _chk(lib().bamd_op_attention(_p(q), _p(k), _p(v), _p(k_cache), _p(v_cache_t), _p(rope_row), H, Hkv, hd, n_ctx, pos, int(prefill_mode),
+    _chk(lib().bamd_op_attention(_p(q), _p(k), _p(v), _p(k_cache), _p(v_cache_t), _p(rope_row), H, Hkv, hd, n_ctx, pos, int(prefill_mode) | (2 if (long_path or want_probs) else 0),
                                  _p(out), _p(probs)))
     return (out, probs) if want_probs else out

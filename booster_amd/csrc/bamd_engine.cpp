@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -20,6 +21,7 @@
 #include <vector>
 
 static thread_local std::string g_err;
+static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return e && e[0] == '1'; }();
 static int fail(const std::string & m) { g_err = m; return 1; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
@@ -122,7 +124,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_device_count(void) {
 extern "C" __attribute__((visibility("default"))) int bamd_backend_init(void) { return bamd_device_count(); }
 
 // upload one matrix: raw bytes -> (optional raw copy) + wave-stream repack on the device
-static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool keep_raw, bool want_stream, void * staging, hipStream_t s) {
+static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool keep_raw, bool want_stream, void * staging, hipStream_t s,
+                      void * stream_dst = nullptr) {
     if (t->ne.size() != 2) return fail("tensor " + t->name + ": expected 2 dims");
     d.type = t->type; d.K = (int) t->ne[0]; d.nrows = (int) t->ne[1]; d.bytes = t->nbytes;
     if (want_stream) {
@@ -133,7 +136,8 @@ static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool kee
     if (keep_raw) { if (dev_alloc(m->allocs, &d.raw, t->nbytes)) return 1; rawdev = d.raw; }
     HIPC(hipMemcpyAsync(rawdev, t->data, t->nbytes, hipMemcpyHostToDevice, s));
     if (want_stream) {
-        if (dev_alloc(m->allocs, &d.stream, t->nbytes)) return 1;
+        if (stream_dst) d.stream = stream_dst;
+        else if (dev_alloc(m->allocs, &d.stream, t->nbytes)) return 1;
         bamd_launch_repack(rawdev, d.stream, d.type, d.nrows, d.K, s);
         m->weight_bytes += (int64_t) t->nbytes;
     }
@@ -215,10 +219,21 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
             if ((rc = upload_f32(m, g.tensor(p + "ffn_norm.weight"), &ly.ffn_norm, m->E, s))) break;
             struct { const char * n; DevMat * d; } mats[] = { { "attn_q", &ly.wq }, { "attn_k", &ly.wk }, { "attn_v", &ly.wv }, { "attn_output", &ly.wo },
                                                               { "ffn_gate", &ly.wg }, { "ffn_up", &ly.wu }, { "ffn_down", &ly.wd } };
+            // wq | wk | wv share one allocation so that equal-typed neighbours form ONE weight stream (fused QKV mat-vec)
+            char * qkv_base = nullptr; size_t qkv_off = 0;
+            {
+                size_t tot = 0;
+                for (int j = 0; j < 3; ++j) { const GgufTensor * t = g.tensor(p + mats[j].n + ".weight"); if (t) tot += t->nbytes; }
+                if (dev_alloc(m->allocs, (void **) &qkv_base, tot)) { rc = 1; break; }
+            }
+            int mi = 0;
             for (auto & mm : mats) {
                 const GgufTensor * t = g.tensor(p + mm.n + ".weight");
                 if (!t) { rc = fail("missing tensor " + p + mm.n + ".weight"); break; }
-                if ((rc = upload_mat(m, t, *mm.d, false, true, staging, s))) break;
+                void * dst = nullptr;
+                if (mi < 3) { dst = qkv_base + qkv_off; qkv_off += t->nbytes; }
+                if ((rc = upload_mat(m, t, *mm.d, false, true, staging, s, dst))) break;
+                ++mi;
             }
             if (rc) break;
             if (ly.wq.nrows != m->E || ly.wq.K != m->E || ly.wk.nrows != m->Hkv * m->hd || ly.wv.nrows != m->Hkv * m->hd || ly.wo.nrows != m->E ||
@@ -278,10 +293,10 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
         HIPC(hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     }
     if (dev_alloc(c->allocs, (void **) &c->x, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->x2, (size_t) m->E * 4) ||
-        dev_alloc(c->allocs, (void **) &c->q, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->k, (size_t) Ekv * 4) ||
-        dev_alloc(c->allocs, (void **) &c->v, (size_t) Ekv * 4) || dev_alloc(c->allocs, (void **) &c->att, (size_t) m->E * 4) ||
+        dev_alloc(c->allocs, (void **) &c->q, (size_t) (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->att, (size_t) m->E * 4) ||
         dev_alloc(c->allocs, (void **) &c->h, (size_t) m->F * 4) || dev_alloc(c->allocs, (void **) &c->scores, (size_t) m->H * n_ctx * 4) ||
         dev_alloc(c->allocs, (void **) &c->logits, (size_t) m->V * 4) || dev_alloc(c->allocs, (void **) &c->st, sizeof(bamd_step_state))) return 1;
+    c->k = c->q + m->E; c->v = c->k + Ekv;                           // q | k | v contiguous: rows of the fused QKV mat-vec
     HIPC(hipMemsetAsync(c->st, 0, sizeof(bamd_step_state), c->stream));
     HIPC(hipMemsetAsync(c->logits, 0, (size_t) m->V * 4, c->stream));
     HIPC(hipHostMalloc((void **) &c->logits_host, (size_t) m->V * 4));
@@ -329,7 +344,11 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         const DevLayer & ly = m->layers[il];
         bamd_mv_args a; memset(&a, 0, sizeof a);
         // 1. q,k,v = W{q,k,v} . Q8_K(rms_norm(x) * attn_norm)          (llama.cpp:8810-8835)
-        seg_of(a.seg[0], ly.wq, c->q); seg_of(a.seg[1], ly.wk, c->k); seg_of(a.seg[2], ly.wv, c->v); a.nseg = 3;
+        seg_of(a.seg[0], ly.wq, c->q); a.nseg = 1;
+        if (ly.wk.type == ly.wq.type) a.seg[0].nrows += ly.wk.nrows;    // streams and outputs are contiguous: extend
+        else { seg_of(a.seg[a.nseg], ly.wk, c->k); a.nseg++; }
+        if (ly.wv.type == ly.wk.type) a.seg[a.nseg - 1].nrows += ly.wv.nrows;
+        else { seg_of(a.seg[a.nseg], ly.wv, c->v); a.nseg++; }
         a.x = c->x; a.normw = ly.attn_norm; a.eps = m->eps; a.K = m->E;
         if (tm) tm->begin(s, 0, (double) (ly.wq.bytes + ly.wk.bytes + ly.wv.bytes));
         bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_STORE, m->n_cu, s);
@@ -339,7 +358,9 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.out = c->att;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
         if (tm) tm->begin(s, 1, 0.0);
-        if (bamd_launch_attention(t, gq, tiles, s)) return fail("attention launch: unsupported head configuration");
+        // three-kernel path (scores | softmax | P.V) everywhere for now: the fused single-launch kernel is correct (tests)
+        // but not yet faster at n_kv ~ 256 (14.9 vs 12.8 us on MI355X) — BAMD_ATTN_FUSED=1 selects it
+        if (bamd_launch_attention(t, gq, g_attn_fused ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
         if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
         memset(&a, 0, sizeof a);
@@ -530,7 +551,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_quantize_q8_K(cons
 }
 
 static int op_matvec(int type, const void * wA, const void * wB, int nrows, int k, const float * x, const float * norm_w, float eps,
-                     const float * residual, float * y, int epi) {
+                     const float * residual, float * y, int epi, int mode) {
     if (need_device()) return 1;
     if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0 || nrows % 8) return fail("bad type/shape");
     Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
@@ -546,19 +567,19 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
     bamd_mv_args a; memset(&a, 0, sizeof a);
     a.seg[0].w = strA; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows; a.nseg = 1;
     if (wB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
-    a.x = dx; a.normw = dw; a.eps = eps; a.K = k; a.res = dres; a.best_key = key;
+    a.x = dx; a.normw = dw; a.eps = eps; a.K = k; a.res = dres; a.best_key = key; a.mode = mode;
     bamd_launch_matvec(a, norm_w ? BAMD_PRO_NORM : BAMD_PRO_PLAIN, epi, n_cu0(), nullptr);
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(y, dy, (size_t) nrows * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
-                                   const float * residual, float * y) {
-    return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE);
+                                   const float * residual, float * y, int mode) {
+    return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, mode);
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
                                    float eps, float * y) {
-    return op_matvec(type, wg_raw, wu_raw, nrows, k, x, norm_w, eps, nullptr, y, BAMD_EPI_SILU_MUL);
+    return op_matvec(type, wg_raw, wu_raw, nrows, k, x, norm_w, eps, nullptr, y, BAMD_EPI_SILU_MUL, 0);
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_get_row(int type, const void * w_raw, int nrows, int k, int row, float * y) {
     if (need_device()) return 1;
@@ -581,6 +602,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_rope_row(int pos, 
 extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const float * q, const float * k, const float * v, uint16_t * k_cache, uint16_t * v_cache_t,
                                  const float * rope_row_h, int H, int Hkv, int hd, int n_ctx, int pos, int prefill_mode, float * out,
                                  float * probs_h0) {
+    const bool split_path = (prefill_mode & 2) != 0;   // bit 1: force the three-kernel (long-context) path
+    prefill_mode &= 1;
     if (need_device()) return 1;
     if (pos < 0 || pos >= n_ctx || n_ctx % 32 || H % Hkv) return fail("bad attention shape");
     Tmp t; const int Ekv = Hkv * hd; const size_t kvb = (size_t) n_ctx * Ekv * 2;
@@ -594,11 +617,53 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     a.rope = (float *) t.up(rope.data(), rope.size() * 4); a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
     if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.out) return fail("device alloc/copy failed");
     a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
-    if (bamd_launch_attention(a, H / Hkv, std::min(std::max(n_ctx / 64, 1), 32), nullptr)) return fail("unsupported head configuration");
+    { const int tiles = std::min(std::max(n_ctx / 64, 1), 32);
+      if (bamd_launch_attention(a, H / Hkv, split_path ? -tiles : tiles, nullptr)) return fail("unsupported head configuration"); }
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(out, a.out, (size_t) H * hd * 4, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(k_cache, a.kc, kvb, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(v_cache_t, a.vc, kvb, hipMemcpyDeviceToHost));
-    if (probs_h0) HIPC(hipMemcpy(probs_h0, a.scores, (size_t) h.n_kv * 4, hipMemcpyDeviceToHost));
+    if (probs_h0 && split_path) HIPC(hipMemcpy(probs_h0, a.scores, (size_t) h.n_kv * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- micro-benchmark of one mat-vec launch shape (random resident weights; HIP-event timing of `iters` launches) ----
+extern "C" __attribute__((visibility("default"))) int bamd_bench_matvec(int type, int nrows, int k, int pro, int epi, int mode, int iters,
+                                                                        float * us_per_launch) {
+    if (need_device()) return 1;
+    if (!bamd_is_kquant(type) || k % 256 || nrows % 8) return fail("bad type/shape");
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
+    std::vector<uint8_t> hw(wb);
+    uint32_t sd = 12345u; for (size_t i = 0; i < wb; ++i) { sd = sd * 1664525u + 1013904223u; hw[i] = (uint8_t) (sd >> 24); }
+    const int bb = bamd_block_bytes(type);
+    for (size_t b = 0; b < wb / bb; ++b) {                    // sane f16 scales (0x1c00 ~ 0.0039)
+        uint8_t * p = hw.data() + b * bb;
+        if (type == BAMD_Q6_K) { p[208] = 0x00; p[209] = 0x1c; } else { p[0] = 0; p[1] = 0x1c; p[2] = 0; p[3] = 0x1c; }
+    }
+    std::vector<float> hx((size_t) k); for (int i = 0; i < k; ++i) { sd = sd * 1664525u + 1013904223u; hx[i] = (float) (int) (sd >> 8) / 8388608.0f - 1.0f; }
+    std::vector<float> hn((size_t) k, 1.0f);
+    void * raw = t.up(hw.data(), wb), * strA = t.up(nullptr, wb), * strB = epi == BAMD_EPI_SILU_MUL ? t.up(nullptr, wb) : nullptr;
+    float * dx = (float *) t.up(hx.data(), (size_t) k * 4), * dw = (float *) t.up(hn.data(), (size_t) k * 4);
+    float * dres = (float *) t.up(nullptr, (size_t) nrows * 4), * dy = (float *) t.up(nullptr, (size_t) nrows * 4);
+    unsigned long long * key = (unsigned long long *) t.up(nullptr, 8);
+    if (!raw || !strA || !dx || !dw || !dres || !dy || !key) return fail("device alloc/copy failed");
+    HIPC(hipMemset(dres, 0, (size_t) nrows * 4)); HIPC(hipMemset(key, 0, 8));
+    bamd_launch_repack(raw, strA, type, nrows, k, nullptr);
+    if (strB) bamd_launch_repack(raw, strB, type, nrows, k, nullptr);
+    bamd_mv_args a; memset(&a, 0, sizeof a);
+    a.seg[0].w = strA; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows; a.nseg = 1;
+    if (strB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
+    a.x = dx; a.normw = dw; a.eps = 1e-5f; a.K = k; a.res = dres; a.best_key = key; a.mode = mode;
+    const int ncu = n_cu0();
+    hipStream_t s; HIPC(hipStreamCreate(&s));
+    for (int i = 0; i < 3; ++i) bamd_launch_matvec(a, pro, epi, ncu, s);
+    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) bamd_launch_matvec(a, pro, epi, ncu, s);
+    HIPC(hipEventRecord(e1, s));
+    HIPC(hipStreamSynchronize(s));
+    float ms = 0.f; HIPC(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_launch = ms * 1000.0f / (float) iters;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return 0;
 }

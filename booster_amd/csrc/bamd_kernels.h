@@ -25,6 +25,7 @@ struct bamd_mv_args {
     float eps; int K;
     const float * res;             // residual (BAMD_EPI_ADD), indexed like seg[0].out
     unsigned long long * best_key; // BAMD_EPI_ARGMAX
+    int mode;                      // 0 auto, 1 force one-wave-per-row-group, 2 force split-K (tests)
 };
 
 struct bamd_attn_args {

@@ -32,6 +32,17 @@
 #include "bamd_kernels.h"
 
 #define WAVE 64
+#ifndef BAMD_SCHED_GROUP
+#define BAMD_SCHED_GROUP 1      /* records the scheduler may interleave between barriers (power of two) */
+#endif
+
+// optional in-kernel phase stamps (build with -DBAMD_TIMING): block 0 / lane 0 of each wave writes s_memtime
+#ifdef BAMD_TIMING
+__device__ unsigned long long g_stamps[64 * 16];
+#define STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short) bits16)); }
 __device__ __forceinline__ unsigned short f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
@@ -87,60 +98,134 @@ __global__ void repack_kernel(const uint8_t * __restrict__ raw, uint8_t * __rest
 //   S [i*8 + c]        : int   = sum of the 32 int8 of chunk c  (= bsums[2c] + bsums[2c+1])
 //   yd[i]              : f32   = block scale d
 // ===========================================================================================================
-template <bool NORM>
-__device__ __forceinline__ void build_act(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
-                                          uint32_t * q8, int * S, float * yd, double * red) {
-    const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6;
-    const int nb = K >> 8;
-    float scale = 1.0f;
-    if (NORM) {
-        double s = 0.0;
-        for (int i = wave; i < nb; i += nwaves) {
-            const float4 v = *(const float4 *) (x + i * 256 + lane * 4);
-            s += (double) (v.x * v.x); s += (double) (v.y * v.y); s += (double) (v.z * v.z); s += (double) (v.w * v.w);
-        }
-        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < nwaves; ++w) tot += red[w];
-        const float mean = (float) (tot / (double) K);
-        scale = 1.0f / sqrtf(mean + eps);
-    }
-    for (int i = wave; i < nb; i += nwaves) {
-        const float4 v = *(const float4 *) (x + i * 256 + lane * 4);
-        float e0 = v.x, e1 = v.y, e2 = v.z, e3 = v.w;
-        if (NORM) {
-            const float4 w = *(const float4 *) (nw + i * 256 + lane * 4);
-            e0 = (e0 * scale) * w.x; e1 = (e1 * scale) * w.y; e2 = (e2 * scale) * w.z; e3 = (e3 * scale) * w.w;
-        }
-        float amax = 0.f, mx = 0.f;
-        { float a = fabsf(e0); if (a > amax) { amax = a; mx = e0; } }
-        { float a = fabsf(e1); if (a > amax) { amax = a; mx = e1; } }
-        { float a = fabsf(e2); if (a > amax) { amax = a; mx = e2; } }
-        { float a = fabsf(e3); if (a > amax) { amax = a; mx = e3; } }
-        int idx = lane;
-        for (int o = 32; o; o >>= 1) {
-            const float oa = __shfl_xor(amax, o), om = __shfl_xor(mx, o);
-            const int oi = __shfl_xor(idx, o);
-            if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-        }
-        uint32_t packed = 0; int s4 = 0; float d = 0.f;
-        if (amax != 0.f) {
-            const float iscale = -127.f / mx;
-            int q0 = nearest_int(iscale * e0), q1 = nearest_int(iscale * e1), q2 = nearest_int(iscale * e2), q3 = nearest_int(iscale * e3);
-            q0 = q0 < 127 ? q0 : 127; q1 = q1 < 127 ? q1 : 127; q2 = q2 < 127 ? q2 : 127; q3 = q3 < 127 ? q3 : 127;
-            packed = (uint32_t) (q0 & 0xff) | ((uint32_t) (q1 & 0xff) << 8) | ((uint32_t) (q2 & 0xff) << 16) | ((uint32_t) (q3 & 0xff) << 24);
-            s4 = q0 + q1 + q2 + q3;
-            d = 1.0f / iscale;
-        }
-        s4 += __shfl_xor(s4, 1); s4 += __shfl_xor(s4, 2); s4 += __shfl_xor(s4, 4);
-        q8[i * 64 + (lane & 7) * 8 + (lane >> 3)] = packed;
-        if ((lane & 7) == 0) S[i * 8 + (lane >> 3)] = s4;
-        if (lane == 0) yd[i] = d;
-    }
-    __syncthreads();
+// ---- cross-lane helpers: DPP (no LDS-crossbar latency) for everything inside a row of 16 lanes, v_readlane across rows ----
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+#define DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141  /* lane i <-> 7-i inside each group of 8 */
+#define DPP_MIRROR 0x140       /* lane i <-> 15-i inside each row of 16 */
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {             // wave-uniform result
+    v = umax_(v, (uint32_t) dpp_i<DPP_XOR1>((int) v)); v = umax_(v, (uint32_t) dpp_i<DPP_XOR2>((int) v));
+    v = umax_(v, (uint32_t) dpp_i<DPP_HALF_MIRROR>((int) v)); v = umax_(v, (uint32_t) dpp_i<DPP_MIRROR>((int) v));
+    const uint32_t r0 = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), r1 = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
+    const uint32_t r2 = (uint32_t) __builtin_amdgcn_readlane((int) v, 47), r3 = (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+    return umax_(umax_(r0, r1), umax_(r2, r3));
 }
+__device__ __forceinline__ int group8_sum(int v) {                          // sum over aligned groups of 8 lanes, in every lane
+    v += dpp_i<DPP_XOR1>(v); v += dpp_i<DPP_XOR2>(v); v += dpp_i<DPP_HALF_MIRROR>(v);
+    return v;
+}
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double s) {                  // fixed order; wave-uniform result
+    s += dpp_d<DPP_XOR1>(s); s += dpp_d<DPP_XOR2>(s); s += dpp_d<DPP_HALF_MIRROR>(s); s += dpp_d<DPP_MIRROR>(s);
+    return ((readlane_d(s, 15) + readlane_d(s, 31)) + readlane_d(s, 47)) + readlane_d(s, 63);
+}
+
+// One wave quantises BATCH super-blocks at a time (independent dependency chains interleave); lane l holds the 4
+// consecutive elements 4l..4l+3 of a block.  quantize_row_q8_K_ref semantics (ggml-quants.c:3593-3630): the scale comes
+// from the FIRST element of largest magnitude (strict > scan), so ties resolve to the lowest lane, lowest element.
+#define BAMD_ACT_BATCH 4
+template <bool NORM>
+struct ActPro {
+    float4 v[BAMD_ACT_BATCH], w[BAMD_ACT_BATCH];
+
+    // the loads of this wave's first batch of blocks: issued at kernel entry, AHEAD of the bulk weight prefetch, so the
+    // (tiny, latency-critical) activation read is not queued behind megabytes of weight requests
+    __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0) {
+        const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, nb = K >> 8;
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const int i = i0 + b * nwaves;
+            v[b] = i < nb ? *(const float4 *) (x + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORM) w[b] = i < nb ? *(const float4 *) (nw + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd) {
+        const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, nb = K >> 8;
+        uint32_t amaxb[BAMD_ACT_BATCH]; float mxl[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            if (NORM) {                                  // y = (x*scale)*w : ggml_vec_scale_f32 then ggml_mul (llama.cpp:7940-7950)
+                v[b].x = (v[b].x * scale) * w[b].x; v[b].y = (v[b].y * scale) * w[b].y;
+                v[b].z = (v[b].z * scale) * w[b].z; v[b].w = (v[b].w * scale) * w[b].w;
+            }
+            float amax = 0.f, mx = 0.f;
+            { const float a = fabsf(v[b].x); if (a > amax) { amax = a; mx = v[b].x; } }
+            { const float a = fabsf(v[b].y); if (a > amax) { amax = a; mx = v[b].y; } }
+            { const float a = fabsf(v[b].z); if (a > amax) { amax = a; mx = v[b].z; } }
+            { const float a = fabsf(v[b].w); if (a > amax) { amax = a; mx = v[b].w; } }
+            amaxb[b] = __float_as_uint(amax);            // non-negative floats order like their bit patterns
+            mxl[b] = mx;
+        }
+        uint32_t wmax[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) wmax[b] = wave_max_u32(amaxb[b]);
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const int i = i0 + b * nwaves;
+            if (i < nb) {                                // wave-uniform
+                uint32_t packed = 0; int s4 = 0; float d = 0.f;
+                if (wmax[b] != 0u) {
+                    const unsigned long long who = __ballot(amaxb[b] == wmax[b]);
+                    const int first = __ffsll((long long) who) - 1;
+                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mxl[b]), first));
+                    const float iscale = -127.f / mx;
+                    int q0 = nearest_int(iscale * v[b].x), q1 = nearest_int(iscale * v[b].y), q2 = nearest_int(iscale * v[b].z), q3 = nearest_int(iscale * v[b].w);
+                    q0 = q0 < 127 ? q0 : 127; q1 = q1 < 127 ? q1 : 127; q2 = q2 < 127 ? q2 : 127; q3 = q3 < 127 ? q3 : 127;
+                    packed = (uint32_t) (q0 & 0xff) | ((uint32_t) (q1 & 0xff) << 8) | ((uint32_t) (q2 & 0xff) << 16) | ((uint32_t) (q3 & 0xff) << 24);
+                    s4 = group8_sum(q0 + q1 + q2 + q3);
+                    d = 1.0f / iscale;
+                }
+                q8[i * 64 + (lane & 7) * 8 + (lane >> 3)] = packed;
+                if ((lane & 7) == 0) S[i * 8 + (lane >> 3)] = s4;
+                if (lane == 0) yd[i] = d;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
+                                           uint32_t * q8, int * S, float * yd, double * red) {
+        const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
+        const int step = nwaves * BAMD_ACT_BATCH;
+        float scale = 1.0f;
+        if (NORM) {
+            // sum of squares in double (ggml.c:11874-11877), fixed tree order instead of the reference's sequential order
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                s += (double) (v[b].x * v[b].x); s += (double) (v[b].y * v[b].y); s += (double) (v[b].z * v[b].z); s += (double) (v[b].w * v[b].w);
+            }
+            for (int i0 = wave + step; i0 < nb; i0 += step) {          // only for K > 256 * 4 * nwaves
+                ActPro<NORM> t; t.issue(x, nw, K, i0);
+#pragma unroll
+                for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                    s += (double) (t.v[b].x * t.v[b].x); s += (double) (t.v[b].y * t.v[b].y); s += (double) (t.v[b].z * t.v[b].z); s += (double) (t.v[b].w * t.v[b].w);
+                }
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            double tot = 0.0;
+            for (int w2 = 0; w2 < nwaves; ++w2) tot += red[w2];
+            const float mean = (float) (tot / (double) K);
+            scale = 1.0f / sqrtf(mean + eps);
+        }
+        quantize_batch(scale, K, wave, q8, S, yd);
+        for (int i0 = wave + step; i0 < nb; i0 += step) {
+            ActPro<NORM> t; t.issue(x, nw, K, i0);
+            t.quantize_batch(scale, K, i0, q8, S, yd);
+        }
+        __syncthreads();
+    }
+};
 
 // test entry: standard block_q8_K bytes out of the prologue (for parity tests against quantize_row_q8_K)
 __global__ void __launch_bounds__(512) quantize_q8k_test_kernel(const float * x, const float * nw, float eps, int K, int norm, uint8_t * out) {
@@ -148,7 +233,8 @@ __global__ void __launch_bounds__(512) quantize_q8k_test_kernel(const float * x,
     const int nb = K >> 8;
     uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
     double * red = (double *) (((uintptr_t) (yd + nb) + 15) & ~(uintptr_t) 15);
-    if (norm) build_act<true>(x, nw, eps, K, q8, S, yd, red); else build_act<false>(x, nw, eps, K, q8, S, yd, red);
+    if (norm) { ActPro<true> ap; ap.issue(x, nw, K, wave_id()); ap.finish(x, nw, eps, K, q8, S, yd, red); }
+    else { ActPro<false> ap; ap.issue(x, nw, K, wave_id()); ap.finish(x, nw, eps, K, q8, S, yd, red); }
     for (int i = threadIdx.x; i < nb * 64; i += blockDim.x) {
         const int blk = i >> 6, e = (i >> 3) & 7, c = i & 7;
         const uint32_t w = q8[i];
@@ -176,6 +262,16 @@ struct RecQ4K { uint4 qs, hd; };
 struct RecQ5K { uint4 qs, hd; uint32_t qh; };
 struct RecQ6K { uint4 ql; uint2 qh, sc; uint32_t d; };
 
+// Pin a loaded register at its point of use: without this, LLVM folds the first ALU op on a ring register into
+// the loop PHI (i.e. executes it right after the load, one iteration early), which forces s_waitcnt vmcnt(0) at
+// the loop tail and serialises the whole prefetch ring.
+__device__ __forceinline__ void pin(uint32_t & x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(uint2 & x) { pin(x.x); pin(x.y); }
+__device__ __forceinline__ void pin(uint4 & x) { pin(x.x); pin(x.y); pin(x.z); pin(x.w); }
+__device__ __forceinline__ void pin_rec(RecQ4K & R) { pin(R.qs); pin(R.hd); }
+__device__ __forceinline__ void pin_rec(RecQ5K & R) { pin(R.qs); pin(R.hd); pin(R.qh); }
+__device__ __forceinline__ void pin_rec(RecQ6K & R) { pin(R.ql); pin(R.qh); pin(R.sc); pin(R.d); }
+
 __device__ __forceinline__ void load_rec(RecQ4K & R, const uint8_t * rec, int lane) {
     R.qs = *(const uint4 *) (rec + lane * 16);
     R.hd = *(const uint4 *) (rec + 1024 + (lane >> 3) * 16);
@@ -201,11 +297,17 @@ __device__ __forceinline__ void unpack_k4(const uint4 & hd, uint32_t & sc03, uin
 }
 #define BYTE(w, k) (int) (((w) >> (8 * (k))) & 0xffu)
 
-__device__ __forceinline__ void consume(const RecQ4K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd, RowAcc & A) {
+// The terms one super-block contributes to the f32 chains of lane (r, e):
+//   d, fs   : acc  = fma(d, fs, acc)                      (all types; fs = (float) of the exact int32 lane sum)
+//   dmin, pm: Q4_K: accm = fma(dmin, pm, accm) for l = e&3 ; Q5_K: accm = accm + dmin*pm (pm = all-8 integer sum)
+struct Terms { float d, fs, dmin, pm; };
+
+__device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
     const int e = lane & 7, l = e & 3;
     const float ydv = yd[ci];
-    const float d = ydv * h2f(R.hd.x & 0xffffu);
-    const float dmin = (-ydv) * h2f(R.hd.x >> 16);
+    Terms T;
+    T.d = ydv * h2f(R.hd.x & 0xffffu);
+    T.dmin = (-ydv) * h2f(R.hd.x >> 16);
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     int sumi = 0;
@@ -213,19 +315,21 @@ __device__ __forceinline__ void consume(const RecQ4K & R, int ci, int lane, cons
     sumi += BYTE(sc03, 2) * sdot4(R.qs.y & 0x0f0f0f0fu, a0.z) + BYTE(sc03, 3) * sdot4((R.qs.y >> 4) & 0x0f0f0f0fu, a0.w);
     sumi += BYTE(sc47, 0) * sdot4(R.qs.z & 0x0f0f0f0fu, a1.x) + BYTE(sc47, 1) * sdot4((R.qs.z >> 4) & 0x0f0f0f0fu, a1.y);
     sumi += BYTE(sc47, 2) * sdot4(R.qs.w & 0x0f0f0f0fu, a1.z) + BYTE(sc47, 3) * sdot4((R.qs.w >> 4) & 0x0f0f0f0fu, a1.w);
-    A.acc = fmaf(d, (float) sumi, A.acc);
+    T.fs = (float) sumi;
     const uint32_t mw = (l < 2) ? mn03 : mn47;
     const int sh = (l & 1) * 16;
     const int ma = (int) ((mw >> sh) & 0xffu), mb = (int) ((mw >> (sh + 8)) & 0xffu);
     const int2 sp = *(const int2 *) (S + ci * 8 + 2 * l);
-    A.accm = fmaf(dmin, (float) (ma * sp.x + mb * sp.y), A.accm);
+    T.pm = (float) (ma * sp.x + mb * sp.y);
+    return T;
 }
 
-__device__ __forceinline__ void consume(const RecQ5K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd, RowAcc & A) {
+__device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
     const int e = lane & 7;
     const float ydv = yd[ci];
-    const float d = ydv * h2f(R.hd.x & 0xffffu);
-    const float dmin = (-ydv) * h2f(R.hd.x >> 16);
+    Terms T;
+    T.d = ydv * h2f(R.hd.x & 0xffffu);
+    T.dmin = (-ydv) * h2f(R.hd.x >> 16);
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     const uint32_t qh = R.qh;
@@ -236,19 +340,21 @@ __device__ __forceinline__ void consume(const RecQ5K & R, int ci, int lane, cons
     sumi += BYTE(sc47, 0) * sdot4(Q5(R.qs.z, 0, 4), a1.x) + BYTE(sc47, 1) * sdot4(Q5(R.qs.z, 4, 5), a1.y);
     sumi += BYTE(sc47, 2) * sdot4(Q5(R.qs.w, 0, 6), a1.z) + BYTE(sc47, 3) * sdot4(Q5(R.qs.w, 4, 7), a1.w);
 #undef Q5
-    A.acc = fmaf(d, (float) sumi, A.acc);
-    // summs += dmin * hsum(mins . q8sums)   (:7515-7518) — integer sum over all 8 sub-blocks, then mul, then add
+    T.fs = (float) sumi;
+    // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
     const uint32_t mw = (e < 4) ? mn03 : mn47;
     int hs = (int) ((mw >> (8 * (e & 3))) & 0xffu) * S[ci * 8 + e];
     hs += __shfl_xor(hs, 1); hs += __shfl_xor(hs, 2); hs += __shfl_xor(hs, 4);
-    const float t = dmin * (float) hs;
-    A.accm = A.accm + t;
+    T.pm = (float) hs;
+    return T;
 }
 
-__device__ __forceinline__ void consume(const RecQ6K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd, RowAcc & A) {
+__device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
     (void) S;
     const int e = lane & 7;
-    const float d = yd[ci] * h2f(R.d);
+    Terms T;
+    T.d = yd[ci] * h2f(R.d);
+    T.dmin = 0.f; T.pm = 0.f;
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     // (q6 - 32) as int8: q6 in [0,63] -> (q6 + 0x60) ^ 0x80 per byte, no inter-byte carry
 #define Q6(lo, hb) ((((lo) | ((hb) << 4)) + 0x60606060u) ^ 0x80808080u)
@@ -270,17 +376,30 @@ __device__ __forceinline__ void consume(const RecQ6K & R, int ci, int lane, cons
     }
 #undef Q6
 #undef SB
-    A.acc = fmaf(d, (float) sumi, A.acc);
+    T.fs = (float) sumi;
+    return T;
 }
 
-// horizontal reductions at the end of a row (hsum_float_8, ggml-quants.c:47-53, and the acc_m folds)
+// one step of the reference's per-lane f32 chains (the ONLY place their order is defined)
+template <int TYPE>
+__device__ __forceinline__ void chain_step(RowAcc & A, float d, float fs, float dmin, float pm) {
+    A.acc = fmaf(d, fs, A.acc);
+    if (TYPE == BAMD_Q4_K) A.accm = fmaf(dmin, pm, A.accm);                    // _mm_fmadd_ps(dmin, prod, acc_m)
+    if (TYPE == BAMD_Q5_K) { const float t = dmin * pm; A.accm = A.accm + t; } // summs += dmin * hsum  (mul, then add)
+}
+
+// horizontal reductions at the end of a row (hsum_float_8, ggml-quants.c:47-53, and the acc_m folds), valid in lane e == 0 of
+// each 8-lane group: (a_e + a_{e+4}) -> (+ lane e+2) -> (+ lane e+1), the reference's tree, by DPP row_shl:4 / quad_perm.
+__device__ __forceinline__ float dpp_f_shl4(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_f_xor2(float v) { return __int_as_float(dpp_i<DPP_XOR2>(__float_as_int(v))); }
+__device__ __forceinline__ float dpp_f_xor1(float v) { return __int_as_float(dpp_i<DPP_XOR1>(__float_as_int(v))); }
 template <int TYPE>
 __device__ __forceinline__ float finish_row(const RowAcc & A) {
     float v = A.acc;
-    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
     if (TYPE == BAMD_Q4_K) {
         float m = A.accm;
-        m += __shfl_xor(m, 2); m += __shfl_xor(m, 1);
+        m = m + dpp_f_xor2(m); m = m + dpp_f_xor1(m);
         return v + m;
     }
     if (TYPE == BAMD_Q5_K) return v + A.accm;
@@ -316,85 +435,115 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, int row) {
     return ((unsigned long long) u << 32) | (unsigned long long) (0xffffffffu - (uint32_t) row);
 }
 
-// ---- the stream over (row-group, super-block) records for one segment -----------------------------------
-// The wave walks row-groups rg = first, first+stride, ... (count of them) as ONE flattened record stream, so the
-// register prefetch ring (depth D records) never drains between row-groups.  With PAIR each row-group is
-// streamed twice back to back — gate (wA) then up (wB) — and the epilogue fuses silu(gate)*up.
-template <int TYPE, typename REC, int D, int EPI>
+struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S; float * yd; double * red; };
+#define BAMD_PRO_ISSUE(ap, pa) (ap).issue((pa).x, (pa).nw, (pa).K, wave_id())
+#define BAMD_PRO_FINISH(ap, pa) (ap).finish((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
+
+// ---- MODE A: one wave per row-group --------------------------------------------------------------------------
+// The wave walks row-groups rg = first, first+stride, ... (count of them).  A register ring of D records is kept
+// in flight by a LOADER cursor that runs D records ahead of the consumer and crosses row-group boundaries by
+// pure (branch-free, scalar) arithmetic, so the prefetch never drains and the compiler can keep counted
+// s_waitcnt vmcnt(N) waits.  The ring is filled BEFORE the activation prologue (weights do not depend on it), so
+// the first HBM round trip overlaps the RMSNorm/Q8_K work.  With PAIR each row-group is streamed twice back to
+// back — gate (wA) then up (wB) — and the epilogue fuses silu(gate)*up.
+template <int TYPE, typename REC, int D, int EPI, int PRO>
 __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb,
                                                int first, int count, int stride, float * __restrict__ out,
-                                               const float * __restrict__ res, const uint32_t * q8, const int * S, const float * yd,
+                                               const float * __restrict__ res, const ProArgs & pa, bool do_pro,
                                                unsigned long long & best) {
     constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    constexpr int NPARTS = PAIR ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int total = count * nb * (PAIR ? 2 : 1);       // D divides nb (chosen by the dispatcher below)
-    const size_t rgb = (size_t) nb * RECB;
-    // loader cursor (wave-uniform)
-    int lrg = first, lpart = 0, li = 0, lt = 0;
+    const int total = count * nb * NPARTS;               // D divides nb (chosen by the dispatcher below)
+    const long rgb = (long) nb * RECB;
+    const long rg_step = (long) stride * rgb;
+    int lt = 0, li = 0, lpart = 0;                       // loader cursor (wave-uniform scalars)
+    long loff = (long) first * rgb;
+    ActPro<PRO == BAMD_PRO_NORM> ap;
+    if (do_pro) BAMD_PRO_ISSUE(ap, pa);                  // activation loads go out FIRST (see ActPro::issue)
     REC ring[D];
 #define BAMD_LOAD_NEXT(slot) do { \
         const uint8_t * base_ = (PAIR && lpart) ? wB : wA; \
-        load_rec(ring[slot], base_ + (size_t) lrg * rgb + (size_t) li * RECB, lane); \
-        if (++lt < total) { if (++li == nb) { li = 0; if (PAIR && lpart == 0) lpart = 1; else { lpart = 0; lrg += stride; } } } \
+        load_rec(ring[slot], base_ + loff + (long) li * RECB, lane); \
+        ++lt; \
+        const bool adv_ = lt < total; const int li1_ = li + 1; const bool wrap_ = li1_ == nb; \
+        li = adv_ ? (wrap_ ? 0 : li1_) : li; \
+        const bool nrg_ = adv_ && wrap_ && (!PAIR || lpart == 1); \
+        if (PAIR) lpart = (adv_ && wrap_) ? (lpart ^ 1) : lpart; \
+        loff = nrg_ ? loff + rg_step : loff; \
     } while (0)
 #pragma unroll
     for (int s = 0; s < D; ++s) BAMD_LOAD_NEXT(s);
-    RowAcc A = { 0.f, 0.f };
-    float gate_val = 0.f;
-    int crg = first, cpart = 0, ci = 0;
-    for (int t0 = 0; t0 < total; t0 += D) {
+    if (do_pro) BAMD_PRO_FINISH(ap, pa);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    const int chunks = nb / D;
+    for (int r = 0; r < count; ++r) {
+        const int rg = first + r * stride;
+        const int row = rg * 8 + (lane >> 3);
+        float gate_val = 0.f;
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
-            const REC R = ring[s];
-            // refill this slot; at the tail the cursor stays on the last record (a redundant, branch-free reload)
-            BAMD_LOAD_NEXT(s);
-            consume(R, ci, lane, q8, S, yd, A);
-            if (++ci == nb) {
-                const float val = finish_row<TYPE>(A);
-                const int row = crg * 8 + (lane >> 3);
-                if (PAIR) {
-                    if (cpart == 0) gate_val = val;
-                    else if ((lane & 7) == 0) out[row] = v_silu(gate_val) * val;
-                } else if ((lane & 7) == 0) {
-                    float o = val;
-                    if (EPI == BAMD_EPI_ADD) o = val + res[row];
-                    out[row] = o;
-                    if (EPI == BAMD_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, row); best = k > best ? k : best; }
+        for (int part = 0; part < NPARTS; ++part) {
+            // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
+            float resv = 0.f;
+            if (EPI == BAMD_EPI_ADD) resv = res[row];
+            RowAcc A = { 0.f, 0.f };
+            for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    pin_rec(ring[s]);
+                    const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
+                    chain_step<TYPE>(A, T.d, T.fs, T.dmin, T.pm);
+                    BAMD_LOAD_NEXT(s);               // refill; at the very end the cursor stays on the last record
+                    if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1)
+                        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from clustering the refills at the loop tail
                 }
-                A.acc = 0.f; A.accm = 0.f; ci = 0;
-                if (PAIR && cpart == 0) cpart = 1; else { cpart = 0; crg += stride; }
+            }
+            const float val = finish_row<TYPE>(A);
+            if (PAIR) {
+                if (part == 0) gate_val = val;
+                else if ((lane & 7) == 0) out[row] = v_silu(gate_val) * val;
+            } else if ((lane & 7) == 0) {
+                float o = val;
+                if (EPI == BAMD_EPI_ADD) o = val + resv;
+                out[row] = o;
+                if (EPI == BAMD_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, row); best = k > best ? k : best; }
             }
         }
     }
 #undef BAMD_LOAD_NEXT
 }
 
-template <int TYPE, typename REC, int EPI>
+template <int TYPE, typename REC, int EPI, int PRO>
 __device__ __forceinline__ void stream_dispatch_depth(const uint8_t * wA, const uint8_t * wB, int nb, int first, int count, int stride,
-                                                      float * out, const float * res, const uint32_t * q8, const int * S, const float * yd,
+                                                      float * out, const float * res, const ProArgs & pa, bool do_pro,
                                                       unsigned long long & best) {
-    if ((nb & 7) == 0)      stream_segment<TYPE, REC, 8, EPI>(wA, wB, nb, first, count, stride, out, res, q8, S, yd, best);
-    else if ((nb & 3) == 0) stream_segment<TYPE, REC, 4, EPI>(wA, wB, nb, first, count, stride, out, res, q8, S, yd, best);
-    else if ((nb & 1) == 0) stream_segment<TYPE, REC, 2, EPI>(wA, wB, nb, first, count, stride, out, res, q8, S, yd, best);
-    else                    stream_segment<TYPE, REC, 1, EPI>(wA, wB, nb, first, count, stride, out, res, q8, S, yd, best);
+    if ((nb & 7) == 0)      stream_segment<TYPE, REC, 8, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
+    else if ((nb & 3) == 0) stream_segment<TYPE, REC, 4, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
+    else if ((nb & 1) == 0) stream_segment<TYPE, REC, 2, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
+    else                    stream_segment<TYPE, REC, 1, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
+}
+
+__device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned char * smem) {
+    const int nb = a.K >> 8;
+    ProArgs pa;
+    pa.x = a.x; pa.nw = a.normw; pa.eps = a.eps; pa.K = a.K;
+    pa.q8 = (uint32_t *) smem; pa.S = (int *) (pa.q8 + nb * 64); pa.yd = (float *) (pa.S + nb * 8);
+    pa.red = (double *) (((uintptr_t) (pa.yd + nb) + 15) & ~(uintptr_t) 15);
+    return pa;
 }
 
 template <int PRO, int EPI>
 __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nb = a.K >> 8;
-    uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
-    double * red = (double *) (((uintptr_t) (yd + nb) + 15) & ~(uintptr_t) 15);
-    const float * x = a.x;
-    if (PRO == BAMD_PRO_NORM) build_act<true>(x, a.normw, a.eps, a.K, q8, S, yd, red);
-    else                      build_act<false>(x, nullptr, 0.f, a.K, q8, S, yd, red);
-
+    const ProArgs pa = carve_lds(a, smem);
     const int wave = wave_id(), nwaves = blockDim.x >> 6;
     const int slot = blockIdx.x + gridDim.x * wave;          // consecutive row-groups land on different CUs
     const int stride = gridDim.x * nwaves;
     unsigned long long best = 0ull;
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    bool pro_done = false;
     int off = 0;
     const int nseg = PAIR ? 1 : a.nseg;
     for (int s = 0; s < nseg; ++s) {
@@ -409,12 +558,14 @@ __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
             const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
             float * out = a.seg[s].out;
             const float * res = a.res;
-            if (t == BAMD_Q4_K)      stream_dispatch_depth<BAMD_Q4_K, RecQ4K, EPI>(wA, wB, nb, g0 - off, count, stride, out, res, q8, S, yd, best);
-            else if (t == BAMD_Q5_K) stream_dispatch_depth<BAMD_Q5_K, RecQ5K, EPI>(wA, wB, nb, g0 - off, count, stride, out, res, q8, S, yd, best);
-            else                     stream_dispatch_depth<BAMD_Q6_K, RecQ6K, EPI>(wA, wB, nb, g0 - off, count, stride, out, res, q8, S, yd, best);
+            if (t == BAMD_Q4_K)      stream_dispatch_depth<BAMD_Q4_K, RecQ4K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
+            else if (t == BAMD_Q5_K) stream_dispatch_depth<BAMD_Q5_K, RecQ5K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
+            else                     stream_dispatch_depth<BAMD_Q6_K, RecQ6K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
+            pro_done = true;
         }
         off += nrg;
     }
+    if (!pro_done) { ActPro<PRO == BAMD_PRO_NORM> ap; BAMD_PRO_ISSUE(ap, pa); BAMD_PRO_FINISH(ap, pa); }   // idle waves still owe the block its barriers
     if (EPI == BAMD_EPI_ARGMAX) {
         // wave max -> block max -> one atomic per workgroup
         for (int o = 32; o; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob > best ? ob : best; }
@@ -428,6 +579,143 @@ __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
             if (b) atomicMax(a.best_key, b);
         }
     }
+}
+
+// ---- MODE B: split-K, one 8-wave workgroup per row-group ------------------------------------------------------
+// For matrices with few row-groups (wq/wk/wv/wo, ffn_down: 512..768 of them) one wave per row-group leaves the chip
+// short of bytes in flight.  Here the 8 waves of a workgroup share a row-group: wave w streams super-blocks
+// [w*nb/8, (w+1)*nb/8) and writes the per-block TERMS (d, fs, dmin, pm — exact integers already converted) to LDS;
+// after a workgroup barrier ONE wave replays the reference's sequential f32 chain over all nb blocks in order.
+// Same arithmetic, same order, 8x the parallelism.  Term buffers are double-buffered so the chain of row-group n
+// overlaps the streaming of row-group n+1; the prefetch ring spans row-group boundaries (M row-groups per body).
+// LDS term buffers: 2 (double buffer) x M (row-groups per batch) x { fs[nb][64], dd[nb][8], dm[nb][8], pm[nb][32] } floats
+#define BAMD_TERM_FLOATS(nb) ((size_t) (nb) * (64 + 8 + 8 + 32))
+
+template <int TYPE, typename REC, int NBW, int M, int EPI, int PRO>
+__device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
+                                             float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa, bool do_pro,
+                                             float * part0, int & batchctr) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int r8 = lane >> 3, l4 = lane & 3;
+    const long rgb = (long) nb * RECB;
+    const long rg_step = (long) stride * rgb;
+    const int total = count * NBW;
+    const int i0 = wave * NBW;                               // this wave's first super-block inside a row
+    const size_t rg_floats = BAMD_TERM_FLOATS(nb);
+    ActPro<PRO == BAMD_PRO_NORM> ap;
+    if (do_pro) BAMD_PRO_ISSUE(ap, pa);                      // activation loads go out FIRST
+    int lt = 0, li = 0;
+    long loff = (long) first * rgb + (long) i0 * RECB;
+    REC ring[D];
+#define BAMD_LOAD_NEXT(slot) do { \
+        load_rec(ring[slot], w + loff + (long) li * RECB, lane); \
+        ++lt; \
+        const bool adv_ = lt < total; const int li1_ = li + 1; const bool wrap_ = li1_ == NBW; \
+        li = adv_ ? (wrap_ ? 0 : li1_) : li; \
+        loff = (adv_ && wrap_) ? loff + rg_step : loff; \
+    } while (0)
+    STAMP(0);
+#pragma unroll
+    for (int s = 0; s < D; ++s) { if (s < total) BAMD_LOAD_NEXT(s); }     // no redundant requests when the stream is short
+    STAMP(1);
+    if (do_pro) BAMD_PRO_FINISH(ap, pa);
+    STAMP(2);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    for (int r0 = 0; r0 < count; r0 += M) {
+        const int nvalid = count - r0 < M ? count - r0 : M;  // workgroup-uniform
+        float * B0 = part0 + (size_t) (batchctr & 1) * M * rg_floats;
+        // the wave that will run the chain of row-group r0+wave fetches its residual now (old by chain time)
+        const int crow = (first + (r0 + (wave < nvalid ? wave : 0)) * stride) * 8 + r8;
+        float resv = 0.f;
+        if (EPI == BAMD_EPI_ADD) resv = res[crow];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            if (m < nvalid) {
+                float * P = B0 + (size_t) m * rg_floats;
+                float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const int s = m * NBW + j;
+                    const int ci = i0 + j;
+                    pin_rec(ring[s]);
+                    const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
+                    fs[ci * 64 + lane] = T.fs;
+                    if ((lane & 7) == 0) { dd[ci * 8 + r8] = T.d; if (TYPE != BAMD_Q6_K) dm[ci * 8 + r8] = T.dmin; }
+                    if (TYPE == BAMD_Q4_K && (lane & 7) < 4) pm[ci * 32 + r8 * 4 + l4] = T.pm;
+                    if (TYPE == BAMD_Q5_K && (lane & 7) == 0) pm[ci * 32 + r8 * 4] = T.pm;
+                    if (lt < total) BAMD_LOAD_NEXT(s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+        if (wave < nvalid) {
+            // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
+            const float * P = B0 + (size_t) wave * rg_floats;
+            const float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
+            RowAcc A = { 0.f, 0.f };
+            for (int i = 0; i < nb; i += 8) {                // nb % 8 == 0 here; LDS reads of 8 blocks issued together
+                float dv[8], fv[8], mv[8], pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dv[u] = dd[(i + u) * 8 + r8]; fv[u] = fs[(i + u) * 64 + lane]; mv[u] = 0.f; pv[u] = 0.f;
+                    if (TYPE == BAMD_Q4_K) { mv[u] = dm[(i + u) * 8 + r8]; pv[u] = pm[(i + u) * 32 + r8 * 4 + l4]; }
+                    if (TYPE == BAMD_Q5_K) { mv[u] = dm[(i + u) * 8 + r8]; pv[u] = pm[(i + u) * 32 + r8 * 4]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dv[u], fv[u], mv[u], pv[u]);
+            }
+            const float val = finish_row<TYPE>(A);
+            if ((lane & 7) == 0) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
+            STAMP(5);
+        }
+        batchctr += 1;
+    }
+#undef BAMD_LOAD_NEXT
+}
+
+template <int TYPE, typename REC, int EPI, int PRO>
+__device__ __forceinline__ void split_dispatch(const uint8_t * w, int nb, int first, int count, int stride, float * out, const float * res,
+                                               const ProArgs & pa, bool do_pro, float * part0, int & rgctr) {
+    const int nbw = nb >> 3;
+    if (nbw == 2)       split_stream<TYPE, REC, 2, 4, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
+    else if (nbw == 7)  split_stream<TYPE, REC, 7, 1, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
+    else if (nbw == 4)  split_stream<TYPE, REC, 4, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
+    else if (nbw == 1)  split_stream<TYPE, REC, 1, 8, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
+    else __builtin_trap();                               // the launcher only picks this kernel for the shapes above
+}
+
+// host must check bamd_split_supported(nb) before choosing this kernel
+template <int PRO, int EPI>
+__global__ void __launch_bounds__(512) matvec_split_kernel(bamd_mv_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = a.K >> 8;
+    const ProArgs pa = carve_lds(a, smem);
+    float * part0 = (float *) (((uintptr_t) (pa.red + 16) + 15) & ~(uintptr_t) 15);
+    int rgctr = 0;
+    bool pro_done = false;
+    int off = 0;
+    const int slot = blockIdx.x, stride = gridDim.x;         // row-groups are dealt to WORKGROUPS here
+    for (int s = 0; s < a.nseg; ++s) {
+        const int nrg = a.seg[s].nrows >> 3;
+        const int k0 = off <= slot ? 0 : (off - slot + stride - 1) / stride;
+        const int g0 = slot + k0 * stride;
+        const int count = g0 < off + nrg ? (off + nrg - 1 - g0) / stride + 1 : 0;
+        if (count > 0) {
+            const int t = a.seg[s].type;
+            const uint8_t * w = (const uint8_t *) a.seg[s].w;
+            if (t == BAMD_Q4_K)      split_dispatch<BAMD_Q4_K, RecQ4K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
+            else if (t == BAMD_Q5_K) split_dispatch<BAMD_Q5_K, RecQ5K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
+            else                     split_dispatch<BAMD_Q6_K, RecQ6K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
+            pro_done = true;
+        }
+        off += nrg;
+    }
+    if (!pro_done) { ActPro<PRO == BAMD_PRO_NORM> ap; BAMD_PRO_ISSUE(ap, pa); BAMD_PRO_FINISH(ap, pa); }
 }
 
 // ===========================================================================================================
@@ -674,6 +962,258 @@ __global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Fused single-token attention for short/medium contexts (n_kv <= BAMD_ATTN_FUSED_MAX): ONE launch per layer,
+// one workgroup per QUERY head.  RoPE -> KV store -> scores -> softmax -> P.V with scores/probabilities in LDS.
+// The K/V rows of a KV head are re-read by the GQ query heads that share it (L2 traffic only).  Same arithmetic
+// and order as the three-kernel path above.
+// -----------------------------------------------------------------------------------------------------------
+#define BAMD_ATTN_FUSED_MAX 2048
+#define BAMD_ATTN_VTILE 256                      /* positions of V staged per pass */
+// K and V^T tiles are fetched with 16-byte-per-lane loads (a 2-byte-per-lane gather is 8x more L1 address work) and
+// TRANSPOSED on their way into LDS, so that the lane which carries SIMD-lane e of the reference's 8-wide chain finds its
+// operands of consecutive steps l contiguous:   Kt[row][e][l], Vt[d][e][l], qt[e][l], pt[e][l]  ->  ds_read_b128 only.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ __attribute__((aligned(16))) float qt[256];          // [e][hd/8]
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
+    __shared__ __attribute__((aligned(16))) unsigned short k16_s[256];   // this token's roped K row, natural order
+    __shared__ __attribute__((aligned(16))) float sc[BAMD_ATTN_FUSED_MAX];   // scores, natural order
+    __shared__ __attribute__((aligned(16))) float pt[BAMD_ATTN_FUSED_MAX];   // probabilities, [tile][e][l]
+    __shared__ float redf[8];
+    __shared__ double redd[8];
+    const bamd_step_state * st = a.st;
+    const int pos = st->pos, n_kv = st->n_kv;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
+    const int h = blockIdx.x, hk = h / gq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    const int L = hd / 8;                                          // chain steps per K row (<= 32)
+    const float * rope = a.rope + (size_t) pos * hd;
+    STAMP(0);
+    // RoPE (NORM mode) of this head's q and of the KV head's k — ggml.c:14130-14143
+    for (int i = tid; i < hd; i += blockDim.x) {                   // i < hd/2: q pair, else k pair
+        const int p = i < hd / 2 ? i : i - hd / 2;
+        const float c = rope[2 * p], s = rope[2 * p + 1];
+        const float * src = i < hd / 2 ? a.q + (size_t) h * hd + 2 * p : a.k + (size_t) hk * hd + 2 * p;
+        const float x0 = src[0], x1 = src[1];
+        const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
+        const float r0 = t0 - t1, r1 = t2 + t3;
+        if (i < hd / 2) {
+            const int n0 = 2 * p, n1 = 2 * p + 1;                  // element n -> [n & 7][n >> 3]
+            qt[(n0 & 7) * L + (n0 >> 3)] = r0; qt[(n1 & 7) * L + (n1 >> 3)] = r1;
+            q16t[(n0 & 7) * L + (n0 >> 3)] = f2h(r0); q16t[(n1 & 7) * L + (n1 >> 3)] = f2h(r1);
+        } else { k16_s[2 * p] = f2h(r0); k16_s[2 * p + 1] = f2h(r1); }
+    }
+    __syncthreads();
+    // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
+    if (h == hk * gq) {
+        for (int i = tid; i < hd; i += blockDim.x) {
+            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16_s[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + pos] = f2h(a.v[hk * hd + i]);
+        }
+    }
+    STAMP(1);
+    // ---- scores: tiles of 256 positions; all 16-byte K loads of a tile are issued first (one HBM round trip per tile),
+    //      then the tile is transposed into LDS: Kt[r][e][l] halves, row = hd*2 + 16 bytes ----
+    const int krow_b = hd * 2 + 16;
+    const int lsh = 31 - __clz(L);                                 // L is a power of two for hd in {32, 64, 128, 256}
+    // first V^T tile: requested now, consumed after the softmax (its HBM round trip hides behind scores + softmax)
+    const int np0 = n_kv < BAMD_ATTN_VTILE ? n_kv : BAMD_ATTN_VTILE;
+    const int LV0 = np0 / 8;
+    uint4 vreg[8];                                                 // hd * LV0 chunks / 512 threads <= 8 for hd <= 128
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = tid + u * 512;
+        vreg[u] = make_uint4(0, 0, 0, 0);
+        if (c < hd * LV0) { const int d = c / LV0, l = c - d * LV0; vreg[u] = *(const uint4 *) (a.vc + (size_t) (hk * hd + d) * n_ctx + l * 8); }
+    }
+    for (int t0 = 0; t0 < n_kv; t0 += 256) {
+        const int nr = n_kv - t0 < 256 ? n_kv - t0 : 256;
+        uint4 kreg[8];                                             // 256 rows * L chunks / 512 threads <= 16; hd <= 128 -> 8
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + u * 512, r = c >> lsh, l = c & (L - 1), i = t0 + r;
+            kreg[u] = make_uint4(0, 0, 0, 0);
+            if (r < nr && i <= pos) kreg[u] = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + l * 8);
+        }
+        for (int u2 = 8; u2 * 512 < 256 * L; ++u2) { (void) u2; }  // hd = 256 handled by the second loop below
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + u * 512, r = c >> lsh, l = c & (L - 1), i = t0 + r;
+            if (r < nr) {
+                uint4 val = kreg[u];
+                if (i == pos) val = *(const uint4 *) (k16_s + l * 8);      // this token's row is not visible in the cache yet
+                unsigned short * dst = (unsigned short *) (smem + r * krow_b) + l;
+                const uint32_t w4[4] = { val.x, val.y, val.z, val.w };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dst[(2 * j) * L] = (unsigned short) w4[j]; dst[(2 * j + 1) * L] = (unsigned short) (w4[j] >> 16); }
+            }
+        }
+        for (int c = tid + 8 * 512; c < nr * L; c += 512) {        // only when hd = 256
+            const int r = c >> lsh, l = c & (L - 1), i = t0 + r;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (i <= pos) val = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + l * 8);
+            if (i == pos) val = *(const uint4 *) (k16_s + l * 8);
+            unsigned short * dst = (unsigned short *) (smem + r * krow_b) + l;
+            const uint32_t w4[4] = { val.x, val.y, val.z, val.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[(2 * j) * L] = (unsigned short) w4[j]; dst[(2 * j + 1) * L] = (unsigned short) (w4[j] >> 16); }
+        }
+        __syncthreads();
+        if (t0 == 0) STAMP(2);
+        for (int r0 = 0; r0 < nr; r0 += 64) {
+            const int r = r0 + wave * 8 + (lane >> 3), i = t0 + r;
+            float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
+            if (r < nr && i <= pos) {
+                const uint4 * kp = (const uint4 *) (smem + r * krow_b + e * L * 2);
+                const unsigned short * kh = (const unsigned short *) kp;
+                if (!a.prefill_mode) {
+                    float acc = 0.f;                               // tinyBLAS F16 x F32, KN = 8 (sgemm.cpp:405-431)
+                    for (int l0 = 0; l0 < L; l0 += 8) {
+                        unsigned short kb[8]; float qb[8];
+                        if ((L & 7) == 0) {
+                            const uint4 kk = kp[l0 >> 3];
+                            kb[0] = (unsigned short) kk.x; kb[1] = (unsigned short) (kk.x >> 16); kb[2] = (unsigned short) kk.y; kb[3] = (unsigned short) (kk.y >> 16);
+                            kb[4] = (unsigned short) kk.z; kb[5] = (unsigned short) (kk.z >> 16); kb[6] = (unsigned short) kk.w; kb[7] = (unsigned short) (kk.w >> 16);
+                            const float4 qa = *(const float4 *) (qt + e * L + l0), qc = *(const float4 *) (qt + e * L + l0 + 4);
+                            qb[0] = qa.x; qb[1] = qa.y; qb[2] = qa.z; qb[3] = qa.w; qb[4] = qc.x; qb[5] = qc.y; qb[6] = qc.z; qb[7] = qc.w;
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { kb[u] = l0 + u < L ? kh[l0 + u] : (unsigned short) 0; qb[u] = l0 + u < L ? qt[e * L + l0 + u] : 0.f; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (l0 + u < L) acc = fmaf(h2f(kb[u]), qb[u], acc);
+                    }
+                    v = acc;
+                    v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
+                } else {
+                    float a4[4] = { 0.f, 0.f, 0.f, 0.f };          // ggml_vec_dot_f16, 4 accumulators x 8 lanes (ggml.c:2038)
+                    for (int l = 0; l < L; ++l) a4[l & 3] = fmaf(h2f(kh[l]), h2f(q16t[e * L + l]), a4[l & 3]);
+                    const float s02 = a4[0] + a4[2], s13 = a4[1] + a4[3];
+                    v = s02 + s13;
+                    v = v + dpp_f_shl4(v); v = v + dpp_f_xor1(v); v = v + dpp_f_xor2(v);   // lo+hi, then two hadd_ps
+                }
+            }
+            if (e == 0 && r < nr) sc[i] = v;
+        }
+        __syncthreads();
+    }
+    STAMP(3);
+    // ---- softmax (ggml.c:13682-13778 + :2619-2671): wp = s*scale (+mask), max, exp, 8-chunk f32 sums, double total ----
+    const float scale = a.kq_scale;
+    float mx = -INFINITY;
+    for (int i = tid; i < n_kv; i += blockDim.x) { const float w = sc[i] * scale; mx = w > mx ? w : mx; }
+    {   // -inf..inf floats: order-preserving key for an unsigned max
+        uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        u = wave_max_u32(u);
+        if (lane == 0) redf[wave] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+    __syncthreads();
+    mx = redf[0];
+    for (int w = 1; w < 8; ++w) mx = redf[w] > mx ? redf[w] : mx;
+    double sum = 0.0;
+    for (int i = tid; i < n_kv; i += blockDim.x) {                 // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+        const float w = sc[i] * scale;
+        const float val = v_expf(w - mx);
+        sc[i] = val;
+        float c = val;
+        c = c + dpp_f_shl4(c); c = c + dpp_f_xor2(c); c = c + dpp_f_xor1(c);
+        if (e == 0) sum += (double) c;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) redd[wave] = sum;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < 8; ++w) tot += redd[w];
+    const float fs = (float) (1.0 / tot);
+    for (int i = tid; i < n_kv; i += blockDim.x) {                 // p = val * (float)(1/sum), stored as pt[tile][e][l]
+        const int t0 = i / BAMD_ATTN_VTILE, j = i - t0 * BAMD_ATTN_VTILE;
+        const int np = n_kv - t0 * BAMD_ATTN_VTILE < BAMD_ATTN_VTILE ? n_kv - t0 * BAMD_ATTN_VTILE : BAMD_ATTN_VTILE;
+        pt[t0 * BAMD_ATTN_VTILE + (j & 7) * (np / 8) + (j >> 3)] = sc[i] * fs;
+    }
+    __syncthreads();
+    STAMP(4);
+    // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (sgemm.cpp:405-431: A = V^T row, B = p);
+    //      V^T staged transposed in tiles of BAMD_ATTN_VTILE positions: Vt[d][e][l], row = np*2 + 16 bytes ----
+    const int d_lo = wave * 8 + (lane >> 3);
+    float acc4[4] = { 0.f, 0.f, 0.f, 0.f };                        // d_lo, d_lo+64, +128, +192
+    for (int p0 = 0; p0 < n_kv; p0 += BAMD_ATTN_VTILE) {
+        const int np = n_kv - p0 < BAMD_ATTN_VTILE ? n_kv - p0 : BAMD_ATTN_VTILE;   // multiple of 32
+        const int LV = np / 8, vrow_b = np * 2 + 16;
+        // chunk c = (row d, step l): 8 positions e = 0..7; the first tile's chunks were prefetched before the scores phase
+#define BAMD_STAGE_V(c_, val_in) do { \
+            const int d = (c_) / LV, l = (c_) - d * LV; \
+            uint4 val = (val_in); \
+            const int idx = pos - (p0 + l * 8);                    /* column `pos` is being written by another workgroup: */ \
+            if (idx >= 0 && idx < 8) {                             /* splice this token's v (f16) into the chunk */ \
+                const uint32_t hv = f2h(a.v[hk * hd + d]); \
+                const uint32_t keep = (idx & 1) ? 0x0000ffffu : 0xffff0000u, ins = (idx & 1) ? hv << 16 : hv; \
+                const int wi = idx >> 1; \
+                val.x = wi == 0 ? (val.x & keep) | ins : val.x; val.y = wi == 1 ? (val.y & keep) | ins : val.y; \
+                val.z = wi == 2 ? (val.z & keep) | ins : val.z; val.w = wi == 3 ? (val.w & keep) | ins : val.w; \
+            } \
+            unsigned short * dst = (unsigned short *) (smem + d * vrow_b) + l; \
+            dst[0 * LV] = (unsigned short) val.x; dst[1 * LV] = (unsigned short) (val.x >> 16); \
+            dst[2 * LV] = (unsigned short) val.y; dst[3 * LV] = (unsigned short) (val.y >> 16); \
+            dst[4 * LV] = (unsigned short) val.z; dst[5 * LV] = (unsigned short) (val.z >> 16); \
+            dst[6 * LV] = (unsigned short) val.w; dst[7 * LV] = (unsigned short) (val.w >> 16); \
+        } while (0)
+        if (p0 == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = tid + u * 512; if (c < hd * LV) BAMD_STAGE_V(c, vreg[u]); }
+            for (int c = tid + 8 * 512; c < hd * LV; c += 512) BAMD_STAGE_V(c, *(const uint4 *) (a.vc + (size_t) (hk * hd + c / LV) * n_ctx + p0 + (c % LV) * 8));
+        } else {
+            for (int c0 = tid; c0 < hd * LV; c0 += 8 * 512) {      // 8 independent loads in flight per thread
+                uint4 vt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int c = c0 + u * 512; vt[u] = make_uint4(0, 0, 0, 0); if (c < hd * LV) vt[u] = *(const uint4 *) (a.vc + (size_t) (hk * hd + c / LV) * n_ctx + p0 + (c % LV) * 8); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int c = c0 + u * 512; if (c < hd * LV) BAMD_STAGE_V(c, vt[u]); }
+            }
+        }
+#undef BAMD_STAGE_V
+        __syncthreads();
+        if (p0 == 0) STAMP(5);
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = d_lo + 64 * dd;
+            if (d < hd) {
+                const uint4 * vp = (const uint4 *) (smem + d * vrow_b + e * LV * 2);   // LV % 4 == 0 -> 8-byte aligned; use 8-half groups when LV % 8 == 0
+                const unsigned short * vh = (const unsigned short *) vp;
+                const float * pp = pt + p0 + e * LV;
+                float acc = acc4[dd];
+                for (int l0 = 0; l0 < LV; l0 += 8) {
+                    unsigned short vb[8]; float pb[8];
+                    if ((LV & 7) == 0) {
+                        const uint4 vv = vp[l0 >> 3];
+                        vb[0] = (unsigned short) vv.x; vb[1] = (unsigned short) (vv.x >> 16); vb[2] = (unsigned short) vv.y; vb[3] = (unsigned short) (vv.y >> 16);
+                        vb[4] = (unsigned short) vv.z; vb[5] = (unsigned short) (vv.z >> 16); vb[6] = (unsigned short) vv.w; vb[7] = (unsigned short) (vv.w >> 16);
+                        const float4 pa = *(const float4 *) (pp + l0), pc = *(const float4 *) (pp + l0 + 4);
+                        pb[0] = pa.x; pb[1] = pa.y; pb[2] = pa.z; pb[3] = pa.w; pb[4] = pc.x; pb[5] = pc.y; pb[6] = pc.z; pb[7] = pc.w;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { vb[u] = l0 + u < LV ? vh[l0 + u] : (unsigned short) 0; pb[u] = l0 + u < LV ? pp[l0 + u] : 0.f; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (l0 + u < LV) acc = fmaf(h2f(vb[u]), pb[u], acc);
+                }
+                acc4[dd] = acc;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        const int d = d_lo + 64 * dd;
+        if (d < hd) {
+            float v = acc4[dd];
+            v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
+            if (e == 0) a.out[(size_t) h * hd + d] = v;
+        }
+    }
+    STAMP(6);
+}
+
 // ===========================================================================================================
 // launchers
 // ===========================================================================================================
@@ -704,17 +1244,41 @@ static void launch_mv_epi(const bamd_mv_args & a, int epi, int grid, hipStream_t
         case BAMD_EPI_ARGMAX:   hipLaunchKernelGGL((matvec_kernel<PRO, BAMD_EPI_ARGMAX>),   dim3(grid), dim3(512), lds, s, a); break;
     }
 }
+template <int PRO>
+static void launch_mv_split(const bamd_mv_args & a, int epi, int grid, hipStream_t s) {
+    const int nb = a.K >> 8;
+    const int nbw = nb >> 3;
+    const int M = nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8;          // must match split_dispatch
+    const size_t lds = act_lds_bytes(a.K) + 16 + 2 * (size_t) M * nb * (64 + 8 + 8 + 32) * 4;
+    if (epi == BAMD_EPI_ADD) hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_ADD>),   dim3(grid), dim3(512), lds, s, a);
+    else                     hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_STORE>), dim3(grid), dim3(512), lds, s, a);
+}
+
+static bool split_supported(int nb) { const int nbw = nb >> 3; return (nb & 7) == 0 && (nbw == 1 || nbw == 2 || nbw == 4 || nbw == 7); }
 
 void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipStream_t s) {
     int nrg = 0;
     if (epi == BAMD_EPI_SILU_MUL) nrg = a.seg[0].nrows >> 3;
     else for (int i = 0; i < a.nseg; ++i) nrg += a.seg[i].nrows >> 3;
-    int grid = n_cu > 0 ? n_cu : 256;                // one 8-wave workgroup per CU (160 VGPRs -> 3 waves/SIMD)
+    const int cus = n_cu > 0 ? n_cu : 256;
+    // few row-groups: split K over the 8 waves of a workgroup (mode B); otherwise one wave per row-group (mode A)
+    const bool can_split = (epi == BAMD_EPI_STORE || epi == BAMD_EPI_ADD) && split_supported(a.K >> 8);
+    const bool split = a.mode == 2 ? can_split : a.mode == 1 ? false : (can_split && nrg < 8 * cus);
+    int grid = cus;                                          // one 8-wave workgroup per CU
     if (grid > nrg) grid = nrg;
     if (grid < 1) grid = 1;
+    if (split) {
+        if (pro == BAMD_PRO_NORM) launch_mv_split<BAMD_PRO_NORM>(a, epi, grid, s);
+        else                      launch_mv_split<BAMD_PRO_PLAIN>(a, epi, grid, s);
+        return;
+    }
     if (pro == BAMD_PRO_NORM) launch_mv_epi<BAMD_PRO_NORM>(a, epi, grid, s);
     else                      launch_mv_epi<BAMD_PRO_PLAIN>(a, epi, grid, s);
 }
+
+#ifdef BAMD_TIMING
+void bamd_read_stamps(unsigned long long * host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16); }
+#endif
 
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s) {
@@ -723,7 +1287,15 @@ void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_
 
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 31)) return 1;
-    int ty = max_tiles < 1 ? 1 : max_tiles;
+    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    if (a.n_ctx <= BAMD_ATTN_FUSED_MAX && max_tiles >= 0) {
+        // context fits the LDS score buffer: one fused launch per layer, one workgroup per query head
+        { size_t ks = (size_t) 256 * (a.hd * 2 + 16), vs = (size_t) a.hd * (BAMD_ATTN_VTILE * 2 + 16);
+          hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), ks > vs ? ks : vs, s, a, gq); }
+        return 0;
+    }
+    int ty = max_tiles < 0 ? -max_tiles : max_tiles;
+    if (ty < 1) ty = 1;
     dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
     switch (gq) {
 #define CASE(G) case G: \

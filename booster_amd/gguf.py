@@ -148,7 +148,7 @@ class GGUFWriter:
         with open(path, "wb") as f:
             f.write(out)
             for (name, shape, ttype, data) in self.tensors:
-                f.write(data.tobytes())
+                f.write(memoryview(data))
                 f.write(b"\0" * ((-data.size) % DEFAULT_ALIGNMENT))
 
 
@@ -189,9 +189,21 @@ def q4_k_m_type(name, il, n_layer):
 
 
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
-                          type_fn=None, rope_freqs=False, embd_type=Q4_K):
-    """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks."""
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False):
+    """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.
+    reuse_layers: generate each (tensor kind, type) once and reuse the bytes in every layer (fast path for the
+    multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged)."""
     rng = np.random.default_rng(seed)
+    _cache = {}
+
+    def kq(t, cols, rows, amp, tag):
+        if not reuse_layers:
+            return random_kquant_tensor(t, cols, rows, rng, amp)
+        key = (tag, t, cols, rows)
+        if key not in _cache:
+            _cache[key] = random_kquant_tensor(t, cols, rows, rng, amp)
+        return _cache[key]
+
     type_fn = type_fn or (lambda name, il: q4_k_m_type(name, il, L))
     hd = E // H
     w = GGUFWriter()
@@ -226,9 +238,9 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
         for nm, rows, cols, amp in (("attn_q", E, E, 2.0), ("attn_k", Hkv * hd, E, 2.0), ("attn_v", Hkv * hd, E, 1.0),
                                     ("attn_output", E, E, 1.0)):
             t = type_fn(nm, il)
-            w.add_tensor(p + nm + ".weight", [cols, rows], t, random_kquant_tensor(t, cols, rows, rng, amp))
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
         w.add_tensor(p + "ffn_norm.weight", [E], F32, norm())
         for nm, rows, cols, amp in (("ffn_gate", F, E, 1.5), ("ffn_up", F, E, 1.5), ("ffn_down", E, F, 1.0)):
             t = type_fn(nm, il)
-            w.add_tensor(p + nm + ".weight", [cols, rows], t, random_kquant_tensor(t, cols, rows, rng, amp))
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
     w.write(path)

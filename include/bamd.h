@@ -77,12 +77,16 @@ int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token);
  * KV bytes read).  Arrays must hold 3 entries. */
 int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes);
 
+/* Micro-benchmark: `iters` back-to-back launches of one mat-vec shape on random resident weights (pro: 0 plain,
+ * 1 RMSNorm prologue; epi: 0 store, 1 +residual, 2 silu(gate)*up pair, 3 store+arg-max; mode as below). */
+int bamd_bench_matvec(int type, int nrows, int k, int pro, int epi, int mode, int iters, float * us_per_launch);
+
 /* ---- op-level entry points (parity tests call the kernels through these; host pointers in, host out) ---- */
 /* quantize_row_q8_K (ggml-quants.c:3593) of norm_w ? rms_norm(x)*norm_w : x ; out = k/256 block_q8_K (292 B each) */
 int bamd_op_quantize_q8_K(const float * x, int64_t k, const float * norm_w, float eps, void * out_blocks);
 /* y[nrows] = W . Q8_K(act) (+ residual), W = GGUF-layout blocks [nrows][k] of `type`  (ggml_compute_forward_mul_mat, ggml.c:12277) */
 int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
-                        const float * residual, float * y);
+                        const float * residual, float * y, int mode /* 0 auto, 1 wave-per-row-group, 2 split-K */);
 /* y[nrows] = silu(Wg . a) * (Wu . a)  (llm_build_ffn LLM_FFN_SILU/LLM_FFN_PAR, llama.cpp:7960-8085) */
 int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
                         float eps, float * y);

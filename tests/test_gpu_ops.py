@@ -48,14 +48,20 @@ def test_rmsnorm_quantize(bamd, po, K):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (4096, 512), (14336, 64)])
-def test_mul_mat_vec(bamd, po, t, K, rows):
+@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (2048, 4104), (4096, 512), (8192, 24), (14336, 64), (14336, 2064)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_mul_mat_vec(bamd, po, t, K, rows, mode):
+    """mode 1: one wave per row-group; mode 2: split-K over the 8 waves of a workgroup (where the shape allows;
+    the launcher falls back to mode 1 otherwise).  Both must give the reference's bits."""
     rng = np.random.default_rng(1000 * t + K)
     W = random_kquant_tensor(t, K, rows, rng)
     x = (rng.standard_normal(K) * 3).astype(np.float32)
-    got = bamd.op_mul_mat_vec(t, W, rows, K, x)
-    want = po.mul_mat_q(t, W, rows, K, x)[0]
-    assert_bits(got, want, "mul_mat_vec type %d K %d" % (t, K))
+    res = rng.standard_normal(rows).astype(np.float32) if rows % 16 == 8 else None
+    got = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=mode)
+    want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0]
+    if res is not None:
+        want = want + res
+    assert_bits(got, want, "mul_mat_vec type %d K %d mode %d" % (t, K, mode))
 
 
 @pytest.mark.parametrize("t", TYPES)
@@ -158,7 +164,8 @@ def oracle_attention(po, q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill)
 
 @pytest.mark.parametrize("H,Hkv,hd", [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 32)])
 @pytest.mark.parametrize("prefill", [False, True])
-def test_attention(bamd, po, H, Hkv, hd, prefill):
+@pytest.mark.parametrize("long_path", [False, True])
+def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
     n_ctx = 256
     rng = np.random.default_rng(H * 100 + hd + prefill)
     Ekv = Hkv * hd
@@ -171,7 +178,10 @@ def test_attention(bamd, po, H, Hkv, hd, prefill):
         rope = po.rope_cache(pos, hd, 500000.0)
         kc2, vc2 = kc.copy(), vc.copy()
         want, wprobs = oracle_attention(po, q, k, v, kc2, vc2, rope, H, Hkv, hd, n_ctx, pos, prefill)
-        got, gprobs = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill, want_probs=True)
+        if long_path:      # three-kernel path (contexts beyond the fused kernel's LDS budget); exposes the probabilities
+            got, gprobs = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill, want_probs=True)
+            assert_bits(gprobs[:wprobs.size], wprobs, "softmax pos %d" % pos)
+        else:              # fused single-launch path
+            got = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill)
         assert np.array_equal(kc, kc2) and np.array_equal(vc, vc2), "KV store differs at pos %d" % pos
-        assert_bits(gprobs[:wprobs.size], wprobs, "softmax pos %d" % pos)
         assert_bits(got, want, "attention out pos %d" % pos)
