@@ -48,7 +48,8 @@ def lib():
         L.bamd_decode.argtypes = [vp, vp, ci, ci]
         L.bamd_get_logits.restype = C.POINTER(C.c_float); L.bamd_get_logits.argtypes = [vp]
         L.bamd_generate_greedy.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_float)]
-        L.bamd_stage_step.argtypes = [vp, C.c_int32, ci, vp, vp, ci, ci, vp]
+        L.bamd_stage_step.argtypes = [vp, C.c_int32, vp, ci, vp, vp, ci, ci, vp]
+        L.bamd_stage_token_to.argtypes = [vp, vp, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
@@ -129,8 +130,12 @@ class Context:
         _chk(lib().bamd_profile_step(self.h, pos, _p(launches), _p(ms), _p(nbytes)))
         return launches, ms, nbytes
 
-    def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr):
-        _chk(lib().bamd_stage_step(self.h, int(token), int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits), int(prefill_mode), stream_ptr))
+    def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr, token_dev_ptr=None):
+        _chk(lib().bamd_stage_step(self.h, int(token), token_dev_ptr, int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits),
+                                   int(prefill_mode), stream_ptr))
+
+    def stage_token_to(self, token_dev_ptr, stream_ptr):
+        _chk(lib().bamd_stage_token_to(self.h, token_dev_ptr, stream_ptr))
 
     def stage_argmax(self, stream_ptr):
         t = C.c_int32(0)

@@ -466,25 +466,37 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
 }
 
 // ---- layer-split stage ---------------------------------------------------------------------------------
-extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_context * c, int32_t token, int pos, const void * hidden_in_dev, void * hidden_out_dev,
-                               int want_logits, int prefill_mode, void * hip_stream) {
+extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev,
+                               void * hidden_out_dev, int want_logits, int prefill_mode, void * hip_stream) {
     bamd_model * m = c->m;
     HIPC(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
-    // state for exactly this token: pos_base = pos, step = 0, one forced token
+    // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx;
     HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(c->forced, &token, 4, hipMemcpyHostToDevice, s));
-    if (m->with_embd) enqueue_begin(c, 1, 1, s);
+    const int32_t * forced = c->forced;
+    if (token_dev) forced = (const int32_t *) token_dev;
+    else HIPC(hipMemcpyAsync(c->forced, &token, 4, hipMemcpyHostToDevice, s));
+    if (m->with_embd) bamd_launch_step_begin(c->st, forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, s);
     else {
         // no embedding on this stage: still advance the device state (pos, n_kv), then take the hidden state
-        bamd_launch_step_begin(c->st, c->forced, 1, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, s);
+        bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, s);
         HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
     }
     if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
     if (m->with_output) { if (want_logits) enqueue_lm_head(c, s, nullptr); }
     else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+// write the arg-max token of the last lm_head of this (last) stage into a device int32 — no host round trip
+extern "C" __attribute__((visibility("default"))) int bamd_stage_token_to(bamd_context * c, void * token_dev, void * hip_stream) {
+    hipStream_t s = (hipStream_t) hip_stream;
+    bamd_model * m = c->m;
+    HIPC(hipSetDevice(m->device));
+    // flush-only step_begin: decodes best_key into out_tokens[n_out]; n_out was reset to 0 by bamd_stage_step
+    bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 0, s);
+    HIPC(hipMemcpyAsync(token_dev, c->out_tokens, 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token) {

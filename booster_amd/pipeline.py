@@ -1,0 +1,171 @@
+"""Layer-split decode across GPUs, one process per GPU (Booster's `gpus:` split: llama.cpp:5932-5969; the hop the
+reference does with cudaMemcpyPeerAsync + events: ggml-cuda.cu:2360-2411, ggml-backend.c:1751-1844).
+
+Rank r owns a contiguous layer range (+ embedding on rank 0, output_norm + lm_head on the last rank) and the KV slice
+of those layers.  Per token and boundary ONE point-to-point message moves the f32 hidden state [n_embd] to the next
+rank (torch.distributed send/recv: RCCL over xGMI with backend "nccl", gloo in the CPU tests); the arg-max token
+returns from the last rank to rank 0 the same way.  There is no collective: the path has no reduction.
+
+With one sequence the stages run strictly one after another (the reference's batch-1 behaviour: tokens/s does not grow
+with N).  With n_seq = N independent sequences in flight — Booster's pods — rank r works on sequence (tick - r) mod N,
+so every GPU streams its weight slice all the time.
+
+The schedule is host-side Python over a small `stage` object, so the same code runs on GPUs (HipStage) and in the
+world_size-2 gloo tests (a CPU fake stage).
+"""
+import time
+
+
+def split_layers(n_layer, n_stage):
+    """Equal `gpus:` weights: stage i gets layers [round(L*i/n), round(L*(i+1)/n))."""
+    cuts = [int(round(n_layer * (i + 1) / n_stage)) for i in range(n_stage)]
+    return list(zip([0] + cuts[:-1], cuts))
+
+
+class HipStage:
+    """One pipeline stage on one MI355X: booster_amd.Model slice + one Context (KV cache) per sequence in flight."""
+
+    def __init__(self, booster_amd, torch, path, device, layer_range, is_first, is_last, n_ctx, n_seq):
+        self.torch = torch
+        self.is_first, self.is_last = is_first, is_last
+        self.model = booster_amd.Model(path, device=device, layer_first=layer_range[0], layer_last=layer_range[1],
+                                       with_embd=is_first, with_output=is_last)
+        self.ctx = [booster_amd.Context(self.model, n_ctx) for _ in range(n_seq)]
+        self.n_embd = self.model.n_embd
+        self.device = torch.device("cuda", device)
+
+    def new_hidden(self):
+        return self.torch.zeros(self.n_embd, dtype=self.torch.float32, device=self.device)
+
+    def new_token(self):
+        return self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
+
+    def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
+        stream = self.torch.cuda.current_stream().cuda_stream
+        self.ctx[seq].stage_step(token_host, pos, None if hin is None else hin.data_ptr(), None if hout is None else hout.data_ptr(),
+                                 want_logits, prefill_mode, stream, None if token_dev is None else token_dev.data_ptr())
+
+    def token_to(self, seq, token_dev):
+        self.ctx[seq].stage_token_to(token_dev.data_ptr(), self.torch.cuda.current_stream().cuda_stream)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        for c in self.ctx:
+            c.close()
+        self.model.close()
+
+
+def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq):
+    """Greedy decode of n_seq sequences (same prompt) through `world` stages.
+
+    Global schedule in ROUNDS: with period P = max(n_seq, world), rank r computes (sequence s, position pos) at round
+    k = pos*P + s + r.  Every message is sent AND received in the same round — the hidden state of (s, pos) leaves rank r at
+    the start of round k+1, where rank r+1 takes it; the arg-max of (s, pos) is held by the last rank until round
+    (pos+1)*P + s, where rank 0 consumes it — and the operations of one round are issued as ONE batch_isend_irecv group.
+    So rounds are identical exchange steps on all ranks and no cycle of blocked point-to-point operations can form
+    (in-order RCCL streams or rendezvous gloo sends alike).  Positions < len(prompt) consume prompt tokens (known on rank 0),
+    later positions the arg-max fed back from the last rank.
+
+    Returns, on rank 0, for every sequence the list of tokens FED after the prompt (n_decode of them); elsewhere empty lists.
+    """
+    n_prompt = len(prompt)
+    total = n_prompt + n_decode                      # positions processed per sequence
+    first, last = rank == 0, rank == world - 1
+    P = max(n_seq, world)
+    hin = [stage.new_hidden() for _ in range(n_seq)] if not first else [None] * n_seq
+    hout = [stage.new_hidden() for _ in range(n_seq)] if not last else [None] * n_seq
+    tok = [stage.new_token() for _ in range(n_seq)]          # rank 0: token being fed ; last rank: arg-max being held
+    fed = [[] for _ in range(n_seq)]
+    prefill_mode = 1 if n_prompt > 1 else 0
+    last_round = (total - 1) * P + (n_seq - 1) + (world - 1) + 1
+
+    def slot(j):                                     # local index -> (pos, s) or None
+        if j < 0:
+            return None
+        pos, s = divmod(j, P)
+        return (pos, s) if s < n_seq and pos < total else None
+
+    for k in range(last_round + 1):
+        ops = []
+        if world > 1:
+            # ---- sends of round k ----
+            if not last:
+                prev = slot(k - 1 - rank)            # what I computed in the previous round
+                if prev is not None:
+                    ops.append(dist.P2POp(dist.isend, hout[prev[1]], rank + 1))
+            else:
+                need = slot(k)                       # what rank 0 computes this round
+                if need is not None and need[0] >= n_prompt:
+                    ops.append(dist.P2POp(dist.isend, tok[need[1]], 0))
+            # ---- receives of round k ----
+            cur = slot(k - rank)
+            if cur is not None:
+                if not first:
+                    ops.append(dist.P2POp(dist.irecv, hin[cur[1]], rank - 1))
+                elif cur[0] >= n_prompt:
+                    ops.append(dist.P2POp(dist.irecv, tok[cur[1]], world - 1))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        cur = slot(k - rank)
+        if cur is None:
+            continue
+        pos, s = cur
+        is_prompt = pos < n_prompt
+        want_logits = last and (pos >= n_prompt - 1) and (pos + 1 < total)
+        if first and not is_prompt:
+            fed[s].append(tok[s].clone())
+            tok_host, tok_dev = 0, tok[s]
+        elif first:
+            tok_host, tok_dev = int(prompt[pos]), None
+        else:
+            tok_host, tok_dev = 0, None
+        stage.step(s, tok_host, tok_dev, pos, hin[s], hout[s], want_logits, prefill_mode if is_prompt else 0)
+        if want_logits:
+            stage.token_to(s, tok[s])                # last rank (world > 1: held until rank 0's round; world == 1: fed next)
+    stage.sync()
+    return [[int(t.item()) for t in f] for f in fed]
+
+
+def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch):
+    """bench.py's N > 1 leg.  Returns the dict bench.py prints (value = whole-job tokens/s with N sequences in flight)."""
+    import booster_amd
+    ranges = split_layers(cfg["L"], N)
+    stage = HipStage(booster_amd, torch, path, local, ranges[rank], rank == 0, rank == N - 1, n_ctx, N)
+    dist.barrier()
+    # warm-up + prompt: every sequence through the prompt and `warmup` decode steps (untimed)
+    # (the pipeline is re-run from position 0 for the timed leg on fresh KV positions beyond: simpler — time a second call)
+    run_pipeline(stage, dist, rank, N, prompt, max(warmup, 1), N)
+    dist.barrier(); stage.sync()
+    t0 = time.perf_counter()
+    run_pipeline(stage, dist, rank, N, prompt, steps, N)
+    stage.sync(); dist.barrier()
+    dt_all = time.perf_counter() - t0
+    # the timed call re-processes the prompt; subtract a prompt-only run measured the same way
+    dist.barrier(); stage.sync()
+    t0 = time.perf_counter()
+    run_pipeline(stage, dist, rank, N, prompt, 1, N)
+    stage.sync(); dist.barrier()
+    dt_prompt = time.perf_counter() - t0
+    # single sequence in flight (latency-bound, the reference's batch-1 layer-split behaviour)
+    k1 = min(steps, 32)
+    dist.barrier(); stage.sync()
+    t0 = time.perf_counter()
+    run_pipeline(stage, dist, rank, N, prompt[:8], k1, 1)
+    stage.sync(); dist.barrier()
+    dt_single = time.perf_counter() - t0
+    t = torch.tensor([dt_all, dt_prompt, dt_single], dtype=torch.float64, device=stage.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_all, dt_prompt, dt_single = [float(v) for v in t.tolist()]
+    dt = max(dt_all - dt_prompt, 1e-9) * steps / max(steps - 1, 1)
+    value = N * steps / dt
+    stage.close()
+    return dict(value=round(value, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
+                config=dict(workload="Llama-3-8B Q4_K_M shapes (synthetic GGUF), greedy decode, layer-split over %d MI355X, %d sequences in flight, "
+                                     "128-token prompt, n_ctx %d" % (N, N, n_ctx),
+                            parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state per boundary per token" % N,
+                            layer_ranges=ranges, single_sequence_tokens_per_s=round(k1 / max(dt_single, 1e-9), 2),
+                            note="single_sequence = one request through all stages (stages idle in turn, the reference's batch-1 behaviour)"),
+                roofline=None)

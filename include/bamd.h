@@ -61,12 +61,15 @@ const float * bamd_get_logits(bamd_context * c);                        /* llama
 int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * out_tokens, float * elapsed_ms);
 
 /* ---- layer-split stage interface (one process per GPU; hidden state moves between stages) ---- */
-/* Run this stage's layers on one token.  hidden_in_dev: f32 [n_embd] device pointer (ignored on the first
- * stage, which embeds `token`); hidden_out_dev: f32 [n_embd] device pointer (ignored on the last stage, which
- * computes logits + arg-max instead).  Work is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream)
- * and NOT synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
-int bamd_stage_step(bamd_context * c, int32_t token, int pos, const void * hidden_in_dev, void * hidden_out_dev,
+/* Run this stage's layers on one token.  The token id comes from `token`, or — when token_dev is non-NULL — from that
+ * device int32 (no host round trip; used on the first stage).  hidden_in_dev: f32 [n_embd] device pointer (ignored on
+ * the first stage, which embeds the token); hidden_out_dev: f32 [n_embd] device pointer (ignored on the last stage,
+ * which computes logits + arg-max instead).  Work is enqueued on `hip_stream` (a hipStream_t; NULL = the default
+ * stream) and NOT synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
+int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev, void * hidden_out_dev,
                     int want_logits, int prefill_mode, void * hip_stream);
+/* last stage: write the arg-max of the last bamd_stage_step(want_logits=1) into a device int32 (stream-ordered). */
+int bamd_stage_token_to(bamd_context * c, void * token_dev, void * hip_stream);
 /* arg-max token of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
 int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token);
 

@@ -91,7 +91,31 @@ def test_layer_split_stages_equal_single_stage(bamd, tmp_path):
         ctxs[2].stage_step(t, pos, hid[1].data_ptr(), None, True, False, stream)
         tok = ctxs[2].stage_argmax(stream)
         assert tok == int(np.argmax(lg)), "pos %d" % pos
+        tdev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ctxs[2].stage_token_to(tdev.data_ptr(), stream)
+        assert int(tdev.item()) == tok
     for c in ctxs + [cf]:
         c.close()
     for s in stages + [full]:
         s.close()
+
+
+def test_pipeline_schedule_single_gpu(bamd, tmp_path):
+    """booster_amd.pipeline.run_pipeline with world = 1 on the GPU == bamd_decode greedy loop (token feedback on the device)."""
+    import torch
+    from booster_amd import pipeline
+    p = str(tmp_path / "syn3.gguf")
+    gguf.write_synthetic_llama(p, E=512, H=4, Hkv=1, L=3, F=768, V=512, seed=5)
+    prompt = [5, 9, 300, 17]
+    st = pipeline.HipStage(bamd, torch, p, 0, (0, 3), True, True, 64, 2)
+    fed = pipeline.run_pipeline(st, None, 0, 1, prompt, 6, 2)
+    st.close()
+    m = bamd.Model(p); ctx = bamd.Context(m, 64)
+    lg = ctx.decode(prompt, 0)
+    want = []
+    n_past = len(prompt)
+    for i in range(6):
+        t = int(np.argmax(lg)); want.append(t)
+        lg = ctx.decode([t], n_past); n_past += 1
+    assert fed[0] == want and fed[1] == want
+    ctx.close(); m.close()

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 (gloo): the layer-split schedule of booster_amd.pipeline — message order, token feedback, several
+sequences in flight — with a CPU stand-in for the GPU stage.  The stand-in is deterministic integer arithmetic, so the
+pipelined result must equal a sequential single-process evaluation."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+E, V = 16, 97
+
+
+class FakeStage:
+    """hidden' = (hidden * a + pos + layer-tag) mod P per layer; first stage embeds the token, last stage picks
+    token = (sum(hidden) * 31 + 7) mod V as its 'arg-max'."""
+
+    def __init__(self, layers, is_first, is_last):
+        self.layers, self.is_first, self.is_last = layers, is_first, is_last
+        self.last_tok = {}
+
+    def new_hidden(self): return torch.zeros(E, dtype=torch.float32)
+    def new_token(self): return torch.zeros(1, dtype=torch.int32)
+
+    def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
+        if self.is_first:
+            tok = int(token_dev.item()) if token_dev is not None else token_host
+            h = torch.arange(E, dtype=torch.float32) * 3 + tok
+        else:
+            h = hin.clone()
+        for l in self.layers:
+            h = torch.remainder(h * 5 + pos + 11 * l + seq * 0, 8191)
+        if self.is_last:
+            if want_logits:
+                self.last_tok[seq] = int((int(h.sum().item()) * 31 + 7) % V)
+        else:
+            hout.copy_(h)
+
+    def token_to(self, seq, token_dev): token_dev.fill_(self.last_tok[seq])
+    def sync(self): pass
+
+
+def reference(prompt, n_decode, n_layers):
+    st = FakeStage(list(range(n_layers)), True, True)
+    out, tok = [], None
+    for pos in range(len(prompt) + n_decode):
+        t = prompt[pos] if pos < len(prompt) else tok
+        if pos >= len(prompt):
+            out.append(t)
+        st.step(0, t, None, pos, None, None, True, 0)
+        tok = st.last_tok[0]
+    return out
+
+
+def worker(rank, world, port, n_seq, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from booster_amd import pipeline
+    ranges = pipeline.split_layers(5, world)
+    st = FakeStage(list(range(*ranges[rank])), rank == 0, rank == world - 1)
+    fed = pipeline.run_pipeline(st, dist, rank, world, [3, 1, 4, 1, 5], 7, n_seq)
+    if rank == 0:
+        q.put(fed)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_seq", [1, 2, 3])
+def test_layer_split_world2(n_seq):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + n_seq + (os.getpid() % 200)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, n_seq, q)) for r in range(2)]
+    for p in procs: p.start()
+    fed = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = reference([3, 1, 4, 1, 5], 7, 5)
+    assert len(fed) == n_seq
+    for f in fed:
+        assert f == want
+
+
+def test_split_layers():
+    from booster_amd import pipeline
+    assert pipeline.split_layers(32, 8) == [(4 * i, 4 * i + 4) for i in range(8)]
+    assert pipeline.split_layers(32, 1) == [(0, 32)]
+    r = pipeline.split_layers(80, 8)
+    assert r[0][0] == 0 and r[-1][1] == 80 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
