@@ -1,0 +1,382 @@
+// bamd_bridge.cpp — level 2 of the C-ABI: the nine cgo symbols of gotzmann/booster (include/booster_bridge.h) on top of the
+// MI355X runtime (include/bamd.h), plus the Janus sampler.  Restates the behaviour of cpp/bridge.cpp (init_context :118-171,
+// do_inference :175-658, C wrappers :697-835) and cpp/janus.cpp (sample_janus_token :191-331, initJanus :410-490, tokType
+// :723-800, isLower :826-850, isPedantic :381-392) — written from their behaviour, sharing no code with them.
+#include "../../include/bamd.h"
+#include "../../include/booster_bridge.h"
+#include "bamd_gguf.h"
+#include "bamd_vocab.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define BAMD_API extern "C" __attribute__((visibility("default")))
+const GgufFile * bamd_model_gguf(const bamd_model * m);
+
+namespace {
+const int EOS_HARDCODED = 2;                     // cpp/janus.h:18 (hard-coded id, kept as is)
+enum { LANG_ZERO = 0, LANG_EN = 2, SPACE_EN = 20, LANG_RU = 3, SPACE_RU = 30, LANG_OTHER = 4, SPACE_OTHER = 40 };
+
+struct JanusParams { int32_t janus = 1, depth = 200; float scale = 0.96f, hi = 0.99f, lo = 0.96f; };
+
+struct Stage { bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in = nullptr; };
+
+struct Pod {
+    std::vector<Stage> stages;
+    BamdVocab vocab;
+    int n_ctx = 0, n_predict = 0, n_batch = 512, n_vocab = 0, n_embd = 0;
+    JanusParams jp;
+    std::vector<float> scales, types;            // per-vocab Janus tables (cpp/janus.cpp:36-37 keeps them global)
+    bool janus_ready = false;
+    std::mt19937 rng;
+    std::atomic<bool> stop{ false };
+    std::vector<float> logits;                   // host copy the sampler may modify in place
+    // llama_timings equivalents (llama.cpp:18527-18551)
+    double t_p_eval_ms = 0, t_eval_ms = 0; int64_t n_p_eval = 0, n_eval = 0;
+};
+
+struct Job {                                     // status() hands out c_str() of the newest version; older versions are retired late
+    std::vector<std::unique_ptr<std::string>> versions;
+    int64_t prompt_eval = 0, timing = 0, prompt_tokens = 0; uint32_t seed = 0;
+    const std::string & cur() { if (versions.empty()) versions.emplace_back(new std::string()); return *versions.back(); }
+    void append(const std::string & piece) {
+        std::unique_ptr<std::string> n(new std::string(cur())); n->append(piece);
+        versions.push_back(std::move(n));
+        if (versions.size() > 16) versions.erase(versions.begin());
+    }
+};
+
+std::mutex g_mu;
+std::unordered_map<std::string, Job> g_jobs;
+Pod * g_pods[8] = { nullptr };
+std::string g_debug;
+bool dbg(const char * what) { return g_debug.find(what) != std::string::npos; }
+
+// ---- Janus ------------------------------------------------------------------------------------------------------------
+int tok_type(const std::string & in) {            // cpp/janus.cpp:723-800
+    int en = 0, ru = 0, other = 0; bool space = false;
+    const unsigned char * b = (const unsigned char *) in.data(); const size_t n = in.size();
+    if (n > 0 && b[0] == 0x20) space = true;
+    for (size_t i = 0; i < n; i++) {
+        if ((b[i] >= 0x41 && b[i] <= 0x5A) || (b[i] >= 0x61 && b[i] <= 0x7A)) { en++; continue; }
+        if (b[i] < 0x80) continue;
+        if (b[i] == 0xD0 && i + 1 < n) { i++; if ((b[i] >= 0x90 && b[i] <= 0xBF) || b[i] == 0x81) ru++; else other++; continue; }
+        if (b[i] == 0xD1 && i + 1 < n) { i++; if ((b[i] >= 0x80 && b[i] <= 0x8F) || b[i] == 0x91) ru++; else other++; continue; }
+        if (b[i] >= 0xC3 && b[i] < 0xE3) { i++; other++; continue; }
+        if (b[i] >= 0xE3 && b[i] < 0xF0) { i += 2; other++; continue; }
+        if (b[i] >= 0xF0) { i += 3; continue; }
+    }
+    if (space) { if (other) return SPACE_OTHER; if (en) return SPACE_EN; if (ru) return SPACE_RU; }
+    if (other) return LANG_OTHER; if (en) return LANG_EN; if (ru) return LANG_RU;
+    return LANG_ZERO;
+}
+bool is_lower(const std::string & in) {           // cpp/janus.cpp:826-850
+    const unsigned char * b = (const unsigned char *) in.data(); const size_t n = in.size();
+    if (n == 0) return false;
+    if (b[0] >= 0x61 && b[0] <= 0x7A) return true;
+    if (b[0] == 0xD0 && n >= 2 && b[1] >= 0xB0 && b[1] <= 0xBF) return true;
+    if (b[0] == 0xD1 && n >= 2 && ((b[1] >= 0x80 && b[1] <= 0x8F) || b[1] == 0x91)) return true;
+    return false;
+}
+bool is_pedantic(const std::string & t) {         // cpp/janus.cpp:381-392 (an empty piece parses as a number there, too)
+    char * end; strtol(t.c_str(), &end, 10);
+    if (*end == 0) return true;
+    if (t == " *" || t == " =" || t == " -" || t == " +") return true;
+    if (t == "{" || t == "}" || t == "[" || t == "]") return true;
+    if (t == " {" || t == " }" || t == " [" || t == " ]") return true;
+    if (t == "<|end_of_text|>" || t == "```") return true;
+    return false;
+}
+void init_janus(Pod & p) {                        // cpp/janus.cpp:410-490
+    JanusParams & jp = p.jp;
+    if (jp.depth <= 0) jp.depth = 200;
+    if (jp.scale <= 0.0 || jp.scale > 1.0) jp.scale = 0.97f;
+    if (jp.hi <= 0.0 || jp.hi > 1.0) jp.hi = 0.99f;
+    if (jp.lo <= 0.0 || jp.lo > 1.0) jp.lo = 0.96f;
+    const float scale = jp.scale;
+    static const float probes[] = { 0.20f, 0.22f, 0.25f, 0.28f, 0.30f, 0.32f, 0.33f, 0.35f, 0.36f, 0.38f,
+                                    0.40f, 0.42f, 0.44f, 0.45f, 0.46f, 0.48f, 0.50f, 0.52f, 0.53f, 0.55f };
+    p.scales.assign((size_t) p.n_vocab, 0.f); p.types.assign((size_t) p.n_vocab, 0.f);
+    for (int id = 0; id < p.n_vocab; id++) {
+        const std::string & piece = p.vocab.token_to_piece(id);
+        const int type = tok_type(piece); const bool lower = is_lower(piece); const size_t len = piece.size();
+        p.types[(size_t) id] = (float) type;
+        if (is_pedantic(piece)) { p.scales[(size_t) id] = (float) (1.0 - (1.0 - scale) * 0.20); continue; }
+        // the reference indexes probes[len/2] / probes[len] without a bound (UB past 20 entries): clamped here
+        if (type == LANG_RU && lower) { p.scales[(size_t) id] = (float) (1.0 - (1.0 - scale) * probes[std::min<size_t>(len / 2, 19)]); continue; }
+        if (type == LANG_EN && lower) { p.scales[(size_t) id] = (float) (1.0 - (1.0 - scale) * probes[std::min<size_t>(len, 19)]); continue; }
+        p.scales[(size_t) id] = scale;
+    }
+    p.janus_ready = true;
+}
+
+struct Cand { int id; float logit, p; };
+
+// cpp/janus.cpp:191-331 + llama_sample_token (llama-sampling.cpp:32-58, :610-631)
+int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, size_t promptLen, size_t pos, size_t max) {
+    const size_t V = (size_t) p.n_vocab, ctxSize = last_tokens.size();
+    const int lastToken = last_tokens[ctxSize - 1];
+    const float lastType = p.types[(size_t) lastToken];
+    if (V > (size_t) EOS_HARDCODED) logits[EOS_HARDCODED] *= 1.0 + log(1.0 + float(pos - promptLen) / float(max)) * 0.05;
+    const size_t depth = std::min((size_t) p.jp.depth, pos - promptLen);
+    for (size_t i = 0; i < depth; i++) {
+        const int id = last_tokens[ctxSize - 1 - i];
+        const float curType = p.types[(size_t) id];
+        if ((lastType == SPACE_RU || lastType == LANG_RU) && curType == LANG_RU) { logits[id] *= 1.0 - (1.0 - p.scales[(size_t) id]) * 0.20; continue; }
+        logits[id] *= p.scales[(size_t) id];
+    }
+    for (size_t id = 0; id < V; id++) {
+        const float curType = p.types[id];
+        if ((lastType == SPACE_RU || lastType == LANG_RU) && (curType == LANG_EN || curType == LANG_OTHER)) logits[id] *= 0.5;
+    }
+    std::vector<Cand> cand; cand.reserve(V);
+    for (int id = 0; id < (int) V; id++) cand.push_back(Cand{ id, logits[id], 0.0f });
+    std::sort(cand.data(), cand.data() + cand.size(), [](const Cand & a, const Cand & b) { return a.logit > b.logit; });
+    const int topToken = cand[0].id; const float topType = p.types[(size_t) topToken], topLogit = cand[0].logit;
+    float cutoff = p.jp.lo;
+    if (is_pedantic(p.vocab.token_to_piece(topToken)) || topType == LANG_RU || topType == LANG_EN) cutoff = p.jp.hi;
+    for (size_t i = 1; i < cand.size(); i++) if (cand[i].logit / topLogit < cutoff) { cand.resize(i); break; }
+    // softmax over the (sorted) shortlist, then one draw from std::discrete_distribution on the pod's mt19937
+    const float max_l = cand[0].logit; float cum = 0.0f;
+    for (auto & c : cand) { c.p = expf(c.logit - max_l); cum += c.p; }
+    std::vector<float> probs; probs.reserve(cand.size());
+    for (auto & c : cand) { c.p /= cum; probs.push_back(c.p); }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return cand[(size_t) dist(p.rng)].id;
+}
+
+// ---- model placement: Booster's gpus: split (cpp/bridge.cpp:745-750, llama.cpp:5932-5969) ----------------------------------
+bool plan_stages(int n_layer, const int gpu[4], std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
+    const int n_gpu_layers = gpu[0] + gpu[1] + gpu[2] + gpu[3];
+    if (n_gpu_layers <= 0) { err = "gpu1..gpu4 are all zero: this build has no CPU path"; return false; }
+    if (n_gpu_layers <= n_layer) { err = "sum(gpuN) must exceed the layer count (partial CPU offload is not supported: no CPU path)"; return false; }
+    const int act = std::min(n_gpu_layers, n_layer + 1);
+    float splits[4], sum = 0.f;
+    for (int i = 0; i < 4; ++i) { sum += (float) gpu[i]; splits[i] = sum; }
+    for (int i = 0; i < 4; ++i) splits[i] /= sum;
+    auto dev_of = [&](int i) { const float f = (float) i / (float) act; int d = 0; while (d < 3 && !(f < splits[d])) ++d; return d; };   // std::upper_bound
+    int start = 0, cur = dev_of(0);
+    for (int il = 1; il <= n_layer; ++il) {
+        const int d = il < n_layer ? dev_of(il) : -1;
+        if (d != cur) { out.push_back({ cur, { start, il } }); start = il; cur = d; }
+    }
+    // the output layer lives with the last fraction (llama.cpp:5961-5966); it must be the device of the last layers
+    const int dout = dev_of(act - 1);
+    if (dout != out.back().first) out.push_back({ dout, { n_layer, n_layer } });
+    return true;
+}
+
+int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // llama_decode for one micro-batch (<= 512 tokens)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p.stages.size() == 1) {
+        if (bamd_decode(p.stages[0].ctx, tokens, n, n_past)) return 1;
+        memcpy(p.logits.data(), bamd_get_logits(p.stages[0].ctx), (size_t) p.n_vocab * 4);
+    } else {
+        const int prefill = n > 1;
+        for (int t = 0; t < n; ++t) {
+            for (size_t s = 0; s < p.stages.size(); ++s) {
+                Stage & st = p.stages[s];
+                const bool last = s + 1 == p.stages.size();
+                void * hout = last ? nullptr : p.stages[s + 1].hidden_in;       // lives on the NEXT device; peer write
+                void * tmp_out = hout;
+                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, tmp_out, last && t == n - 1, prefill, nullptr)) return 1;
+                if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }   // hand-off: producer done before consumer starts
+            }
+        }
+        const float * lg = bamd_stage_get_logits(p.stages.back().ctx, nullptr);
+        if (!lg) return 1;
+        memcpy(p.logits.data(), lg, (size_t) p.n_vocab * 4);
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (n == 1) { p.t_eval_ms += ms; p.n_eval += 1; } else { p.t_p_eval_ms += ms; p.n_p_eval += n; }    // llama_synchronize, llama.cpp:18527-18551
+    return 0;
+}
+
+void pod_free(Pod * p) {
+    if (!p) return;
+    for (auto & s : p->stages) { if (s.hidden_in) { hipSetDevice(s.device); hipFree(s.hidden_in); } if (s.ctx) bamd_context_free(s.ctx); if (s.model) bamd_model_free(s.model); }
+    delete p;
+}
+}  // namespace
+
+// ===========================================================================================================================
+BAMD_API void init(char * swap, char * debug) {
+    (void) swap;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_debug = debug ? debug : "";
+    bamd_backend_init();
+}
+
+BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_size, int gpu1, int gpu2, int gpu3, int gpu4, int context, int predict,
+                            int32_t mirostat, float mirostat_tau, float mirostat_eta, float temperature, int top_k, float top_p, float typical_p,
+                            float repetition_penalty, int penalty_last_n, int32_t janus, int32_t depth, float scale, float hi, float lo, uint32_t seed,
+                            char * debug) {
+    (void) threads; (void) mirostat; (void) mirostat_tau; (void) mirostat_eta; (void) temperature; (void) top_k; (void) top_p; (void) typical_p;
+    (void) repetition_penalty; (void) penalty_last_n; (void) seed;
+    if (idx < 0 || idx >= 8 || !modelName) return nullptr;
+    { std::lock_guard<std::mutex> lk(g_mu); g_debug = debug ? debug : ""; }
+    const std::string path = modelName;                       // the Go side leaks its C.CString; we keep our own copy anyway
+    std::unique_ptr<Pod, void (*)(Pod *)> pod(new Pod(), pod_free);
+    const int ndev = bamd_device_count();
+    if (ndev <= 0) { fprintf(stderr, "initContext: %s\n", bamd_last_error()); return nullptr; }
+    // first look at the file to learn the layer count (a stage with no layers and no tensors is cheap to load)
+    bamd_model * probe = bamd_model_load(path.c_str(), 0, 0, 0, 0, 0);
+    if (!probe) { fprintf(stderr, "initContext: error: failed to load model '%s': %s\n", path.c_str(), bamd_last_error()); return nullptr; }
+    const int n_layer = bamd_model_n_layer(probe);
+    std::string err;
+    if (!pod->vocab.load(*bamd_model_gguf(probe), err)) { fprintf(stderr, "initContext: tokenizer: %s\n", err.c_str()); bamd_model_free(probe); return nullptr; }
+    pod->n_vocab = bamd_model_n_vocab(probe); pod->n_embd = bamd_model_n_embd(probe);
+    const int n_ctx_train = bamd_model_n_ctx_train(probe);
+    bamd_model_free(probe);
+    const int gpu[4] = { gpu1, gpu2, gpu3, gpu4 };
+    std::vector<std::pair<int, std::pair<int, int>>> plan;
+    if (!plan_stages(n_layer, gpu, plan, err)) { fprintf(stderr, "initContext: %s\n", err.c_str()); return nullptr; }
+    int n_ctx = context > 0 ? context : n_ctx_train;          // n_ctx 0 = from model (llama.cpp:16640)
+    n_ctx = (n_ctx + 31) / 32 * 32;
+    pod->n_ctx = n_ctx; pod->n_predict = predict;
+    pod->n_batch = (batch_size > 0 && batch_size <= n_ctx) ? batch_size : 512;          // cpp/bridge.cpp:152-160 (GPU branch)
+    pod->jp.janus = janus; pod->jp.depth = depth; pod->jp.scale = scale; pod->jp.hi = hi; pod->jp.lo = lo;
+    for (size_t s = 0; s < plan.size(); ++s) {
+        Stage st; st.device = plan[s].first;
+        if (st.device >= ndev) { fprintf(stderr, "initContext: gpu%d requested but only %d HIP device(s) present\n", st.device + 1, ndev); return nullptr; }
+        const bool first = s == 0, last = s + 1 == plan.size();
+        st.model = bamd_model_load(path.c_str(), st.device, plan[s].second.first, plan[s].second.second, first, last);
+        if (!st.model) { fprintf(stderr, "initContext: error: failed to load model '%s': %s\n", path.c_str(), bamd_last_error()); return nullptr; }
+        pod->stages.push_back(st);
+        Stage & ref = pod->stages.back();
+        ref.ctx = bamd_context_new(ref.model, n_ctx);
+        if (!ref.ctx) { fprintf(stderr, "initContext: error: failed to create context: %s\n", bamd_last_error()); return nullptr; }
+        if (!first) {
+            hipSetDevice(ref.device);
+            if (hipMalloc(&ref.hidden_in, (size_t) pod->n_embd * 4) != hipSuccess) return nullptr;
+            // let the producer's device write the hand-off buffer directly over xGMI (the reference: cudaDeviceEnablePeerAccess, ggml-cuda.cu:1304)
+            const int prev = pod->stages[s - 1].device;
+            if (prev != ref.device) { int can = 0; hipDeviceCanAccessPeer(&can, prev, ref.device); if (can) { hipSetDevice(prev); hipDeviceEnablePeerAccess(ref.device, 0); } }
+        }
+    }
+    pod->logits.assign((size_t) pod->n_vocab, 0.f);
+    Pod * raw = pod.release();
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pods[idx]) pod_free(g_pods[idx]);
+    g_pods[idx] = raw;
+    return raw;
+}
+
+BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID, char * prompt) {
+    (void) sessionID;
+    if (idx < 0 || idx >= 8 || !ctx || !jobID || !prompt) return 1;
+    Pod & p = *(Pod *) ctx;
+    const std::string job = jobID, text = prompt;
+    p.t_p_eval_ms = p.t_eval_ms = 0; p.n_p_eval = p.n_eval = 0;             // llama_reset_timings
+    p.stop.store(false);
+    if (!p.janus_ready) init_janus(p);                                       // the reference rebuilds (and leaks) the tables per request
+    const uint32_t seed = (uint32_t) time(nullptr);
+    p.rng.seed(seed);                                                        // llama_set_rng_seed
+    { std::lock_guard<std::mutex> lk(g_mu); g_jobs[job].seed = seed; }
+    if (p.vocab.type == BAMD_VOCAB_NONE) { fprintf(stderr, "doInference: model has no tokenizer (tokenizer.ggml.model = no_vocab)\n"); return 1; }
+    const std::vector<int> embd_inp = p.vocab.tokenize(text, false, true);
+    if (dbg("tokenizer")) { fprintf(stderr, "TOKENS: ["); for (int t : embd_inp) fprintf(stderr, " %d,", t); fprintf(stderr, " ]\n"); }
+    const int n_ctx = p.n_ctx;
+    { std::lock_guard<std::mutex> lk(g_mu); g_jobs[job].prompt_tokens = (int64_t) embd_inp.size(); }
+    if ((int) embd_inp.size() > n_ctx - 4) { fprintf(stderr, "doInference: error: prompt is too long (%d tokens, max %d)\n", (int) embd_inp.size(), n_ctx - 4); return 0; }
+    std::vector<int> last_tokens((size_t) n_ctx, 0);
+    int n_past = 0, n_consumed = 0, n_remain = p.n_predict;
+    std::vector<int> embd;
+    for (auto & s : p.stages) bamd_kv_cache_clear(s.ctx);
+    const int max_embd_size = n_ctx - 4;
+    while (n_remain && n_past < max_embd_size && !p.stop.load()) {
+        if (!embd.empty()) {
+            if ((int) embd.size() > max_embd_size) embd.resize((size_t) max_embd_size);
+            // (context shift, bridge.cpp:482-507, can never trigger: the loop guard stops at n_ctx-4 positions)
+            for (int i = 0; i < (int) embd.size(); i += p.n_batch) {
+                int n_eval = std::min((int) embd.size() - i, p.n_batch);
+                for (int u = 0; u < n_eval; u += 512) {                      // llama_decode's n_ubatch = 512 micro-batches (llama.cpp:14615)
+                    const int nu = std::min(512, n_eval - u);
+                    if (pod_decode(p, &embd[(size_t) (i + u)], nu, n_past + u)) return 1;
+                }
+                n_past += n_eval;
+            }
+        }
+        embd.clear();
+        if ((int) embd_inp.size() <= n_consumed) {
+            const int id = sample_janus(p, p.logits.data(), last_tokens, embd_inp.size(), (size_t) n_past, (size_t) p.n_predict);
+            last_tokens.erase(last_tokens.begin()); last_tokens.push_back(id);
+            embd.push_back(id);
+            --n_remain;
+        } else {
+            while ((int) embd_inp.size() > n_consumed) {
+                embd.push_back(embd_inp[(size_t) n_consumed]); ++n_consumed;
+                if ((int) embd.size() >= p.n_batch) break;
+            }
+        }
+        {
+            std::string add; for (int id : embd) add += p.vocab.token_to_piece(id);
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_jobs[job].append(add);
+        }
+        if (p.vocab.is_eog(embd.back())) break;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    Job & j = g_jobs[job];
+    j.prompt_eval = p.n_p_eval ? (int64_t) (p.t_p_eval_ms / (double) p.n_p_eval) : 0;
+    j.timing = p.n_eval ? (int64_t) (p.t_eval_ms / (double) p.n_eval) : 0;
+    return p.n_p_eval + p.n_eval;
+}
+
+BAMD_API void stopInference(int idx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx >= 0 && idx < 8 && g_pods[idx]) g_pods[idx]->stop.store(true);
+}
+BAMD_API const char * status(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].cur().c_str(); }
+BAMD_API int64_t promptEval(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_eval; }
+BAMD_API int64_t getPromptTokenCount(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_tokens; }
+BAMD_API int64_t timing(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].timing; }
+BAMD_API uint32_t getSeed(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].seed; }
+
+// ---- test hooks (not part of the cgo surface): tokenizer and Janus as pure functions -------------------------------------------
+BAMD_API int bamd_bridge_tokenize(void * ctx, const char * text, int add_special, int parse_special, int32_t * out, int cap) {
+    Pod & p = *(Pod *) ctx;
+    const std::vector<int> t = p.vocab.tokenize(text, add_special != 0, parse_special != 0);
+    for (int i = 0; i < (int) t.size() && i < cap; ++i) out[i] = t[(size_t) i];
+    return (int) t.size();
+}
+BAMD_API const char * bamd_bridge_token_to_piece(void * ctx, int id, int * len) {
+    Pod & p = *(Pod *) ctx; const std::string & s = p.vocab.token_to_piece(id); if (len) *len = (int) s.size(); return s.c_str();
+}
+
+// ---- vocabulary-only entry points (no GPU needed): llama_tokenize / llama_token_to_piece / llama_token_is_eog of a GGUF ----------
+struct bamd_vocab { GgufFile file; BamdVocab v; };
+BAMD_API bamd_vocab * bamd_vocab_load(const char * gguf_path) {
+    std::unique_ptr<bamd_vocab> h(new bamd_vocab());
+    std::string err;
+    if (!h->file.open(gguf_path, err) || !h->v.load(h->file, err)) { fprintf(stderr, "bamd_vocab_load: %s\n", err.c_str()); return nullptr; }
+    return h.release();
+}
+BAMD_API void bamd_vocab_free(bamd_vocab * h) { delete h; }
+BAMD_API int bamd_vocab_tokenize(const bamd_vocab * h, const char * text, int text_len, int add_special, int parse_special, int32_t * out, int cap) {
+    const std::vector<int> t = h->v.tokenize(std::string(text, (size_t) text_len), add_special != 0, parse_special != 0);
+    for (int i = 0; i < (int) t.size() && i < cap; ++i) out[i] = t[(size_t) i];
+    return (int) t.size();
+}
+BAMD_API int bamd_vocab_piece(const bamd_vocab * h, int id, char * buf, int cap) {
+    const std::string & s = h->v.token_to_piece(id);
+    if ((int) s.size() > cap) return -(int) s.size();
+    memcpy(buf, s.data(), s.size());
+    return (int) s.size();
+}
+BAMD_API int bamd_vocab_n(const bamd_vocab * h) { return h->v.n_vocab(); }
+BAMD_API int bamd_vocab_is_eog(const bamd_vocab * h, int id) { return h->v.is_eog(id) ? 1 : 0; }
+BAMD_API int bamd_vocab_eos(const bamd_vocab * h) { return h->v.eos; }
+BAMD_API int bamd_vocab_eot(const bamd_vocab * h) { return h->v.eot; }

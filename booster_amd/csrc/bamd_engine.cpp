@@ -508,6 +508,19 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_argmax(bamd_con
     return 0;
 }
 
+// host logits of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`
+extern "C" __attribute__((visibility("default"))) const float * bamd_stage_get_logits(bamd_context * c, void * hip_stream) {
+    hipStream_t s = (hipStream_t) hip_stream;
+    bamd_model * m = c->m;
+    if (hipSetDevice(m->device) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    return c->logits_host;
+}
+// raw GGUF access for the tokenizer side of the bridge
+const GgufFile * bamd_model_gguf(const bamd_model * m) { return m->file.get(); }
+extern "C" __attribute__((visibility("default"))) int bamd_model_device(const bamd_model * m) { return m->device; }
+
 // ---- measurement -----------------------------------------------------------------------------------------
 extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
     bamd_model * m = c->m;

@@ -189,7 +189,7 @@ def q4_k_m_type(name, il, n_layer):
 
 
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
-                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False):
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None):
     """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.
     reuse_layers: generate each (tensor kind, type) once and reuse the bytes in every layer (fast path for the
     multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged)."""
@@ -219,7 +219,25 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
     w.add_u32("llama.rope.dimension_count", hd)
     w.add_f32("llama.rope.freq_base", theta)
     w.add_u32("llama.vocab_size", V)
-    w.add_str("tokenizer.ggml.model", "no_vocab")
+    if vocab is None:
+        w.add_str("tokenizer.ggml.model", "no_vocab")
+    else:
+        assert len(vocab["tokens"]) == V
+        w.add_str("tokenizer.ggml.model", vocab["model"])
+        if "pre" in vocab:
+            w.add_str("tokenizer.ggml.pre", vocab["pre"])
+        w.add_arr_str("tokenizer.ggml.tokens", vocab["tokens"])
+        if "scores" in vocab:
+            w.add_arr("tokenizer.ggml.scores", T_F32, [float(x) for x in vocab["scores"]])
+        w.add_arr("tokenizer.ggml.token_type", T_I32, [int(x) for x in vocab["types"]])
+        if "merges" in vocab:
+            w.add_arr_str("tokenizer.ggml.merges", vocab["merges"])
+        for key in ("bos_token_id", "eos_token_id", "unknown_token_id", "eot_token_id"):
+            if key in vocab:
+                w.add_u32("tokenizer.ggml." + key, vocab[key])
+        for key in ("add_bos_token", "add_eos_token", "add_space_prefix"):
+            if key in vocab:
+                w.add_bool("tokenizer.ggml." + key, vocab[key])
 
     def norm():
         return (1.0 + 0.1 * rng.standard_normal(E)).astype(np.float32)
@@ -244,3 +262,61 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
             t = type_fn(nm, il)
             w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
     w.write(path)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# synthetic vocabularies (tests of the tokenizer side of the bridge)
+# ---------------------------------------------------------------------------------------------------------
+def synthetic_spm_vocab(n_extra=200, seed=1):
+    """SentencePiece-style vocab: <unk> <s> </s>, 256 byte tokens, single characters, random multi-character pieces."""
+    import random
+    rnd = random.Random(seed)
+    toks, scores, types = ["<unk>", "<s>", "</s>"], [0.0, 0.0, 0.0], [2, 3, 3]
+    for b in range(256):
+        toks.append("<0x%02X>" % b); scores.append(0.0); types.append(6)
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCDE0123456789.,!?'-") + ["\u2581", "\u00e9", "\u0436", "\u4e2d"]
+    for ch in alphabet:
+        toks.append(ch); scores.append(-10.0 - rnd.random()); types.append(1)
+    seen = set(toks)
+    while len(toks) < 3 + 256 + len(alphabet) + n_extra:
+        n = rnd.choice([2, 2, 3, 3, 4, 5])
+        piece = "".join(rnd.choice(alphabet[:26] + ["\u2581", "\u2581", "e", "t", "a"]) for _ in range(n))
+        if piece in seen:
+            continue
+        seen.add(piece); toks.append(piece); scores.append(-rnd.random() * 8.0 - n * 0.01); types.append(1)
+    toks.append("<|user|>"); scores.append(0.0); types.append(4)
+    return dict(model="llama", tokens=toks, scores=scores, types=types, bos_token_id=1, eos_token_id=2, unknown_token_id=0,
+                add_bos_token=True, add_space_prefix=True)
+
+
+def _bytes_to_unicode():
+    bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
+def synthetic_bpe_vocab(n_merges=300, seed=2, pre="llama-bpe"):
+    """Byte-level BPE vocab (GPT-2 / Llama-3 style): 256 byte symbols, random merges, a few control tokens."""
+    import random
+    rnd = random.Random(seed)
+    b2u = _bytes_to_unicode()
+    toks = [b2u[b] for b in range(256)]
+    merges = []
+    seen = set(toks)
+    common = [b2u[ord(c)] for c in "etaoinshrdlu"] + [b2u[ord(" ")]]
+    while len(merges) < n_merges:
+        a = rnd.choice(toks if rnd.random() < 0.5 else common)
+        b = rnd.choice(toks if rnd.random() < 0.3 else common)
+        if a + b in seen or " " in a or " " in b:
+            continue
+        seen.add(a + b); toks.append(a + b); merges.append(a + " " + b)
+    types = [1] * len(toks)
+    for sp in ("<|begin_of_text|>", "<|end_of_text|>", "<|eot_id|>", "<|start_header_id|>"):
+        toks.append(sp); types.append(3)
+    n = len(toks)
+    return dict(model="gpt2", pre=pre, tokens=toks, types=types, merges=merges, bos_token_id=n - 4, eos_token_id=n - 3,
+                add_bos_token=False)

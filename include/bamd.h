@@ -70,8 +70,24 @@ int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int
                     int want_logits, int prefill_mode, void * hip_stream);
 /* last stage: write the arg-max of the last bamd_stage_step(want_logits=1) into a device int32 (stream-ordered). */
 int bamd_stage_token_to(bamd_context * c, void * token_dev, void * hip_stream);
+/* host logits (n_vocab floats) of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
+const float * bamd_stage_get_logits(bamd_context * c, void * hip_stream);
+int bamd_model_device(const bamd_model * m);
 /* arg-max token of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
 int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token);
+
+/* ---- tokenizer of a GGUF, CPU only: llama_tokenize / llama_token_to_piece / llama_token_is_eog ---- */
+typedef struct bamd_vocab bamd_vocab;
+bamd_vocab * bamd_vocab_load(const char * gguf_path);                   /* llm_load_vocab, llama.cpp:5250 */
+void bamd_vocab_free(bamd_vocab * v);
+/* llama_tokenize (llama-vocab.cpp:1243); returns the token count (may exceed cap) */
+int bamd_vocab_tokenize(const bamd_vocab * v, const char * text, int text_len, int add_special, int parse_special, int32_t * out, int cap);
+/* llama_token_to_piece with special = true (llama-vocab.cpp:1539); returns bytes written, or -needed */
+int bamd_vocab_piece(const bamd_vocab * v, int id, char * buf, int cap);
+int bamd_vocab_n(const bamd_vocab * v);
+int bamd_vocab_is_eog(const bamd_vocab * v, int id);                    /* llama_token_is_eog */
+int bamd_vocab_eos(const bamd_vocab * v);
+int bamd_vocab_eot(const bamd_vocab * v);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.
