@@ -140,11 +140,14 @@ def main():
         tok_s = steps / dt
         # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length
         L_, MS_, B_ = np.zeros(3), np.zeros(3), np.zeros(3)
-        for i in range(4):
+        ev_over = []
+        reps = 4
+        for i in range(reps):
             l, ms, b = ctx.profile_step(n_past - 1)
-            L_ += l; MS_ += ms; B_ += b
+            L_ += l[:3]; MS_ += ms[:3]; B_ += b[:3]; ev_over.append(ms[3])
+        ev_overhead_ms = float(np.median(ev_over))                       # an empty event pair on the same stream
         mv_bytes_per_launch = B_[0] / L_[0]
-        mv_ms_per_launch = MS_[0] / L_[0]
+        mv_ms_per_launch = max(MS_[0] / L_[0] - ev_overhead_ms, 1e-6)
         achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
         n_kv_avg = N_PROMPT + warmup + steps / 2.0
         bytes_per_token = m.weight_bytes + KV_BYTES_PER_POS * n_kv_avg
@@ -154,8 +157,8 @@ def main():
                                  "128-token prompt, n_ctx 512, n_kv %d..%d" % (N_PROMPT + warmup, n_past),
                         parallelism="single GPU", graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
-                        time_split_ms_per_token=dict(matvec=round(MS_[0] / 4, 4), attention=round(MS_[1] / 4, 4), other=round(MS_[2] / 4, 4)),
-                        launches_per_token=int(L_.sum() / 4)),
+                        time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps, 4), other=round(MS_[2] / reps, 4)),
+                        launches_per_token=int(L_[0] / reps + 3 * L_[1] / reps + L_[2] / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                           traffic=None, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),

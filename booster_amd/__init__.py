@@ -126,7 +126,7 @@ class Context:
         return np.ctypeslib.as_array(lib().bamd_get_logits(self.h), shape=(self.model.n_vocab,)).copy()
 
     def profile_step(self, pos):
-        launches = np.zeros(3, np.int32); ms = np.zeros(3, np.float64); nbytes = np.zeros(3, np.float64)
+        launches = np.zeros(4, np.int32); ms = np.zeros(4, np.float64); nbytes = np.zeros(4, np.float64)
         _chk(lib().bamd_profile_step(self.h, pos, _p(launches), _p(ms), _p(nbytes)))
         return launches, ms, nbytes
 

@@ -70,7 +70,8 @@ static void rope_row(float * cache, int32_t pos, int n_dims, float freq_base, fl
 struct DevMat {                      // one quantised matrix resident in HBM
     void * stream = nullptr;         // wave-stream records (matmul operand)
     void * raw = nullptr;            // GGUF layout (kept only for token_embd: row gather)
-    int type = 0, nrows = 0, K = 0;
+    int type = 0, nrows = 0, K = 0;  // nrows = rows in the GGUF
+    int nrows_pad = 0;               // rows of the stream (next multiple of 8; missing rows are zero records)
     size_t bytes = 0;
 };
 struct DevLayer {
@@ -130,14 +131,17 @@ static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool kee
     d.type = t->type; d.K = (int) t->ne[0]; d.nrows = (int) t->ne[1]; d.bytes = t->nbytes;
     if (want_stream) {
         if (!bamd_is_kquant(d.type)) return fail("tensor " + t->name + ": only Q4_K/Q5_K/Q6_K matrices are supported on the matmul path");
-        if (d.K % 256 || d.nrows % 8) return fail("tensor " + t->name + ": shape not a multiple of (256, 8)");
+        if (d.K % 256) return fail("tensor " + t->name + ": row length not a multiple of 256");
     }
+    d.nrows_pad = (d.nrows + 7) / 8 * 8;
+    if (d.nrows_pad != d.nrows && stream_dst) return fail("tensor " + t->name + ": fused QKV needs row counts that are multiples of 8");
     void * rawdev = staging;
     if (keep_raw) { if (dev_alloc(m->allocs, &d.raw, t->nbytes)) return 1; rawdev = d.raw; }
     HIPC(hipMemcpyAsync(rawdev, t->data, t->nbytes, hipMemcpyHostToDevice, s));
     if (want_stream) {
+        const size_t stream_bytes = bamd_row_bytes(d.type, d.K) * (size_t) d.nrows_pad;
         if (stream_dst) d.stream = stream_dst;
-        else if (dev_alloc(m->allocs, &d.stream, t->nbytes)) return 1;
+        else { if (dev_alloc(m->allocs, &d.stream, stream_bytes)) return 1; if (d.nrows_pad != d.nrows) HIPC(hipMemsetAsync(d.stream, 0, stream_bytes, s)); }
         bamd_launch_repack(rawdev, d.stream, d.type, d.nrows, d.K, s);
         m->weight_bytes += (int64_t) t->nbytes;
     }
@@ -333,7 +337,7 @@ struct StepTimer {                 // optional per-launch HIP-event timing (bamd
     void end(hipStream_t s) { if (!on) return; hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, s); ev.push_back(b); }
 };
 
-static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.stream; sg.out = out; sg.type = d.type; sg.nrows = d.nrows; }
+static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.stream; sg.out = out; sg.type = d.type; sg.nrows = d.nrows_pad; sg.nvalid = d.nrows; }
 
 // enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm) {
@@ -345,9 +349,9 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         bamd_mv_args a; memset(&a, 0, sizeof a);
         // 1. q,k,v = W{q,k,v} . Q8_K(rms_norm(x) * attn_norm)          (llama.cpp:8810-8835)
         seg_of(a.seg[0], ly.wq, c->q); a.nseg = 1;
-        if (ly.wk.type == ly.wq.type) a.seg[0].nrows += ly.wk.nrows;    // streams and outputs are contiguous: extend
+        if (ly.wk.type == ly.wq.type) { a.seg[0].nrows += ly.wk.nrows; a.seg[0].nvalid += ly.wk.nrows; }   // streams and outputs are contiguous: extend
         else { seg_of(a.seg[a.nseg], ly.wk, c->k); a.nseg++; }
-        if (ly.wv.type == ly.wk.type) a.seg[a.nseg - 1].nrows += ly.wv.nrows;
+        if (ly.wv.type == ly.wk.type) { a.seg[a.nseg - 1].nrows += ly.wv.nrows; a.seg[a.nseg - 1].nvalid += ly.wv.nrows; }
         else { seg_of(a.seg[a.nseg], ly.wv, c->v); a.nseg++; }
         a.x = c->x; a.normw = ly.attn_norm; a.eps = m->eps; a.K = m->E;
         if (tm) tm->begin(s, 0, (double) (ly.wq.bytes + ly.wk.bytes + ly.wv.bytes));
@@ -535,7 +539,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
     if (enqueue_layers(c, 0, s, &tm)) return 1;
     enqueue_lm_head(c, s, &tm);
     HIPC(hipStreamSynchronize(s));
-    for (int i = 0; i < 3; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
+    for (int i = 0; i < 4; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
     const int n_kv = std::min(c->n_ctx, (pos + 1 + 31) / 32 * 32);
     for (size_t i = 0; i < tm.cls.size(); ++i) {
         float t = 0.f; hipEventElapsedTime(&t, tm.ev[2 * i], tm.ev[2 * i + 1]);
@@ -544,6 +548,18 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
         bytes[k] += k == 1 ? (double) n_kv * m->Hkv * m->hd * 2 * 2 : tm.bytes[i];
     }
     for (auto e : tm.ev) hipEventDestroy(e);
+    // entry 3: what an empty event pair reads on this stream (median of 9) — subtract it per launch
+    {
+        std::vector<float> ov;
+        for (int i = 0; i < 9; ++i) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, s); hipEventRecord(b, s); hipStreamSynchronize(s);
+            float t = 0.f; hipEventElapsedTime(&t, a, b); ov.push_back(t);
+            hipEventDestroy(a); hipEventDestroy(b);
+        }
+        std::sort(ov.begin(), ov.end());
+        launches[3] = 9; ms[3] = ov[4]; bytes[3] = 0;
+    }
     return 0;
 }
 
@@ -578,10 +594,13 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_quantize_q8_K(cons
 static int op_matvec(int type, const void * wA, const void * wB, int nrows, int k, const float * x, const float * norm_w, float eps,
                      const float * residual, float * y, int epi, int mode) {
     if (need_device()) return 1;
-    if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0 || nrows % 8) return fail("bad type/shape");
-    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
-    void * rawA = t.up(wA, wb), * strA = t.up(nullptr, wb), * rawB = nullptr, * strB = nullptr;
-    if (wB) { rawB = t.up(wB, wb); strB = t.up(nullptr, wb); }
+    if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0) return fail("bad type/shape");
+    const int nrows_pad = (nrows + 7) / 8 * 8;
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_row_bytes(type, k) * (size_t) nrows_pad;
+    void * rawA = t.up(wA, wb), * strA = t.up(nullptr, wbp), * rawB = nullptr, * strB = nullptr;
+    if (wB) { rawB = t.up(wB, wb); strB = t.up(nullptr, wbp); }
+    if (strA) HIPC(hipMemset(strA, 0, wbp));
+    if (strB) HIPC(hipMemset(strB, 0, wbp));
     float * dx = (float *) t.up(x, (size_t) k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr;
     float * dres = residual ? (float *) t.up(residual, (size_t) nrows * 4) : nullptr; float * dy = (float *) t.up(nullptr, (size_t) nrows * 4);
     unsigned long long * key = (unsigned long long *) t.up(nullptr, 8);
@@ -590,7 +609,7 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
     bamd_launch_repack(rawA, strA, type, nrows, k, nullptr);
     if (wB) bamd_launch_repack(rawB, strB, type, nrows, k, nullptr);
     bamd_mv_args a; memset(&a, 0, sizeof a);
-    a.seg[0].w = strA; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows; a.nseg = 1;
+    a.seg[0].w = strA; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows_pad; a.seg[0].nvalid = nrows; a.nseg = 1;
     if (wB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
     a.x = dx; a.normw = dw; a.eps = eps; a.K = k; a.res = dres; a.best_key = key; a.mode = mode;
     bamd_launch_matvec(a, norm_w ? BAMD_PRO_NORM : BAMD_PRO_PLAIN, epi, n_cu0(), nullptr);

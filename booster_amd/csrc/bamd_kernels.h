@@ -17,7 +17,7 @@ struct bamd_step_state {
     unsigned long long best_key;   // arg-max key of the last lm_head (0 = none)
 };
 
-struct bamd_mv_seg { const void * w; float * out; int type; int nrows; };
+struct bamd_mv_seg { const void * w; float * out; int type; int nrows; int nvalid; };   // nrows: multiple of 8 (stream rows, zero-padded); nvalid: real rows (0 = nrows)
 struct bamd_mv_args {
     bamd_mv_seg seg[3]; int nseg;
     const float * x;               // f32 activation [K]

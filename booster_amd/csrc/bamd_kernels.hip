@@ -450,7 +450,7 @@ template <int TYPE, typename REC, int D, int EPI, int PRO>
 __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb,
                                                int first, int count, int stride, float * __restrict__ out,
                                                const float * __restrict__ res, const ProArgs & pa, bool do_pro,
-                                               unsigned long long & best) {
+                                               unsigned long long & best, int nvalid) {
     constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
     constexpr int NPARTS = PAIR ? 2 : 1;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
         for (int part = 0; part < NPARTS; ++part) {
             // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
             float resv = 0.f;
-            if (EPI == BAMD_EPI_ADD) resv = res[row];
+            if (EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
             RowAcc A = { 0.f, 0.f };
             for (int c = 0; c < chunks; ++c) {
 #pragma unroll
@@ -502,8 +502,8 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             const float val = finish_row<TYPE>(A);
             if (PAIR) {
                 if (part == 0) gate_val = val;
-                else if ((lane & 7) == 0) out[row] = v_silu(gate_val) * val;
-            } else if ((lane & 7) == 0) {
+                else if ((lane & 7) == 0 && row < nvalid) out[row] = v_silu(gate_val) * val;
+            } else if ((lane & 7) == 0 && row < nvalid) {
                 float o = val;
                 if (EPI == BAMD_EPI_ADD) o = val + resv;
                 out[row] = o;
@@ -517,11 +517,11 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
 template <int TYPE, typename REC, int EPI, int PRO>
 __device__ __forceinline__ void stream_dispatch_depth(const uint8_t * wA, const uint8_t * wB, int nb, int first, int count, int stride,
                                                       float * out, const float * res, const ProArgs & pa, bool do_pro,
-                                                      unsigned long long & best) {
-    if ((nb & 7) == 0)      stream_segment<TYPE, REC, 8, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
-    else if ((nb & 3) == 0) stream_segment<TYPE, REC, 4, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
-    else if ((nb & 1) == 0) stream_segment<TYPE, REC, 2, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
-    else                    stream_segment<TYPE, REC, 1, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best);
+                                                      unsigned long long & best, int nvalid) {
+    if ((nb & 7) == 0)      stream_segment<TYPE, REC, 8, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best, nvalid);
+    else if ((nb & 3) == 0) stream_segment<TYPE, REC, 4, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best, nvalid);
+    else if ((nb & 1) == 0) stream_segment<TYPE, REC, 2, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best, nvalid);
+    else                    stream_segment<TYPE, REC, 1, EPI, PRO>(wA, wB, nb, first, count, stride, out, res, pa, do_pro, best, nvalid);
 }
 
 __device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned char * smem) {
@@ -558,9 +558,10 @@ __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
             const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
             float * out = a.seg[s].out;
             const float * res = a.res;
-            if (t == BAMD_Q4_K)      stream_dispatch_depth<BAMD_Q4_K, RecQ4K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
-            else if (t == BAMD_Q5_K) stream_dispatch_depth<BAMD_Q5_K, RecQ5K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
-            else                     stream_dispatch_depth<BAMD_Q6_K, RecQ6K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best);
+            const int nv = a.seg[s].nvalid > 0 ? a.seg[s].nvalid : a.seg[s].nrows;
+            if (t == BAMD_Q4_K)      stream_dispatch_depth<BAMD_Q4_K, RecQ4K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best, nv);
+            else if (t == BAMD_Q5_K) stream_dispatch_depth<BAMD_Q5_K, RecQ5K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best, nv);
+            else                     stream_dispatch_depth<BAMD_Q6_K, RecQ6K, EPI, PRO>(wA, wB, nb, g0 - off, count, stride, out, res, pa, !pro_done, best, nv);
             pro_done = true;
         }
         off += nrg;
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
 template <int TYPE, typename REC, int NBW, int M, int EPI, int PRO>
 __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa, bool do_pro,
-                                             float * part0, int & batchctr) {
+                                             float * part0, int & batchctr, int nvalid) {
     constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
     constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -624,15 +625,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     STAMP(2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     for (int r0 = 0; r0 < count; r0 += M) {
-        const int nvalid = count - r0 < M ? count - r0 : M;  // workgroup-uniform
+        const int nbatch = count - r0 < M ? count - r0 : M;  // workgroup-uniform
         float * B0 = part0 + (size_t) (batchctr & 1) * M * rg_floats;
         // the wave that will run the chain of row-group r0+wave fetches its residual now (old by chain time)
-        const int crow = (first + (r0 + (wave < nvalid ? wave : 0)) * stride) * 8 + r8;
+        const int crow = (first + (r0 + (wave < nbatch ? wave : 0)) * stride) * 8 + r8;
         float resv = 0.f;
-        if (EPI == BAMD_EPI_ADD) resv = res[crow];
+        if (EPI == BAMD_EPI_ADD && crow < nvalid) resv = res[crow];
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            if (m < nvalid) {
+            if (m < nbatch) {
                 float * P = B0 + (size_t) m * rg_floats;
                 float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
 #pragma unroll
@@ -653,7 +654,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         STAMP(3);
         __syncthreads();
         STAMP(4);
-        if (wave < nvalid) {
+        if (wave < nbatch) {
             // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
             const float * P = B0 + (size_t) wave * rg_floats;
             const float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
@@ -670,7 +671,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                 for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dv[u], fv[u], mv[u], pv[u]);
             }
             const float val = finish_row<TYPE>(A);
-            if ((lane & 7) == 0) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
+            if ((lane & 7) == 0 && crow < nvalid) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
             STAMP(5);
         }
         batchctr += 1;
@@ -680,12 +681,12 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
 
 template <int TYPE, typename REC, int EPI, int PRO>
 __device__ __forceinline__ void split_dispatch(const uint8_t * w, int nb, int first, int count, int stride, float * out, const float * res,
-                                               const ProArgs & pa, bool do_pro, float * part0, int & rgctr) {
+                                               const ProArgs & pa, bool do_pro, float * part0, int & rgctr, int nvalid) {
     const int nbw = nb >> 3;
-    if (nbw == 2)       split_stream<TYPE, REC, 2, 4, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
-    else if (nbw == 7)  split_stream<TYPE, REC, 7, 1, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
-    else if (nbw == 4)  split_stream<TYPE, REC, 4, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
-    else if (nbw == 1)  split_stream<TYPE, REC, 1, 8, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr);
+    if (nbw == 2)       split_stream<TYPE, REC, 2, 4, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 7)  split_stream<TYPE, REC, 7, 1, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 4)  split_stream<TYPE, REC, 4, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 1)  split_stream<TYPE, REC, 1, 8, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
     else __builtin_trap();                               // the launcher only picks this kernel for the shapes above
 }
 
@@ -708,9 +709,10 @@ __global__ void __launch_bounds__(512) matvec_split_kernel(bamd_mv_args a) {
         if (count > 0) {
             const int t = a.seg[s].type;
             const uint8_t * w = (const uint8_t *) a.seg[s].w;
-            if (t == BAMD_Q4_K)      split_dispatch<BAMD_Q4_K, RecQ4K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
-            else if (t == BAMD_Q5_K) split_dispatch<BAMD_Q5_K, RecQ5K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
-            else                     split_dispatch<BAMD_Q6_K, RecQ6K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr);
+            const int nv = a.seg[s].nvalid > 0 ? a.seg[s].nvalid : a.seg[s].nrows;
+            if (t == BAMD_Q4_K)      split_dispatch<BAMD_Q4_K, RecQ4K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr, nv);
+            else if (t == BAMD_Q5_K) split_dispatch<BAMD_Q5_K, RecQ5K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr, nv);
+            else                     split_dispatch<BAMD_Q6_K, RecQ6K, EPI, PRO>(w, nb, g0 - off, count, stride, a.seg[s].out, a.res, pa, !pro_done, part0, rgctr, nv);
             pro_done = true;
         }
         off += nrg;

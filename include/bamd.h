@@ -93,7 +93,8 @@ int bamd_vocab_eot(const bamd_vocab * v);
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.
  * classes: 0 matvec (all weight streaming), 1 attention (qk+softmax+pv), 2 step-begin/other.
  * For each class: launches[], ms[] (sum of durations), bytes[] (algorithmic bytes: weight records streamed /
- * KV bytes read).  Arrays must hold 3 entries. */
+ * KV bytes read).  Entry 3: ms[3] = what an EMPTY event pair reads on that stream (to subtract per launch).
+ * Arrays must hold 4 entries. */
 int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes);
 
 /* Micro-benchmark: `iters` back-to-back launches of one mat-vec shape on random resident weights (pro: 0 plain,

@@ -38,3 +38,11 @@ def test_no_cpu_fallback(L):
         booster_amd.op_quantize_q8_K(x)
     with pytest.raises(booster_amd.BamdError):
         booster_amd.Model(os.path.join(ROOT, "tests", "golden", "tiny_a.gguf"))
+
+
+def test_bridge_symbols_exported(L):
+    """the nine cgo symbols of cpp/bridge.h:132-165"""
+    syms = declared_symbols("booster_bridge.h")
+    assert sorted(syms) == sorted(["init", "initContext", "doInference", "stopInference", "status", "promptEval", "getPromptTokenCount", "timing", "getSeed"])
+    for s in syms:
+        assert hasattr(L, s), "missing export: " + s

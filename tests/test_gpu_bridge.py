@@ -1,0 +1,91 @@
+"""GPU: the nine cgo symbols (include/booster_bridge.h) driven the way pkg/server/server.go drives them:
+initContext -> init -> doInference on one thread while status/getPromptTokenCount are polled, then the counters."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from booster_amd import gguf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(bamd):
+    L = bamd.lib()
+    f, i, u = C.c_float, C.c_int, C.c_uint32
+    L.init.argtypes = [C.c_char_p, C.c_char_p]; L.init.restype = None
+    L.initContext.restype = C.c_void_p
+    L.initContext.argtypes = [i, C.c_char_p, i, i, i, i, i, i, i, i, C.c_int32, f, f, f, i, f, f, f, i, C.c_int32, C.c_int32, f, f, f, u, C.c_char_p]
+    L.doInference.restype = C.c_int64; L.doInference.argtypes = [i, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.stopInference.argtypes = [i]; L.stopInference.restype = None
+    L.status.restype = C.c_char_p; L.status.argtypes = [C.c_char_p]
+    for n in ("promptEval", "getPromptTokenCount", "timing"):
+        getattr(L, n).restype = C.c_int64; getattr(L, n).argtypes = [C.c_char_p]
+    L.getSeed.restype = C.c_uint32; L.getSeed.argtypes = [C.c_char_p]
+    L.bamd_bridge_tokenize.argtypes = [C.c_void_p, C.c_char_p, i, i, C.c_void_p, i]
+    return L
+
+
+def make_model(tmp_path, name):
+    vocab = gguf.synthetic_spm_vocab()
+    p = str(tmp_path / name)
+    gguf.write_synthetic_llama(p, E=512, H=4, Hkv=1, L=3, F=768, V=len(vocab["tokens"]), seed=21, vocab=vocab)
+    return p, vocab
+
+
+def ctx_args(idx, path, gpus, n_ctx, predict, hi=1.0, lo=1.0):
+    return (idx, path.encode(), 4, 512, gpus[0], gpus[1], gpus[2], gpus[3], n_ctx, predict, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64,
+            1, 200, 0.97, hi, lo, 42, b"")
+
+
+def test_scripted_session(lib, bamd, tmp_path):
+    path, vocab = make_model(tmp_path, "bridge.gguf")
+    ctx = lib.initContext(*ctx_args(0, path, (100, 0, 0, 0), 128, 24))
+    assert ctx, "initContext failed"
+    lib.init(b"", b"")                                   # config mode calls init AFTER initContext (server.go:532-553)
+    prompt = b"the cat sat on the hat"
+    ids = np.zeros(256, np.int32)
+    n_prompt = lib.bamd_bridge_tokenize(ctx, prompt, 0, 1, ids.ctypes.data_as(C.c_void_p), 256)
+    seen = []
+    done = threading.Event()
+
+    def poll():
+        while not done.is_set():
+            seen.append(lib.status(b"job-1"))
+            lib.getPromptTokenCount(b"job-1")
+            time.sleep(0.001)
+    t = threading.Thread(target=poll); t.start()
+    n = lib.doInference(0, ctx, b"job-1", b"sess", prompt)
+    done.set(); t.join()
+    assert lib.getPromptTokenCount(b"job-1") == n_prompt
+    text = lib.status(b"job-1")
+    assert text.startswith(b" the cat sat on the hat") or text.startswith(prompt)    # SPM pieces re-insert the leading space
+    # n_p_eval + n_eval: the prompt batch, then one eval per generated token except the last one (never fed back)
+    assert n_prompt + 1 <= n <= n_prompt + 24
+    assert lib.promptEval(b"job-1") >= 0 and lib.timing(b"job-1") >= 0
+    assert lib.getSeed(b"job-1") > 1_600_000_000
+    assert all(text.startswith(s) for s in seen if s)    # every polled snapshot is a prefix of the final text
+    # same prompt again: Janus with hi = lo = 1.0 collapses to the arg-max -> deterministic text
+    n2 = lib.doInference(0, ctx, b"job-2", b"sess", prompt)
+    assert n2 == n and lib.status(b"job-2") == text
+    # prompt longer than n_ctx - 4 -> 0
+    assert lib.doInference(0, ctx, b"job-3", b"", b"a " * 400) == 0
+
+
+def test_layer_split_on_one_device_and_stop(lib, bamd, tmp_path):
+    """gpus: [2, 2] on a 1-GPU box must fail cleanly; virtual split (all weight on gpu1) equals the plain pod;
+    stopInference ends a long generation."""
+    path, vocab = make_model(tmp_path, "bridge2.gguf")
+    if bamd.device_count() < 2:
+        assert not lib.initContext(*ctx_args(1, path, (2, 2, 0, 0), 64, 8))
+    assert not lib.initContext(*ctx_args(1, path, (0, 0, 0, 0), 64, 8))      # no CPU path
+    assert not lib.initContext(*ctx_args(1, path, (2, 0, 0, 0), 64, 8))      # sum <= n_layer: partial offload unsupported
+    ctx = lib.initContext(*ctx_args(1, path, (10, 0, 0, 0), 2048, 1500))
+    assert ctx
+    res = {}
+    th = threading.Thread(target=lambda: res.setdefault("n", lib.doInference(1, ctx, b"job-long", b"", b"hello there")))
+    th.start(); time.sleep(0.15); lib.stopInference(1); th.join(timeout=60)
+    assert not th.is_alive() and 0 < res["n"] < 1500

@@ -48,7 +48,7 @@ def test_rmsnorm_quantize(bamd, po, K):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (2048, 4104), (4096, 512), (8192, 24), (14336, 64), (14336, 2064)])
+@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (768, 13), (2048, 4104), (4096, 512), (4096, 510), (8192, 24), (14336, 64), (14336, 2064)])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_mul_mat_vec(bamd, po, t, K, rows, mode):
     """mode 1: one wave per row-group; mode 2: split-K over the 8 waves of a workgroup (where the shape allows;
@@ -56,7 +56,7 @@ def test_mul_mat_vec(bamd, po, t, K, rows, mode):
     rng = np.random.default_rng(1000 * t + K)
     W = random_kquant_tensor(t, K, rows, rng)
     x = (rng.standard_normal(K) * 3).astype(np.float32)
-    res = rng.standard_normal(rows).astype(np.float32) if rows % 16 == 8 else None
+    res = rng.standard_normal(rows).astype(np.float32) if rows % 16 in (8, 13, 14) else None
     got = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=mode)
     want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0]
     if res is not None:
