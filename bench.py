@@ -149,6 +149,12 @@ def main():
         mv_bytes_per_launch = B_[0] / L_[0]
         mv_ms_per_launch = max(MS_[0] / L_[0] - ev_overhead_ms, 1e-6)
         achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
+        traffic = None                                                   # HBM bytes per launch from the committed PMC pass, if any
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_summary.json")))
+            traffic = int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
+        except Exception:
+            pass
         n_kv_avg = N_PROMPT + warmup + steps / 2.0
         bytes_per_token = m.weight_bytes + KV_BYTES_PER_POS * n_kv_avg
         result = dict(
@@ -160,7 +166,7 @@ def main():
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps, 4), other=round(MS_[2] / reps, 4)),
                         launches_per_token=int(L_[0] / reps + 3 * L_[1] / reps + L_[2] / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                          traffic=None, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
+                          traffic=traffic, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
         )
         if not args.no_cpu_baseline:
