@@ -46,7 +46,18 @@ __device__ unsigned long long g_stamps[64 * 16];
 
 __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short) bits16)); }
 __device__ __forceinline__ unsigned short f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
-__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false); }
+// v_dot4_i32_i8 with an inline-constant 0 accumulator (the builtin lowers to v_dot4c + a v_mov 0 per call)
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) {
+#ifdef BAMD_ASM_DOT4
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false);
+#endif
+}
+// scale (<= 8 bits) x block dot (<= 15 bits): full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
 
 // ggml-quants.c:1632-1637
@@ -272,20 +283,35 @@ __device__ __forceinline__ void pin_rec(RecQ4K & R) { pin(R.qs); pin(R.hd); }
 __device__ __forceinline__ void pin_rec(RecQ5K & R) { pin(R.qs); pin(R.hd); pin(R.qh); }
 __device__ __forceinline__ void pin_rec(RecQ6K & R) { pin(R.ql); pin(R.qh); pin(R.sc); pin(R.d); }
 
+// `rec` is wave-uniform (SGPR pair); the per-lane part is a 32-bit offset, so the loads take the saddr form and need no
+// 64-bit VALU address arithmetic.  Weights are read exactly once per token: non-temporal loads keep them out of the way
+// of the L2-resident activations (MI355X_MICROARCH.md, row nt-weights).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T ldnt(const uint8_t * rec, uint32_t off) { return __builtin_nontemporal_load((const T *) (rec + off)); }
+template <> __device__ __forceinline__ uint4 ldnt<uint4>(const uint8_t * rec, uint32_t off) {
+    const u32x4_t v = __builtin_nontemporal_load((const u32x4_t *) (rec + off)); return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ uint2 ldnt<uint2>(const uint8_t * rec, uint32_t off) {
+    const u32x2_t v = __builtin_nontemporal_load((const u32x2_t *) (rec + off)); return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ void load_rec(RecQ4K & R, const uint8_t * rec, int lane) {
-    R.qs = *(const uint4 *) (rec + lane * 16);
-    R.hd = *(const uint4 *) (rec + 1024 + (lane >> 3) * 16);
+    const uint32_t l = (uint32_t) lane;
+    R.qs = ldnt<uint4>(rec, l * 16u);
+    R.hd = ldnt<uint4>(rec, 1024u + (l >> 3) * 16u);
 }
 __device__ __forceinline__ void load_rec(RecQ5K & R, const uint8_t * rec, int lane) {
-    R.qs = *(const uint4 *) (rec + lane * 16);
-    R.qh = *(const uint32_t *) (rec + 1024 + lane * 4);
-    R.hd = *(const uint4 *) (rec + 1280 + (lane >> 3) * 16);
+    const uint32_t l = (uint32_t) lane;
+    R.qs = ldnt<uint4>(rec, l * 16u);
+    R.qh = ldnt<uint32_t>(rec, 1024u + l * 4u);
+    R.hd = ldnt<uint4>(rec, 1280u + (l >> 3) * 16u);
 }
 __device__ __forceinline__ void load_rec(RecQ6K & R, const uint8_t * rec, int lane) {
-    R.ql = *(const uint4 *) (rec + lane * 16);
-    R.qh = *(const uint2 *) (rec + 1024 + lane * 8);
-    R.sc = *(const uint2 *) (rec + 1536 + (lane >> 3) * 16 + ((lane >> 2) & 1) * 8);
-    R.d  = *(const unsigned short *) (rec + 1664 + (lane >> 3) * 2);
+    const uint32_t l = (uint32_t) lane;
+    R.ql = ldnt<uint4>(rec, l * 16u);
+    R.qh = ldnt<uint2>(rec, 1024u + l * 8u);
+    R.sc = ldnt<uint2>(rec, 1536u + (l >> 3) * 16u + ((l >> 2) & 1u) * 8u);
+    R.d  = ldnt<unsigned short>(rec, 1664u + (l >> 3) * 2u);
 }
 
 // 6-bit scale/min unpack, ggml-quants.c:6928-6933
@@ -311,10 +337,10 @@ __device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane,
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     int sumi = 0;
-    sumi += BYTE(sc03, 0) * sdot4(R.qs.x & 0x0f0f0f0fu, a0.x) + BYTE(sc03, 1) * sdot4((R.qs.x >> 4) & 0x0f0f0f0fu, a0.y);
-    sumi += BYTE(sc03, 2) * sdot4(R.qs.y & 0x0f0f0f0fu, a0.z) + BYTE(sc03, 3) * sdot4((R.qs.y >> 4) & 0x0f0f0f0fu, a0.w);
-    sumi += BYTE(sc47, 0) * sdot4(R.qs.z & 0x0f0f0f0fu, a1.x) + BYTE(sc47, 1) * sdot4((R.qs.z >> 4) & 0x0f0f0f0fu, a1.y);
-    sumi += BYTE(sc47, 2) * sdot4(R.qs.w & 0x0f0f0f0fu, a1.z) + BYTE(sc47, 3) * sdot4((R.qs.w >> 4) & 0x0f0f0f0fu, a1.w);
+    sumi += mul24(BYTE(sc03, 0), sdot4(R.qs.x & 0x0f0f0f0fu, a0.x)) + mul24(BYTE(sc03, 1), sdot4((R.qs.x >> 4) & 0x0f0f0f0fu, a0.y));
+    sumi += mul24(BYTE(sc03, 2), sdot4(R.qs.y & 0x0f0f0f0fu, a0.z)) + mul24(BYTE(sc03, 3), sdot4((R.qs.y >> 4) & 0x0f0f0f0fu, a0.w));
+    sumi += mul24(BYTE(sc47, 0), sdot4(R.qs.z & 0x0f0f0f0fu, a1.x)) + mul24(BYTE(sc47, 1), sdot4((R.qs.z >> 4) & 0x0f0f0f0fu, a1.y));
+    sumi += mul24(BYTE(sc47, 2), sdot4(R.qs.w & 0x0f0f0f0fu, a1.z)) + mul24(BYTE(sc47, 3), sdot4((R.qs.w >> 4) & 0x0f0f0f0fu, a1.w));
     T.fs = (float) sumi;
     const uint32_t mw = (l < 2) ? mn03 : mn47;
     const int sh = (l & 1) * 16;
@@ -335,10 +361,10 @@ __device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane,
     const uint32_t qh = R.qh;
 #define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))
     int sumi = 0;
-    sumi += BYTE(sc03, 0) * sdot4(Q5(R.qs.x, 0, 0), a0.x) + BYTE(sc03, 1) * sdot4(Q5(R.qs.x, 4, 1), a0.y);
-    sumi += BYTE(sc03, 2) * sdot4(Q5(R.qs.y, 0, 2), a0.z) + BYTE(sc03, 3) * sdot4(Q5(R.qs.y, 4, 3), a0.w);
-    sumi += BYTE(sc47, 0) * sdot4(Q5(R.qs.z, 0, 4), a1.x) + BYTE(sc47, 1) * sdot4(Q5(R.qs.z, 4, 5), a1.y);
-    sumi += BYTE(sc47, 2) * sdot4(Q5(R.qs.w, 0, 6), a1.z) + BYTE(sc47, 3) * sdot4(Q5(R.qs.w, 4, 7), a1.w);
+    sumi += mul24(BYTE(sc03, 0), sdot4(Q5(R.qs.x, 0, 0), a0.x)) + mul24(BYTE(sc03, 1), sdot4(Q5(R.qs.x, 4, 1), a0.y));
+    sumi += mul24(BYTE(sc03, 2), sdot4(Q5(R.qs.y, 0, 2), a0.z)) + mul24(BYTE(sc03, 3), sdot4(Q5(R.qs.y, 4, 3), a0.w));
+    sumi += mul24(BYTE(sc47, 0), sdot4(Q5(R.qs.z, 0, 4), a1.x)) + mul24(BYTE(sc47, 1), sdot4(Q5(R.qs.z, 4, 5), a1.y));
+    sumi += mul24(BYTE(sc47, 2), sdot4(Q5(R.qs.w, 0, 6), a1.z)) + mul24(BYTE(sc47, 3), sdot4(Q5(R.qs.w, 4, 7), a1.w));
 #undef Q5
     T.fs = (float) sumi;
     // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
@@ -362,17 +388,17 @@ __device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane,
     int sumi = 0;
     {
         const uint32_t A_ = R.ql.x, B_ = R.ql.y, h = R.qh.x, s = R.sc.x;
-        sumi += SB(s, 0) * sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a0.x);
-        sumi += SB(s, 1) * sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a0.y);
-        sumi += SB(s, 2) * sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a0.z);
-        sumi += SB(s, 3) * sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a0.w);
+        sumi += mul24(SB(s, 0), sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a0.x));
+        sumi += mul24(SB(s, 1), sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a0.y));
+        sumi += mul24(SB(s, 2), sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a0.z));
+        sumi += mul24(SB(s, 3), sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a0.w));
     }
     {
         const uint32_t A_ = R.ql.z, B_ = R.ql.w, h = R.qh.y, s = R.sc.y;
-        sumi += SB(s, 0) * sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a1.x);
-        sumi += SB(s, 1) * sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a1.y);
-        sumi += SB(s, 2) * sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a1.z);
-        sumi += SB(s, 3) * sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a1.w);
+        sumi += mul24(SB(s, 0), sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a1.x));
+        sumi += mul24(SB(s, 1), sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a1.y));
+        sumi += mul24(SB(s, 2), sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a1.z));
+        sumi += mul24(SB(s, 3), sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a1.w));
     }
 #undef Q6
 #undef SB
