@@ -21,7 +21,7 @@
 #include <vector>
 
 static thread_local std::string g_err;
-static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return e && e[0] == '1'; }();
+static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
@@ -100,7 +100,8 @@ struct bamd_context {
     int n_ctx = 0;
     std::vector<unsigned short *> kc, vc;
     float * rope = nullptr;
-    float * x = nullptr, * x2 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr, * scores = nullptr;
+    float * x = nullptr, * x2 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr, * scores = nullptr, * probs = nullptr;
+    int n_ctx_pad = 0;              // KV row stride: n_ctx rounded up to 64 (V^T rows are stored in 64-position blocks)
     float * logits = nullptr;        // device
     float * logits_host = nullptr;   // pinned
     bamd_step_state * st = nullptr;
@@ -189,7 +190,7 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     if (m->H % m->Hkv) return fail("n_head % n_head_kv != 0");
     const int gq = m->H / m->Hkv;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return fail("GQA ratio must be 1, 2, 4 or 8");
-    if (m->hd % 32 || m->hd > 256) return fail("head dim must be a multiple of 32 and <= 256");
+    if (m->hd % 64 || m->hd > 256) return fail("head dim must be 64, 128, 192 or 256");
     if (m->E % 256 || m->F % 256) return fail("n_embd and n_ff must be multiples of 256");
     if (ll < 0 || ll > m->L) ll = m->L;
     if (lf < 0 || lf > ll) return fail("bad layer range");
@@ -283,7 +284,8 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
     HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int nl = (int) m->layers.size(), Ekv = m->Hkv * m->hd;
     c->kc.resize((size_t) nl); c->vc.resize((size_t) nl);
-    const size_t kvb = (size_t) n_ctx * Ekv * 2;
+    c->n_ctx_pad = (n_ctx + 63) / 64 * 64;
+    const size_t kvb = (size_t) c->n_ctx_pad * Ekv * 2;
     for (int i = 0; i < nl; ++i) {                                   // llama_kv_cache_init :2926-3026 — zero-initialised
         if (dev_alloc(c->allocs, (void **) &c->kc[(size_t) i], kvb) || dev_alloc(c->allocs, (void **) &c->vc[(size_t) i], kvb)) return 1;
         HIPC(hipMemsetAsync(c->kc[(size_t) i], 0, kvb, c->stream)); HIPC(hipMemsetAsync(c->vc[(size_t) i], 0, kvb, c->stream));
@@ -298,7 +300,7 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
     }
     if (dev_alloc(c->allocs, (void **) &c->x, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->x2, (size_t) m->E * 4) ||
         dev_alloc(c->allocs, (void **) &c->q, (size_t) (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->att, (size_t) m->E * 4) ||
-        dev_alloc(c->allocs, (void **) &c->h, (size_t) m->F * 4) || dev_alloc(c->allocs, (void **) &c->scores, (size_t) m->H * n_ctx * 4) ||
+        dev_alloc(c->allocs, (void **) &c->h, (size_t) m->F * 4) || dev_alloc(c->allocs, (void **) &c->scores, (size_t) m->H * c->n_ctx_pad * 4) || dev_alloc(c->allocs, (void **) &c->probs, (size_t) m->H * c->n_ctx_pad * 4) ||
         dev_alloc(c->allocs, (void **) &c->logits, (size_t) m->V * 4) || dev_alloc(c->allocs, (void **) &c->st, sizeof(bamd_step_state))) return 1;
     c->k = c->q + m->E; c->v = c->k + Ekv;                           // q | k | v contiguous: rows of the fused QKV mat-vec
     HIPC(hipMemsetAsync(c->st, 0, sizeof(bamd_step_state), c->stream));
@@ -359,8 +361,8 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         if (tm) tm->end(s);
         // 2. RoPE, KV store, softmax(QK^T) V                               (llama.cpp:8837-8849, :8318-8353)
         bamd_attn_args t; memset(&t, 0, sizeof t);
-        t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.out = c->att;
-        t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
+        t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
+        t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
         if (tm) tm->begin(s, 1, 0.0);
         // three-kernel path (scores | softmax | P.V) everywhere for now: the fused single-launch kernel is correct (tests)
         // but not yet faster at n_kv ~ 256 (14.9 vs 12.8 us on MI355X) — BAMD_ATTN_FUSED=1 selects it
@@ -643,6 +645,23 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_rope_row(int pos, 
     rope_row(row, pos, n_dims, freq_base, freq_scale, freq_factors, 0.0f, 1.0f, 8192, 32.0f, 1.0f);
     return 0;
 }
+// reference layout <-> chain-major device layout of the KV cache (bamd_kernels.hip, "Attention")
+static void kv_to_device_order(const uint16_t * k_ref, const uint16_t * v_ref, int n_ctx, int n_ctx_pad, int Hkv, int hd, std::vector<uint16_t> & kd, std::vector<uint16_t> & vd) {
+    const int Ekv = Hkv * hd, L = hd / 8;
+    kd.assign((size_t) n_ctx_pad * Ekv, 0); vd.assign((size_t) Ekv * n_ctx_pad, 0);
+    for (int i = 0; i < n_ctx; ++i) for (int h = 0; h < Hkv; ++h) for (int n = 0; n < hd; ++n)
+        kd[(size_t) i * Ekv + h * hd + (n & 7) * L + (n >> 3)] = k_ref[(size_t) i * Ekv + h * hd + n];
+    for (int r = 0; r < Ekv; ++r) for (int p = 0; p < n_ctx; ++p)
+        vd[(size_t) r * n_ctx_pad + (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3)] = v_ref[(size_t) r * n_ctx + p];
+}
+static void kv_from_device_order(uint16_t * k_ref, uint16_t * v_ref, int n_ctx, int n_ctx_pad, int Hkv, int hd, const std::vector<uint16_t> & kd, const std::vector<uint16_t> & vd) {
+    const int Ekv = Hkv * hd, L = hd / 8;
+    for (int i = 0; i < n_ctx; ++i) for (int h = 0; h < Hkv; ++h) for (int n = 0; n < hd; ++n)
+        k_ref[(size_t) i * Ekv + h * hd + n] = kd[(size_t) i * Ekv + h * hd + (n & 7) * L + (n >> 3)];
+    for (int r = 0; r < Ekv; ++r) for (int p = 0; p < n_ctx; ++p)
+        v_ref[(size_t) r * n_ctx + p] = vd[(size_t) r * n_ctx_pad + (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3)];
+}
+
 extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const float * q, const float * k, const float * v, uint16_t * k_cache, uint16_t * v_cache_t,
                                  const float * rope_row_h, int H, int Hkv, int hd, int n_ctx, int pos, int prefill_mode, float * out,
                                  float * probs_h0) {
@@ -650,24 +669,32 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     prefill_mode &= 1;
     if (need_device()) return 1;
     if (pos < 0 || pos >= n_ctx || n_ctx % 32 || H % Hkv) return fail("bad attention shape");
-    Tmp t; const int Ekv = Hkv * hd; const size_t kvb = (size_t) n_ctx * Ekv * 2;
+    Tmp t; const int Ekv = Hkv * hd; const int n_ctx_pad = (n_ctx + 63) / 64 * 64; const size_t kvb = (size_t) n_ctx_pad * Ekv * 2;
     std::vector<float> rope((size_t) n_ctx * hd, 0.f);
     memcpy(rope.data() + (size_t) pos * hd, rope_row_h, (size_t) hd * 4);
+    std::vector<uint16_t> kd, vd;
+    kv_to_device_order(k_cache, v_cache_t, n_ctx, n_ctx_pad, Hkv, hd, kd, vd);
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos = pos; h.n_ctx = n_ctx; h.n_kv = std::min(n_ctx, std::max(32, (pos + 1 + 31) / 32 * 32));
     bamd_attn_args a; memset(&a, 0, sizeof a);
     a.st = (bamd_step_state *) t.up(&h, sizeof h);
     a.q = (float *) t.up(q, (size_t) H * hd * 4); a.k = (float *) t.up(k, (size_t) Ekv * 4); a.v = (float *) t.up(v, (size_t) Ekv * 4);
-    a.kc = (unsigned short *) t.up(k_cache, kvb); a.vc = (unsigned short *) t.up(v_cache_t, kvb);
-    a.rope = (float *) t.up(rope.data(), rope.size() * 4); a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
-    if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.out) return fail("device alloc/copy failed");
-    a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
+    a.kc = (unsigned short *) t.up(kd.data(), kvb); a.vc = (unsigned short *) t.up(vd.data(), kvb);
+    a.rope = (float *) t.up(rope.data(), rope.size() * 4); a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4);
+    a.probs = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
+    if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.probs || !a.out) return fail("device alloc/copy failed");
+    a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx_pad; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
     { const int tiles = std::min(std::max(n_ctx / 64, 1), 32);
       if (bamd_launch_attention(a, H / Hkv, split_path ? -tiles : tiles, nullptr)) return fail("unsupported head configuration"); }
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(out, a.out, (size_t) H * hd * 4, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(k_cache, a.kc, kvb, hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(v_cache_t, a.vc, kvb, hipMemcpyDeviceToHost));
-    if (probs_h0 && split_path) HIPC(hipMemcpy(probs_h0, a.scores, (size_t) h.n_kv * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(kd.data(), a.kc, kvb, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(vd.data(), a.vc, kvb, hipMemcpyDeviceToHost));
+    kv_from_device_order(k_cache, v_cache_t, n_ctx, n_ctx_pad, Hkv, hd, kd, vd);
+    if (probs_h0 && split_path) {
+        std::vector<float> pp((size_t) n_ctx_pad);
+        HIPC(hipMemcpy(pp.data(), a.probs, (size_t) n_ctx_pad * 4, hipMemcpyDeviceToHost));
+        for (int p = 0; p < h.n_kv; ++p) probs_h0[p] = pp[(size_t) ((p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3))];
+    }
     return 0;
 }
 

@@ -831,94 +831,111 @@ __global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, c
 }
 
 // ===========================================================================================================
-// Attention (decode): RoPE + KV store + scores | softmax | P.V        (reference: llm_build_kv, llama.cpp:8318)
+// Attention (single token): RoPE + KV store + scores + softmax + P.V         (reference: llm_build_kv, llama.cpp:8318)
 // ===========================================================================================================
-// K cache [n_ctx][Hkv*hd] f16, V cache transposed [Hkv*hd][n_ctx] f16 — the reference's layouts (llama.cpp:7845-7875).
-// grid (Hkv, tiles of 64 positions), block 512 = 8 waves x (8 positions x 8 lanes).
+// KV cache, "chain-major" physical order (logically the reference's K [n_ctx][Hkv*hd] f16 and V^T [Hkv*hd][n_ctx] f16,
+// llama.cpp:7845-7875; bamd_op_attention converts at the boundary):
+//   K : inside each head row, element n = 8l + e is stored at index e*(hd/8) + l
+//   V^T: inside each row, position p = 64B + 8l + e is stored at index 64B + 8e + l
+// The reference's attention mat-muls (tinyBLAS, sgemm.cpp:405-431) keep 8 SIMD lanes e, each a sequential f32 chain over
+// the steps l.  With this order the wave lane that stands for SIMD lane e finds the operands of consecutive steps
+// CONTIGUOUS: 16-byte loads straight from HBM/L2, no LDS staging, no gather.
+__device__ __forceinline__ int kperm(int n, int L) { return (n & 7) * L + (n >> 3); }
+__device__ __forceinline__ int vperm(int p) { return (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3); }
+
+// dot of up to 32 steps for lane e: k8 = this lane's L halves of the K row (L <= 32), q = this lane's L floats / halves
+template <bool PREFILL>
+__device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const float * qf, const unsigned short * qh) {
+    if (!PREFILL) {
+        float acc = 0.f;                                           // tinyBLAS F16 x F32, KN = 8 (sgemm.cpp:405-431)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 8 < L) {
+                const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
+                const float4 qa = *(const float4 *) (qf + g * 8), qb = *(const float4 *) (qf + g * 8 + 4);
+                const float qv[8] = { qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w };
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), qv[u], acc);
+            }
+        }
+        return acc;
+    } else {
+        float a4[4] = { 0.f, 0.f, 0.f, 0.f };                      // ggml_vec_dot_f16: 4 accumulators x 8 lanes (ggml.c:2038)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 8 < L) {
+                const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
+                const uint4 qq = *(const uint4 *) (qh + g * 8);
+                const uint32_t qw[4] = { qq.x, qq.y, qq.z, qq.w };
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    a4[u & 3] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), h2f((qw[u >> 1] >> (16 * (u & 1))) & 0xffffu), a4[u & 3]);
+            }
+        }
+        const float s02 = a4[0] + a4[2], s13 = a4[1] + a4[3];
+        return s02 + s13;
+    }
+}
+__device__ __forceinline__ float hsum8_tinyblas(float v) { v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v); return v; }
+__device__ __forceinline__ float hsum8_vecdot(float v) { v = v + dpp_f_shl4(v); v = v + dpp_f_xor1(v); v = v + dpp_f_xor2(v); return v; }   // lo+hi, then two hadd_ps
+
+// RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143) of `nheads` consecutive heads of src into chain-major LDS copies
+__device__ __forceinline__ void rope_heads(const float * src, const float * rope, int hd, int nheads, float * qt, unsigned short * q16t,
+                                           unsigned short * k16t) {
+    const int L = hd >> 3;
+    for (int i = threadIdx.x; i < nheads * (hd / 2); i += blockDim.x) {
+        const int hh = i / (hd / 2), p = i - hh * (hd / 2);
+        const float c = rope[2 * p], s = rope[2 * p + 1];
+        const float x0 = src[hh * hd + 2 * p], x1 = src[hh * hd + 2 * p + 1];
+        const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
+        const float r0 = t0 - t1, r1 = t2 + t3;
+        const int i0 = hh * hd + kperm(2 * p, L), i1 = hh * hd + kperm(2 * p + 1, L);
+        if (qt) { qt[i0] = r0; qt[i1] = r1; q16t[i0] = f2h(r0); q16t[i1] = f2h(r1); }
+        else { k16t[i0] = f2h(r0); k16t[i1] = f2h(r1); }
+    }
+}
+
+// ---- long contexts: three launches (scores | softmax | P.V), positions / rows spread over many workgroups ------------------
+// grid (Hkv, tiles of 64 positions), block 512 = 8 waves x (8 positions x 8 lanes); the GQ query heads of a KV head share K
 template <int GQ>
 __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
-    __shared__ float q_s[GQ * 256];
-    __shared__ unsigned short q16_s[GQ * 256];
-    __shared__ unsigned short k16_s[256];
+    __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
     const bamd_step_state * st = a.st;
     const int pos = st->pos, n_kv = st->n_kv;
-    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
     const int hk = blockIdx.x;
-    const float * rope = a.rope + (size_t) pos * hd;          // (cos, sin) pairs, host-built (ggml_rope_cache_init)
-    // RoPE (NORM mode, adjacent pairs) — ggml.c:14130-14143
-    for (int i = threadIdx.x; i < (GQ + 1) * (hd / 2); i += blockDim.x) {
-        const int hh = i / (hd / 2), p = i % (hd / 2);
-        const float c = rope[2 * p], s = rope[2 * p + 1];
-        if (hh < GQ) {
-            const float * src = a.q + (size_t) (hk * GQ + hh) * hd + 2 * p;
-            const float x0 = src[0], x1 = src[1];
-            const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
-            const float r0 = t0 - t1, r1 = t2 + t3;
-            q_s[hh * hd + 2 * p] = r0; q_s[hh * hd + 2 * p + 1] = r1;
-            q16_s[hh * hd + 2 * p] = f2h(r0); q16_s[hh * hd + 2 * p + 1] = f2h(r1);
-        } else {
-            const float * src = a.k + (size_t) hk * hd + 2 * p;
-            const float x0 = src[0], x1 = src[1];
-            const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
-            k16_s[2 * p] = f2h(t0 - t1); k16_s[2 * p + 1] = f2h(t2 + t3);
-        }
-    }
+    const float * rope = a.rope + (size_t) pos * hd;
+    rope_heads(a.q + (size_t) hk * GQ * hd, rope, hd, GQ, qt, q16t, nullptr);
+    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
     __syncthreads();
-    const int tiles = (n_kv + 63) >> 6;
     // KV store by the block that owns the tile of `pos` — llm_build_kv_store, llama.cpp:7830-7875
     if ((int) blockIdx.y == ((pos >> 6) % (int) gridDim.y)) {
         for (int i = threadIdx.x; i < hd; i += blockDim.x) {
-            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16_s[i];
-            a.vc[(size_t) (hk * hd + i) * n_ctx + pos] = f2h(a.v[hk * hd + i]);
+            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
         }
     }
-    const int lane = threadIdx.x & 63, wave = wave_id();
-    const int e = lane & 7;
+    const int lane = threadIdx.x & 63, wave = wave_id(), e = lane & 7;
+    const int tiles = (n_kv + 63) >> 6;
     for (int tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
         const int i = tile * 64 + wave * 8 + (lane >> 3);        // position
         if (i >= n_kv) continue;
         float sc[GQ];
-        if (i > pos) {
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) sc[g] = -INFINITY;      // masked (KQ_mask, llama.cpp:14152-14200)
-        } else {
-            const unsigned short * krow = (i == pos) ? k16_s : a.kc + (size_t) i * Ekv + hk * hd;
-            if (!a.prefill_mode) {
-                // tinyBLAS F16 x F32, KN = 8: Cv[e] = fma(K[l+e], q[l+e], Cv[e]) ; then hsum   (sgemm.cpp:405-431)
-                float acc[GQ];
+        for (int g = 0; g < GQ; ++g) sc[g] = -INFINITY;          // masked (KQ_mask, llama.cpp:14152-14200)
+        if (i <= pos) {
+            uint4 kreg[4];
 #pragma unroll
-                for (int g = 0; g < GQ; ++g) acc[g] = 0.f;
-                for (int l = 0; l < hd; l += 8) {
-                    const float kv = h2f(krow[l + e]);
+            for (int g = 0; g < 4; ++g) {
+                kreg[g] = make_uint4(0, 0, 0, 0);
+                if (g * 8 < L) kreg[g] = i == pos ? *(const uint4 *) (k16t + e * L + g * 8) : *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8);
+            }
 #pragma unroll
-                    for (int g = 0; g < GQ; ++g) acc[g] = fmaf(kv, q_s[g * hd + l + e], acc[g]);
-                }
-#pragma unroll
-                for (int g = 0; g < GQ; ++g) {
-                    float v = acc[g];
-                    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-                    sc[g] = v;
-                }
-            } else {
-                // T > 1: q rounded to f16, ggml_vec_dot_f16 with 4 accumulators x 8 lanes (ggml.c:2038, :1285-1305)
-                float acc[GQ][4];
-#pragma unroll
-                for (int g = 0; g < GQ; ++g) { acc[g][0] = acc[g][1] = acc[g][2] = acc[g][3] = 0.f; }
-                for (int l = 0; l < hd; l += 32) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float kv = h2f(krow[l + 8 * j + e]);
-#pragma unroll
-                        for (int g = 0; g < GQ; ++g) acc[g][j] = fmaf(kv, h2f(q16_s[g * hd + l + 8 * j + e]), acc[g][j]);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < GQ; ++g) {
-                    const float s02 = acc[g][0] + acc[g][2], s13 = acc[g][1] + acc[g][3];
-                    float v = s02 + s13;
-                    v += __shfl_xor(v, 4); v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);   // lo+hi, then two hadd_ps
-                    sc[g] = v;
-                }
+            for (int g = 0; g < GQ; ++g) {
+                const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * L) : kq_chain<false>(kreg, L, qt + g * hd + e * L, nullptr);
+                sc[g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
             }
         }
         if (e == 0) {
@@ -929,6 +946,7 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 }
 
 // softmax over n_kv scores of one head: grid (H), block 256.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
+// Probabilities are written back in the V^T position order (vperm) so the P.V lanes read them contiguously.
 __global__ void __launch_bounds__(256) attn_softmax_kernel(bamd_attn_args a) {
     __shared__ float redf[4];
     __shared__ double redd[4];
@@ -938,33 +956,30 @@ __global__ void __launch_bounds__(256) attn_softmax_kernel(bamd_attn_args a) {
     float * s = a.scores + (size_t) h * n_ctx;
     const float scale = a.kq_scale;
     const int lane = threadIdx.x & 63, wave = wave_id();
-    // wp = s*scale + mask  (mask already folded in as -inf scores); max
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < n_kv; i += blockDim.x) { const float w = s[i] * scale; mx = w > mx ? w : mx; }
     for (int o = 32; o; o >>= 1) { const float om = __shfl_xor(mx, o); mx = om > mx ? om : mx; }
     if (lane == 0) redf[wave] = mx;
     __syncthreads();
     mx = redf[0]; for (int w = 1; w < 4; ++w) mx = redf[w] > mx ? redf[w] : mx;
-    // exp, 8-element chunk sums (f32 tree of the reference), double accumulation of the chunk sums
     double sum = 0.0;
     for (int i = threadIdx.x; i < n_kv; i += blockDim.x) {
         const float w = s[i] * scale;
         const float val = v_expf(w - mx);
-        s[i] = val;
-        float c = val;
-        c += __shfl_xor(c, 4); c += __shfl_xor(c, 2); c += __shfl_xor(c, 1);
+        s[i] = val;                                              // same index this thread just read: no hazard
+        const float c = hsum8_tinyblas(val);                     // the reference's 8-wide partial sum (same tree shape)
         if ((lane & 7) == 0) sum += (double) c;
     }
-    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_f64(sum);
     if (lane == 0) redd[wave] = sum;
     __syncthreads();
     double tot = 0.0; for (int w = 0; w < 4; ++w) tot += redd[w];
     const float fs = (float) (1.0 / tot);
-    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) s[i] = s[i] * fs;
+    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) a.probs[(size_t) h * n_ctx + vperm(i)] = s[i] * fs;
 }
 
-// P.V: grid (Hkv, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d) for the
-// GQ heads that share this KV head.  sgemm.cpp:405-431 with A = V^T rows (f16), B = p (f32).
+// P.V: grid (Hkv, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d) for the GQ heads
+// that share this KV head.  sgemm.cpp:405-431 with A = V^T rows (f16), B = p (f32).
 template <int GQ>
 __global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
     const bamd_step_state * st = a.st;
@@ -973,160 +988,100 @@ __global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
     const int lane = threadIdx.x, e = lane & 7;
     const int d = blockIdx.y * 8 + (lane >> 3);
     const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx;
-    const float * p = a.scores + (size_t) (hk * GQ) * n_ctx;
+    const float * p = a.probs + (size_t) (hk * GQ) * n_ctx;
     float acc[GQ];
 #pragma unroll
     for (int g = 0; g < GQ; ++g) acc[g] = 0.f;
-    for (int l = 0; l < n_kv; l += 8) {
-        const float vv = h2f(vrow[l + e]);
+    for (int b0 = 0; b0 < n_kv; b0 += 64) {                      // one 64-position block = 8 chain steps per lane
+        const uint4 vv = *(const uint4 *) (vrow + b0 + e * 8);
+        const uint32_t w[4] = { vv.x, vv.y, vv.z, vv.w };
+        const int nstep = n_kv - b0 >= 64 ? 8 : (n_kv - b0) >> 3;
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) acc[g] = fmaf(vv, p[(size_t) g * n_ctx + l + e], acc[g]);
+        for (int g = 0; g < GQ; ++g) {
+            const float4 pa = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8), pb = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8 + 4);
+            const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < nstep) acc[g] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc[g]);
+        }
     }
 #pragma unroll
     for (int g = 0; g < GQ; ++g) {
-        float v = acc[g];
-        v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        const float v = hsum8_tinyblas(acc[g]);
         if (e == 0) a.out[(size_t) (hk * GQ + g) * hd + d] = v;
     }
 }
 
-// -----------------------------------------------------------------------------------------------------------
-// Fused single-token attention for short/medium contexts (n_kv <= BAMD_ATTN_FUSED_MAX): ONE launch per layer,
-// one workgroup per QUERY head.  RoPE -> KV store -> scores -> softmax -> P.V with scores/probabilities in LDS.
-// The K/V rows of a KV head are re-read by the GQ query heads that share it (L2 traffic only).  Same arithmetic
-// and order as the three-kernel path above.
-// -----------------------------------------------------------------------------------------------------------
+// ---- short / medium contexts (n_kv <= BAMD_ATTN_FUSED_MAX): ONE launch per layer, one workgroup per QUERY head -------------
 #define BAMD_ATTN_FUSED_MAX 2048
-#define BAMD_ATTN_VTILE 256                      /* positions of V staged per pass */
-// K and V^T tiles are fetched with 16-byte-per-lane loads (a 2-byte-per-lane gather is 8x more L1 address work) and
-// TRANSPOSED on their way into LDS, so that the lane which carries SIMD-lane e of the reference's 8-wide chain finds its
-// operands of consecutive steps l contiguous:   Kt[row][e][l], Vt[d][e][l], qt[e][l], pt[e][l]  ->  ds_read_b128 only.
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ __attribute__((aligned(16))) float qt[256];          // [e][hd/8]
+    __shared__ __attribute__((aligned(16))) float qt[256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
-    __shared__ __attribute__((aligned(16))) unsigned short k16_s[256];   // this token's roped K row, natural order
-    __shared__ __attribute__((aligned(16))) float sc[BAMD_ATTN_FUSED_MAX];   // scores, natural order
-    __shared__ __attribute__((aligned(16))) float pt[BAMD_ATTN_FUSED_MAX];   // probabilities, [tile][e][l]
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    __shared__ __attribute__((aligned(16))) float sc[BAMD_ATTN_FUSED_MAX];   // scores, then exp values (natural order)
+    __shared__ __attribute__((aligned(16))) float pt[BAMD_ATTN_FUSED_MAX];   // probabilities in V^T position order
     __shared__ float redf[8];
     __shared__ double redd[8];
     const bamd_step_state * st = a.st;
     const int pos = st->pos, n_kv = st->n_kv;
-    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
     const int h = blockIdx.x, hk = h / gq;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
-    const int L = hd / 8;                                          // chain steps per K row (<= 32)
     const float * rope = a.rope + (size_t) pos * hd;
     STAMP(0);
-    // RoPE (NORM mode) of this head's q and of the KV head's k — ggml.c:14130-14143
-    for (int i = tid; i < hd; i += blockDim.x) {                   // i < hd/2: q pair, else k pair
-        const int p = i < hd / 2 ? i : i - hd / 2;
-        const float c = rope[2 * p], s = rope[2 * p + 1];
-        const float * src = i < hd / 2 ? a.q + (size_t) h * hd + 2 * p : a.k + (size_t) hk * hd + 2 * p;
-        const float x0 = src[0], x1 = src[1];
-        const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
-        const float r0 = t0 - t1, r1 = t2 + t3;
-        if (i < hd / 2) {
-            const int n0 = 2 * p, n1 = 2 * p + 1;                  // element n -> [n & 7][n >> 3]
-            qt[(n0 & 7) * L + (n0 >> 3)] = r0; qt[(n1 & 7) * L + (n1 >> 3)] = r1;
-            q16t[(n0 & 7) * L + (n0 >> 3)] = f2h(r0); q16t[(n1 & 7) * L + (n1 >> 3)] = f2h(r1);
-        } else { k16_s[2 * p] = f2h(r0); k16_s[2 * p + 1] = f2h(r1); }
+    // requests that do not depend on RoPE go out first: this lane's K chunks of the first 4 x 64 positions and its V^T chunks
+    const int r_pos = wave * 8 + (lane >> 3);                     // position inside a 64-tile (scores) / d inside a 64-block (P.V)
+    uint4 kreg[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = t * 64 + r_pos;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kreg[t][g] = (i < n_kv && i < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
     }
+    // ... and its V^T chunks: the first 4 blocks of 64 positions of rows d = r_pos and r_pos + 64 (consumed after the softmax)
+    uint4 vreg[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const int d = r_pos + 64 * dd;
+            vreg[t][dd] = (t * 64 < n_kv && d < hd) ? *(const uint4 *) (a.vc + (size_t) (hk * hd + d) * n_ctx + t * 64 + e * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    rope_heads(a.q + (size_t) h * hd, rope, hd, 1, qt, q16t, nullptr);
+    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
     __syncthreads();
     // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
     if (h == hk * gq) {
         for (int i = tid; i < hd; i += blockDim.x) {
-            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16_s[i];
-            a.vc[(size_t) (hk * hd + i) * n_ctx + pos] = f2h(a.v[hk * hd + i]);
+            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
         }
     }
     STAMP(1);
-    // ---- scores: tiles of 256 positions; all 16-byte K loads of a tile are issued first (one HBM round trip per tile),
-    //      then the tile is transposed into LDS: Kt[r][e][l] halves, row = hd*2 + 16 bytes ----
-    const int krow_b = hd * 2 + 16;
-    const int lsh = 31 - __clz(L);                                 // L is a power of two for hd in {32, 64, 128, 256}
-    // first V^T tile: requested now, consumed after the softmax (its HBM round trip hides behind scores + softmax)
-    const int np0 = n_kv < BAMD_ATTN_VTILE ? n_kv : BAMD_ATTN_VTILE;
-    const int LV0 = np0 / 8;
-    uint4 vreg[8];                                                 // hd * LV0 chunks / 512 threads <= 8 for hd <= 128
+    // ---- scores ----
+#define BAMD_SCORE_TILE(t0_, KL_) do { \
+        const int i = (t0_) + r_pos; \
+        float v = -INFINITY;                                       /* masked (KQ_mask, llama.cpp:14152-14200) */ \
+        if (i < n_kv && i <= pos) { \
+            if (i == pos) {                                        /* this token's K row is not visible in the cache yet */ \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) if (g * 8 < L) KL_[g] = *(const uint4 *) (k16t + e * L + g * 8); \
+            } \
+            v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(KL_, L, nullptr, q16t + e * L)) : hsum8_tinyblas(kq_chain<false>(KL_, L, qt + e * L, nullptr)); \
+        } \
+        if (e == 0 && i < n_kv) sc[i] = v; \
+    } while (0)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int c = tid + u * 512;
-        vreg[u] = make_uint4(0, 0, 0, 0);
-        if (c < hd * LV0) { const int d = c / LV0, l = c - d * LV0; vreg[u] = *(const uint4 *) (a.vc + (size_t) (hk * hd + d) * n_ctx + l * 8); }
+    for (int t = 0; t < 4; ++t) { if (t * 64 < n_kv) BAMD_SCORE_TILE(t * 64, kreg[t]); }
+    for (int t0 = 256; t0 < n_kv; t0 += 64) {
+        const int i2 = t0 + r_pos;
+        uint4 kl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kl[g] = (i2 < n_kv && i2 < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i2 * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+        BAMD_SCORE_TILE(t0, kl);
     }
-    for (int t0 = 0; t0 < n_kv; t0 += 256) {
-        const int nr = n_kv - t0 < 256 ? n_kv - t0 : 256;
-        uint4 kreg[8];                                             // 256 rows * L chunks / 512 threads <= 16; hd <= 128 -> 8
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + u * 512, r = c >> lsh, l = c & (L - 1), i = t0 + r;
-            kreg[u] = make_uint4(0, 0, 0, 0);
-            if (r < nr && i <= pos) kreg[u] = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + l * 8);
-        }
-        for (int u2 = 8; u2 * 512 < 256 * L; ++u2) { (void) u2; }  // hd = 256 handled by the second loop below
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + u * 512, r = c >> lsh, l = c & (L - 1), i = t0 + r;
-            if (r < nr) {
-                uint4 val = kreg[u];
-                if (i == pos) val = *(const uint4 *) (k16_s + l * 8);      // this token's row is not visible in the cache yet
-                unsigned short * dst = (unsigned short *) (smem + r * krow_b) + l;
-                const uint32_t w4[4] = { val.x, val.y, val.z, val.w };
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { dst[(2 * j) * L] = (unsigned short) w4[j]; dst[(2 * j + 1) * L] = (unsigned short) (w4[j] >> 16); }
-            }
-        }
-        for (int c = tid + 8 * 512; c < nr * L; c += 512) {        // only when hd = 256
-            const int r = c >> lsh, l = c & (L - 1), i = t0 + r;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (i <= pos) val = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + l * 8);
-            if (i == pos) val = *(const uint4 *) (k16_s + l * 8);
-            unsigned short * dst = (unsigned short *) (smem + r * krow_b) + l;
-            const uint32_t w4[4] = { val.x, val.y, val.z, val.w };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { dst[(2 * j) * L] = (unsigned short) w4[j]; dst[(2 * j + 1) * L] = (unsigned short) (w4[j] >> 16); }
-        }
-        __syncthreads();
-        if (t0 == 0) STAMP(2);
-        for (int r0 = 0; r0 < nr; r0 += 64) {
-            const int r = r0 + wave * 8 + (lane >> 3), i = t0 + r;
-            float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
-            if (r < nr && i <= pos) {
-                const uint4 * kp = (const uint4 *) (smem + r * krow_b + e * L * 2);
-                const unsigned short * kh = (const unsigned short *) kp;
-                if (!a.prefill_mode) {
-                    float acc = 0.f;                               // tinyBLAS F16 x F32, KN = 8 (sgemm.cpp:405-431)
-                    for (int l0 = 0; l0 < L; l0 += 8) {
-                        unsigned short kb[8]; float qb[8];
-                        if ((L & 7) == 0) {
-                            const uint4 kk = kp[l0 >> 3];
-                            kb[0] = (unsigned short) kk.x; kb[1] = (unsigned short) (kk.x >> 16); kb[2] = (unsigned short) kk.y; kb[3] = (unsigned short) (kk.y >> 16);
-                            kb[4] = (unsigned short) kk.z; kb[5] = (unsigned short) (kk.z >> 16); kb[6] = (unsigned short) kk.w; kb[7] = (unsigned short) (kk.w >> 16);
-                            const float4 qa = *(const float4 *) (qt + e * L + l0), qc = *(const float4 *) (qt + e * L + l0 + 4);
-                            qb[0] = qa.x; qb[1] = qa.y; qb[2] = qa.z; qb[3] = qa.w; qb[4] = qc.x; qb[5] = qc.y; qb[6] = qc.z; qb[7] = qc.w;
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) { kb[u] = l0 + u < L ? kh[l0 + u] : (unsigned short) 0; qb[u] = l0 + u < L ? qt[e * L + l0 + u] : 0.f; }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) if (l0 + u < L) acc = fmaf(h2f(kb[u]), qb[u], acc);
-                    }
-                    v = acc;
-                    v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
-                } else {
-                    float a4[4] = { 0.f, 0.f, 0.f, 0.f };          // ggml_vec_dot_f16, 4 accumulators x 8 lanes (ggml.c:2038)
-                    for (int l = 0; l < L; ++l) a4[l & 3] = fmaf(h2f(kh[l]), h2f(q16t[e * L + l]), a4[l & 3]);
-                    const float s02 = a4[0] + a4[2], s13 = a4[1] + a4[3];
-                    v = s02 + s13;
-                    v = v + dpp_f_shl4(v); v = v + dpp_f_xor1(v); v = v + dpp_f_xor2(v);   // lo+hi, then two hadd_ps
-                }
-            }
-            if (e == 0 && r < nr) sc[i] = v;
-        }
-        __syncthreads();
-    }
-    STAMP(3);
+#undef BAMD_SCORE_TILE
+    __syncthreads();
+    STAMP(2);
     // ---- softmax (ggml.c:13682-13778 + :2619-2671): wp = s*scale (+mask), max, exp, 8-chunk f32 sums, double total ----
     const float scale = a.kq_scale;
     float mx = -INFINITY;
@@ -1144,8 +1099,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float w = sc[i] * scale;
         const float val = v_expf(w - mx);
         sc[i] = val;
-        float c = val;
-        c = c + dpp_f_shl4(c); c = c + dpp_f_xor2(c); c = c + dpp_f_xor1(c);
+        const float c = hsum8_tinyblas(val);
         if (e == 0) sum += (double) c;
     }
     sum = wave_sum_f64(sum);
@@ -1154,92 +1108,54 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     double tot = 0.0;
     for (int w = 0; w < 8; ++w) tot += redd[w];
     const float fs = (float) (1.0 / tot);
-    for (int i = tid; i < n_kv; i += blockDim.x) {                 // p = val * (float)(1/sum), stored as pt[tile][e][l]
-        const int t0 = i / BAMD_ATTN_VTILE, j = i - t0 * BAMD_ATTN_VTILE;
-        const int np = n_kv - t0 * BAMD_ATTN_VTILE < BAMD_ATTN_VTILE ? n_kv - t0 * BAMD_ATTN_VTILE : BAMD_ATTN_VTILE;
-        pt[t0 * BAMD_ATTN_VTILE + (j & 7) * (np / 8) + (j >> 3)] = sc[i] * fs;
-    }
+    for (int i = tid; i < n_kv; i += blockDim.x) pt[vperm(i)] = sc[i] * fs;
+    // half-filled last block (n_kv % 64 == 32): p = 0 for the missing positions, so the chain steps there are exact no-ops
+    for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) pt[vperm(i)] = 0.f;
     __syncthreads();
-    STAMP(4);
-    // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (sgemm.cpp:405-431: A = V^T row, B = p);
-    //      V^T staged transposed in tiles of BAMD_ATTN_VTILE positions: Vt[d][e][l], row = np*2 + 16 bytes ----
-    const int d_lo = wave * 8 + (lane >> 3);
-    float acc4[4] = { 0.f, 0.f, 0.f, 0.f };                        // d_lo, d_lo+64, +128, +192
-    for (int p0 = 0; p0 < n_kv; p0 += BAMD_ATTN_VTILE) {
-        const int np = n_kv - p0 < BAMD_ATTN_VTILE ? n_kv - p0 : BAMD_ATTN_VTILE;   // multiple of 32
-        const int LV = np / 8, vrow_b = np * 2 + 16;
-        // chunk c = (row d, step l): 8 positions e = 0..7; the first tile's chunks were prefetched before the scores phase
-#define BAMD_STAGE_V(c_, val_in) do { \
-            const int d = (c_) / LV, l = (c_) - d * LV; \
-            uint4 val = (val_in); \
-            const int idx = pos - (p0 + l * 8);                    /* column `pos` is being written by another workgroup: */ \
-            if (idx >= 0 && idx < 8) {                             /* splice this token's v (f16) into the chunk */ \
-                const uint32_t hv = f2h(a.v[hk * hd + d]); \
-                const uint32_t keep = (idx & 1) ? 0x0000ffffu : 0xffff0000u, ins = (idx & 1) ? hv << 16 : hv; \
-                const int wi = idx >> 1; \
-                val.x = wi == 0 ? (val.x & keep) | ins : val.x; val.y = wi == 1 ? (val.y & keep) | ins : val.y; \
-                val.z = wi == 2 ? (val.z & keep) | ins : val.z; val.w = wi == 3 ? (val.w & keep) | ins : val.w; \
-            } \
-            unsigned short * dst = (unsigned short *) (smem + d * vrow_b) + l; \
-            dst[0 * LV] = (unsigned short) val.x; dst[1 * LV] = (unsigned short) (val.x >> 16); \
-            dst[2 * LV] = (unsigned short) val.y; dst[3 * LV] = (unsigned short) (val.y >> 16); \
-            dst[4 * LV] = (unsigned short) val.z; dst[5 * LV] = (unsigned short) (val.z >> 16); \
-            dst[6 * LV] = (unsigned short) val.w; dst[7 * LV] = (unsigned short) (val.w >> 16); \
-        } while (0)
-        if (p0 == 0) {
+    STAMP(3);
+    // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (A = V^T row, B = p), up to 4 rows d per lane ----
+    const unsigned short vcur[4] = { f2h(a.v[hk * hd + (r_pos < hd ? r_pos : 0)]), f2h(a.v[hk * hd + (r_pos + 64 < hd ? r_pos + 64 : 0)]),
+                                     f2h(a.v[hk * hd + (r_pos + 128 < hd ? r_pos + 128 : 0)]), f2h(a.v[hk * hd + (r_pos + 192 < hd ? r_pos + 192 : 0)]) };
+    float acc4[4] = { 0.f, 0.f, 0.f, 0.f };
+    const int pblk = pos & ~63, pe = pos & 7, pl = (pos & 63) >> 3;   // where this token's own V element sits
+#define BAMD_PV_BLOCK(b0_, dd_, VV_) do { \
+        const float4 pa = *(const float4 *) (pt + (b0_) + e * 8), pb = *(const float4 *) (pt + (b0_) + e * 8 + 4); \
+        const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w }; \
+        uint32_t w[4] = { (VV_).x, (VV_).y, (VV_).z, (VV_).w }; \
+        if ((b0_) == pblk && e == pe) {                            /* column `pos` is being written by another workgroup: splice it in */ \
+            const uint32_t keep = (pl & 1) ? 0x0000ffffu : 0xffff0000u, ins = (pl & 1) ? (uint32_t) vcur[dd_] << 16 : (uint32_t) vcur[dd_]; \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j == (pl >> 1)) w[j] = (w[j] & keep) | ins; \
+        } \
+        float acc = acc4[dd_]; \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc); \
+        acc4[dd_] = acc; \
+    } while (0)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int c = tid + u * 512; if (c < hd * LV) BAMD_STAGE_V(c, vreg[u]); }
-            for (int c = tid + 8 * 512; c < hd * LV; c += 512) BAMD_STAGE_V(c, *(const uint4 *) (a.vc + (size_t) (hk * hd + c / LV) * n_ctx + p0 + (c % LV) * 8));
-        } else {
-            for (int c0 = tid; c0 < hd * LV; c0 += 8 * 512) {      // 8 independent loads in flight per thread
-                uint4 vt[8];
+    for (int t = 0; t < 4; ++t) {                                  // blocks whose V chunks were requested at kernel entry
+        if (t * 64 < n_kv) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int c = c0 + u * 512; vt[u] = make_uint4(0, 0, 0, 0); if (c < hd * LV) vt[u] = *(const uint4 *) (a.vc + (size_t) (hk * hd + c / LV) * n_ctx + p0 + (c % LV) * 8); }
+            for (int dd = 0; dd < 2; ++dd) if (r_pos + 64 * dd < hd) BAMD_PV_BLOCK(t * 64, dd, vreg[t][dd]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int c = c0 + u * 512; if (c < hd * LV) BAMD_STAGE_V(c, vt[u]); }
+            for (int dd = 2; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {  // hd > 128
+                const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + t * 64 + e * 8);
+                BAMD_PV_BLOCK(t * 64, dd, vv);
             }
         }
-#undef BAMD_STAGE_V
-        __syncthreads();
-        if (p0 == 0) STAMP(5);
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const int d = d_lo + 64 * dd;
-            if (d < hd) {
-                const uint4 * vp = (const uint4 *) (smem + d * vrow_b + e * LV * 2);   // LV % 4 == 0 -> 8-byte aligned; use 8-half groups when LV % 8 == 0
-                const unsigned short * vh = (const unsigned short *) vp;
-                const float * pp = pt + p0 + e * LV;
-                float acc = acc4[dd];
-                for (int l0 = 0; l0 < LV; l0 += 8) {
-                    unsigned short vb[8]; float pb[8];
-                    if ((LV & 7) == 0) {
-                        const uint4 vv = vp[l0 >> 3];
-                        vb[0] = (unsigned short) vv.x; vb[1] = (unsigned short) (vv.x >> 16); vb[2] = (unsigned short) vv.y; vb[3] = (unsigned short) (vv.y >> 16);
-                        vb[4] = (unsigned short) vv.z; vb[5] = (unsigned short) (vv.z >> 16); vb[6] = (unsigned short) vv.w; vb[7] = (unsigned short) (vv.w >> 16);
-                        const float4 pa = *(const float4 *) (pp + l0), pc = *(const float4 *) (pp + l0 + 4);
-                        pb[0] = pa.x; pb[1] = pa.y; pb[2] = pa.z; pb[3] = pa.w; pb[4] = pc.x; pb[5] = pc.y; pb[6] = pc.z; pb[7] = pc.w;
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { vb[u] = l0 + u < LV ? vh[l0 + u] : (unsigned short) 0; pb[u] = l0 + u < LV ? pp[l0 + u] : 0.f; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) if (l0 + u < LV) acc = fmaf(h2f(vb[u]), pb[u], acc);
-                }
-                acc4[dd] = acc;
-            }
-        }
-        __syncthreads();
     }
+    for (int b0 = 256; b0 < n_kv; b0 += 64) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {
+            const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
+            BAMD_PV_BLOCK(b0, dd, vv);
+        }
+    }
+#undef BAMD_PV_BLOCK
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
-        const int d = d_lo + 64 * dd;
-        if (d < hd) {
-            float v = acc4[dd];
-            v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
-            if (e == 0) a.out[(size_t) h * hd + d] = v;
-        }
+        const int d = r_pos + 64 * dd;
+        if (d < hd) { const float v = hsum8_tinyblas(acc4[dd]); if (e == 0) a.out[(size_t) h * hd + d] = v; }
     }
-    STAMP(6);
+    STAMP(4);
 }
 
 // ===========================================================================================================
@@ -1314,12 +1230,11 @@ void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_
 }
 
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
-    if (a.hd > 256 || (a.hd & 31)) return 1;
+    if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     if (a.n_ctx <= BAMD_ATTN_FUSED_MAX && max_tiles >= 0) {
         // context fits the LDS score buffer: one fused launch per layer, one workgroup per query head
-        { size_t ks = (size_t) 256 * (a.hd * 2 + 16), vs = (size_t) a.hd * (BAMD_ATTN_VTILE * 2 + 16);
-          hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), ks > vs ? ks : vs, s, a, gq); }
+        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), 0, s, a, gq);
         return 0;
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;

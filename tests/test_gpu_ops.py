@@ -162,7 +162,7 @@ def oracle_attention(po, q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill)
     return out, probs0
 
 
-@pytest.mark.parametrize("H,Hkv,hd", [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 32)])
+@pytest.mark.parametrize("H,Hkv,hd", [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 256)])
 @pytest.mark.parametrize("prefill", [False, True])
 @pytest.mark.parametrize("long_path", [False, True])
 def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
