@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbooster_amd.so")
+LIB_PATH = os.environ.get("BAMD_LIB") or os.path.join(_HERE, "lib", "libbooster_amd.so")   # BAMD_LIB: experiment builds (tools/)
 _lib = None
 
 F32, F16, Q4_K, Q5_K, Q6_K = 0, 1, 12, 13, 14

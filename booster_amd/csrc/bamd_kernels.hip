@@ -111,20 +111,21 @@ __global__ void repack_kernel(const uint8_t * __restrict__ raw, uint8_t * __rest
 // ===========================================================================================================
 // ---- cross-lane helpers: DPP (no LDS-crossbar latency) for everything inside a row of 16 lanes, v_readlane across rows ----
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ int dpp_z(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // old = 0: foldable into add / umax
 #define DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
 #define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
 #define DPP_HALF_MIRROR 0x141  /* lane i <-> 7-i inside each group of 8 */
 #define DPP_MIRROR 0x140       /* lane i <-> 15-i inside each row of 16 */
 __device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {             // wave-uniform result
-    v = umax_(v, (uint32_t) dpp_i<DPP_XOR1>((int) v)); v = umax_(v, (uint32_t) dpp_i<DPP_XOR2>((int) v));
-    v = umax_(v, (uint32_t) dpp_i<DPP_HALF_MIRROR>((int) v)); v = umax_(v, (uint32_t) dpp_i<DPP_MIRROR>((int) v));
+    v = umax_(v, (uint32_t) dpp_z<DPP_XOR1>((int) v)); v = umax_(v, (uint32_t) dpp_z<DPP_XOR2>((int) v));
+    v = umax_(v, (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) v)); v = umax_(v, (uint32_t) dpp_z<DPP_MIRROR>((int) v));
     const uint32_t r0 = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), r1 = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
     const uint32_t r2 = (uint32_t) __builtin_amdgcn_readlane((int) v, 47), r3 = (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
     return umax_(umax_(r0, r1), umax_(r2, r3));
 }
 __device__ __forceinline__ int group8_sum(int v) {                          // sum over aligned groups of 8 lanes, in every lane
-    v += dpp_i<DPP_XOR1>(v); v += dpp_i<DPP_XOR2>(v); v += dpp_i<DPP_HALF_MIRROR>(v);
+    v += dpp_z<DPP_XOR1>(v); v += dpp_z<DPP_XOR2>(v); v += dpp_z<DPP_HALF_MIRROR>(v);
     return v;
 }
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
@@ -159,45 +160,77 @@ struct ActPro {
         }
     }
 
+    // Issue-bound code (every CU quantises the whole activation vector: ~1/3 of a decode step's VALU work), so the instruction
+    // count per block is what matters here:
+    //   - the two IEEE divisions per block (iscale = -127/max, d = 1/iscale) run ONCE per batch: block b's operand sits in lane b;
+    //   - nearest_int(v) & 0xff is the low byte of the bits of v + 12582912.f (ggml-quants.c:1632-1637: the mask and the
+    //     0x400000 offset do not touch that byte), and MIN(127, .) (:3617) never binds for |iscale * x| <= 127(1 + 2^-23);
+    //   - the sum of the four signed bytes is one v_dot4 against 0x01010101;
+    //   - the four wave-max chains are interleaved step by step (DPP results need wait states); row_bcast leaves the result in lane 63.
     __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd) {
         const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, nb = K >> 8;
-        uint32_t amaxb[BAMD_ACT_BATCH]; float mxl[BAMD_ACT_BATCH];
+        uint32_t amaxb[BAMD_ACT_BATCH];
 #pragma unroll
         for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
             if (NORM) {                                  // y = (x*scale)*w : ggml_vec_scale_f32 then ggml_mul (llama.cpp:7940-7950)
                 v[b].x = (v[b].x * scale) * w[b].x; v[b].y = (v[b].y * scale) * w[b].y;
                 v[b].z = (v[b].z * scale) * w[b].z; v[b].w = (v[b].w * scale) * w[b].w;
             }
-            float amax = 0.f, mx = 0.f;
-            { const float a = fabsf(v[b].x); if (a > amax) { amax = a; mx = v[b].x; } }
-            { const float a = fabsf(v[b].y); if (a > amax) { amax = a; mx = v[b].y; } }
-            { const float a = fabsf(v[b].z); if (a > amax) { amax = a; mx = v[b].z; } }
-            { const float a = fabsf(v[b].w); if (a > amax) { amax = a; mx = v[b].w; } }
-            amaxb[b] = __float_as_uint(amax);            // non-negative floats order like their bit patterns
-            mxl[b] = mx;
+            const float a = fmaxf(fmaxf(fmaxf(fabsf(v[b].x), fabsf(v[b].y)), fabsf(v[b].z)), fabsf(v[b].w));
+            amaxb[b] = __float_as_uint(a);               // non-negative floats order like their bit patterns
         }
-        uint32_t wmax[BAMD_ACT_BATCH];
+        uint32_t t[BAMD_ACT_BATCH], wmax[BAMD_ACT_BATCH];
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) wmax[b] = wave_max_u32(amaxb[b]);
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(amaxb[b], (uint32_t) dpp_z<DPP_XOR1>((int) amaxb[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_XOR2>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_MIRROR>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x142, 0xa, 0xf, false));   // row_bcast:15
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x143, 0xc, 0xf, false));   // row_bcast:31
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) wmax[b] = (uint32_t) __builtin_amdgcn_readlane((int) t[b], 63);
+        // the scale comes from the FIRST element of largest magnitude (strict > scan of the reference): lowest lane, lowest element
+        float mine[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const float M = __uint_as_float(wmax[b]);
+            const bool ex = fabsf(v[b].x) == M, ey = fabsf(v[b].y) == M, ez = fabsf(v[b].z) == M;
+            float m = v[b].w;                            // branch-free selects, lowest element wins
+            m = ez ? v[b].z : m; m = ey ? v[b].y : m; m = ex ? v[b].x : m;
+            mine[b] = m;
+        }
+        int mxv = __float_as_int(1.0f);
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const unsigned long long who = __ballot(amaxb[b] == wmax[b]);
+            const int first = __ffsll((long long) who) - 1;
+            const int mxb = __builtin_amdgcn_readlane(__float_as_int(mine[b]), first);
+            mxv = lane == b ? mxb : mxv;
+        }
+        const float isc = -127.f / __int_as_float(mxv);  // lane b: block b (other lanes: -127)
+        const float dd = 1.0f / isc;
 #pragma unroll
         for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
             const int i = i0 + b * nwaves;
             if (i < nb) {                                // wave-uniform
-                uint32_t packed = 0; int s4 = 0; float d = 0.f;
-                if (wmax[b] != 0u) {
-                    const unsigned long long who = __ballot(amaxb[b] == wmax[b]);
-                    const int first = __ffsll((long long) who) - 1;
-                    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mxl[b]), first));
-                    const float iscale = -127.f / mx;
-                    int q0 = nearest_int(iscale * v[b].x), q1 = nearest_int(iscale * v[b].y), q2 = nearest_int(iscale * v[b].z), q3 = nearest_int(iscale * v[b].w);
-                    q0 = q0 < 127 ? q0 : 127; q1 = q1 < 127 ? q1 : 127; q2 = q2 < 127 ? q2 : 127; q3 = q3 < 127 ? q3 : 127;
-                    packed = (uint32_t) (q0 & 0xff) | ((uint32_t) (q1 & 0xff) << 8) | ((uint32_t) (q2 & 0xff) << 16) | ((uint32_t) (q3 & 0xff) << 24);
-                    s4 = group8_sum(q0 + q1 + q2 + q3);
-                    d = 1.0f / iscale;
-                }
+                const float iscale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isc), b));
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dd), b));
+                const bool nz = wmax[b] != 0u;           // all-zero block: q = 0, d = 0 (ggml-quants.c:3607-3612)
+                const float t0 = iscale * v[b].x + 12582912.f, t1 = iscale * v[b].y + 12582912.f;
+                const float t2 = iscale * v[b].z + 12582912.f, t3 = iscale * v[b].w + 12582912.f;
+                const uint32_t p01 = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x0c0c0400u);
+                const uint32_t p23 = __builtin_amdgcn_perm(__float_as_uint(t3), __float_as_uint(t2), 0x0c0c0400u);
+                uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                packed = nz ? packed : 0u;
+                const int s4 = group8_sum(sdot4(packed, 0x01010101u));
                 q8[i * 64 + (lane & 7) * 8 + (lane >> 3)] = packed;
                 if ((lane & 7) == 0) S[i * 8 + (lane >> 3)] = s4;
-                if (lane == 0) yd[i] = d;
+                if (lane == 0) yd[i] = nz ? d : 0.f;
             }
         }
     }
@@ -346,7 +379,7 @@ __device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane,
     const int sh = (l & 1) * 16;
     const int ma = (int) ((mw >> sh) & 0xffu), mb = (int) ((mw >> (sh + 8)) & 0xffu);
     const int2 sp = *(const int2 *) (S + ci * 8 + 2 * l);
-    T.pm = (float) (ma * sp.x + mb * sp.y);
+    T.pm = (float) (mul24(ma, sp.x) + mul24(mb, sp.y));  // 6-bit min x sum of 32 int8
     return T;
 }
 
@@ -369,8 +402,7 @@ __device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane,
     T.fs = (float) sumi;
     // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
     const uint32_t mw = (e < 4) ? mn03 : mn47;
-    int hs = (int) ((mw >> (8 * (e & 3))) & 0xffu) * S[ci * 8 + e];
-    hs += __shfl_xor(hs, 1); hs += __shfl_xor(hs, 2); hs += __shfl_xor(hs, 4);
+    const int hs = group8_sum(mul24((int) ((mw >> (8 * (e & 3))) & 0xffu), S[ci * 8 + e]));
     T.pm = (float) hs;
     return T;
 }
