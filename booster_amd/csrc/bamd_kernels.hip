@@ -144,6 +144,8 @@ __device__ __forceinline__ double wave_sum_f64(double s) {                  // f
 // consecutive elements 4l..4l+3 of a block.  quantize_row_q8_K_ref semantics (ggml-quants.c:3593-3630): the scale comes
 // from the FIRST element of largest magnitude (strict > scan), so ties resolve to the lowest lane, lowest element.
 #define BAMD_ACT_BATCH 4
+// LDS layout of the quantised activations of one mat-vec: q8[nb][64] u32 | S[nb][8] i32 | yd[nb] f32 | (16-byte aligned) red[16] f64
+#define BAMD_ACT_RED_OFF(nb) ((((size_t) (nb) * (256 + 32 + 4)) + 15) & ~(size_t) 15)
 template <bool NORM>
 struct ActPro {
     float4 v[BAMD_ACT_BATCH], w[BAMD_ACT_BATCH];
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(512) quantize_q8k_test_kernel(const float * x,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nb = K >> 8;
     uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
-    double * red = (double *) (((uintptr_t) (yd + nb) + 15) & ~(uintptr_t) 15);
+    double * red = (double *) (smem + BAMD_ACT_RED_OFF(nb));
     if (norm) { ActPro<true> ap; ap.issue(x, nw, K, wave_id()); ap.finish(x, nw, eps, K, q8, S, yd, red); }
     else { ActPro<false> ap; ap.issue(x, nw, K, wave_id()); ap.finish(x, nw, eps, K, q8, S, yd, red); }
     for (int i = threadIdx.x; i < nb * 64; i += blockDim.x) {
@@ -513,46 +515,48 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
     constexpr int NPARTS = PAIR ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const int total = count * nb * NPARTS;               // D divides nb (chosen by the dispatcher below)
-    const long rgb = (long) nb * RECB;
+    const long rgb = (long) nb * RECB;                   // D divides nb (chosen by the dispatcher below)
     const long rg_step = (long) stride * rgb;
-    int lt = 0, li = 0, lpart = 0;                       // loader cursor (wave-uniform scalars)
-    long loff = (long) first * rgb;
+    const int chunks = nb / D;
     ActPro<PRO == BAMD_PRO_NORM> ap;
     if (do_pro) BAMD_PRO_ISSUE(ap, pa);                  // activation loads go out FIRST (see ActPro::issue)
     REC ring[D];
-#define BAMD_LOAD_NEXT(slot) do { \
-        const uint8_t * base_ = (PAIR && lpart) ? wB : wA; \
-        load_rec(ring[slot], base_ + loff + (long) li * RECB, lane); \
-        ++lt; \
-        const bool adv_ = lt < total; const int li1_ = li + 1; const bool wrap_ = li1_ == nb; \
-        li = adv_ ? (wrap_ ? 0 : li1_) : li; \
-        const bool nrg_ = adv_ && wrap_ && (!PAIR || lpart == 1); \
-        if (PAIR) lpart = (adv_ && wrap_) ? (lpart ^ 1) : lpart; \
-        loff = nrg_ ? loff + rg_step : loff; \
-    } while (0)
+    // The loader runs exactly one CHUNK (D records = the whole ring) ahead of the consumer: slot s is refilled, right after it
+    // is consumed, with record s of the chunk that follows in this wave's sequence (next chunk of the row, else the other half
+    // of a gate/up pair, else the next row-group).  One wave-uniform base address per chunk: the per-record cost of the cursor
+    // is a constant offset, and the loads stay unconditional so the compiler keeps counted s_waitcnt vmcnt(N) waits.
+    const uint8_t * rowA = wA + (long) first * rgb;
 #pragma unroll
-    for (int s = 0; s < D; ++s) BAMD_LOAD_NEXT(s);
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * RECB, lane);
     if (do_pro) BAMD_PRO_FINISH(ap, pa);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
-    const int chunks = nb / D;
     for (int r = 0; r < count; ++r) {
         const int rg = first + r * stride;
         const int row = rg * 8 + (lane >> 3);
+        const long rowoff = (long) rg * rgb;
         float gate_val = 0.f;
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) {
+            const uint8_t * pbase = (part ? wB : wA) + rowoff;
+            // after the last chunk of this row-part: the other half of the pair, the next row-group, or — at the very end of the
+            // wave's stream — its own last record again, D times (step 0: one record of redundant traffic, never consumed; the
+            // requests stay unconditional so that the waits stay counted)
+            const bool last = !(PAIR && part == 0) && r + 1 >= count;
+            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
             // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
             float resv = 0.f;
             if (EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
             RowAcc A = { 0.f, 0.f };
             for (int c = 0; c < chunks; ++c) {
+                const bool inrow = c + 1 < chunks;
+                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const int step = (inrow || !last) ? RECB : 0;
 #pragma unroll
                 for (int s = 0; s < D; ++s) {
                     pin_rec(ring[s]);
                     const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
                     chain_step<TYPE>(A, T.d, T.fs, T.dmin, T.pm);
-                    BAMD_LOAD_NEXT(s);               // refill; at the very end the cursor stays on the last record
+                    load_rec(ring[s], nxt + s * step, lane);
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1)
                         __builtin_amdgcn_sched_barrier(0);   // keep hipcc from clustering the refills at the loop tail
                 }
@@ -569,7 +573,6 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             }
         }
     }
-#undef BAMD_LOAD_NEXT
 }
 
 template <int TYPE, typename REC, int EPI, int PRO>
@@ -587,7 +590,8 @@ __device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned ch
     ProArgs pa;
     pa.x = a.x; pa.nw = a.normw; pa.eps = a.eps; pa.K = a.K;
     pa.q8 = (uint32_t *) smem; pa.S = (int *) (pa.q8 + nb * 64); pa.yd = (float *) (pa.S + nb * 8);
-    pa.red = (double *) (((uintptr_t) (pa.yd + nb) + 15) & ~(uintptr_t) 15);
+    pa.red = (double *) (smem + BAMD_ACT_RED_OFF(nb));     // byte offsets, never a pointer->integer->pointer round trip: that loses
+                                                           // the LDS address space and turns every access into a FLAT instruction
     return pa;
 }
 
@@ -754,7 +758,7 @@ __global__ void __launch_bounds__(512) matvec_split_kernel(bamd_mv_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nb = a.K >> 8;
     const ProArgs pa = carve_lds(a, smem);
-    float * part0 = (float *) (((uintptr_t) (pa.red + 16) + 15) & ~(uintptr_t) 15);
+    float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double));
     int rgctr = 0;
     bool pro_done = false;
     int off = 0;
