@@ -651,10 +651,10 @@ __global__ void __launch_bounds__(512) matvec_kernel(bamd_mv_args a) {
 // after a workgroup barrier ONE wave replays the reference's sequential f32 chain over all nb blocks in order.
 // Same arithmetic, same order, 8x the parallelism.  Term buffers are double-buffered so the chain of row-group n
 // overlaps the streaming of row-group n+1; the prefetch ring spans row-group boundaries (M row-groups per body).
-// LDS term buffers: 2 (double buffer) x M (row-groups per batch) x { fs[nb][64], dd[nb][8], dm[nb][8], pm[nb][32] } floats
-#define BAMD_TERM_FLOATS(nb) ((size_t) (nb) * (64 + 8 + 8 + 32))
+// LDS term buffers: 2 (double buffer) x M (row-groups per batch) x nb x 64 lanes x float4 {d, fs, dmin, pm}
+#define BAMD_TERM_FLOATS(nb) ((size_t) (nb) * 256)      /* one float4 {d, fs, dmin, pm} per lane per super-block */
 
-template <int TYPE, typename REC, int NBW, int M, int EPI, int PRO>
+template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO>
 __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa, bool do_pro,
                                              float * part0, int & batchctr, int nvalid) {
@@ -664,31 +664,29 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     const int r8 = lane >> 3, l4 = lane & 3;
     const long rgb = (long) nb * RECB;
     const long rg_step = (long) stride * rgb;
-    const int total = count * NBW;
     const int i0 = wave * NBW;                               // this wave's first super-block inside a row
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
     ActPro<PRO == BAMD_PRO_NORM> ap;
     if (do_pro) BAMD_PRO_ISSUE(ap, pa);                      // activation loads go out FIRST
-    int lt = 0, li = 0;
-    long loff = (long) first * rgb + (long) i0 * RECB;
+    // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
+    // r0+M+m, i.e. a constant M*rg_step further on: the loader needs one wave-uniform base per batch and nothing per record
+    const uint8_t * bbase = w + (long) first * rgb + (long) i0 * RECB;
     REC ring[D];
-#define BAMD_LOAD_NEXT(slot) do { \
-        load_rec(ring[slot], w + loff + (long) li * RECB, lane); \
-        ++lt; \
-        const bool adv_ = lt < total; const int li1_ = li + 1; const bool wrap_ = li1_ == NBW; \
-        li = adv_ ? (wrap_ ? 0 : li1_) : li; \
-        loff = (adv_ && wrap_) ? loff + rg_step : loff; \
-    } while (0)
     STAMP(0);
 #pragma unroll
-    for (int s = 0; s < D; ++s) { if (s < total) BAMD_LOAD_NEXT(s); }     // no redundant requests when the stream is short
+    for (int m = 0; m < M; ++m) {
+        if (m < count) {                                     // no redundant requests when the stream is short
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], bbase + (long) m * rg_step + j * RECB, lane);
+        }
+    }
     STAMP(1);
     if (do_pro) BAMD_PRO_FINISH(ap, pa);
     STAMP(2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     for (int r0 = 0; r0 < count; r0 += M) {
         const int nbatch = count - r0 < M ? count - r0 : M;  // workgroup-uniform
-        float * B0 = part0 + (size_t) (batchctr & 1) * M * rg_floats;
+        float * B0 = part0 + (NBUF == 2 ? (size_t) (batchctr & 1) * M * rg_floats : (size_t) 0);
         // the wave that will run the chain of row-group r0+wave fetches its residual now (old by chain time)
         const int crow = (first + (r0 + (wave < nbatch ? wave : 0)) * stride) * 8 + r8;
         float resv = 0.f;
@@ -696,19 +694,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             if (m < nbatch) {
-                float * P = B0 + (size_t) m * rg_floats;
-                float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
+                float4 * P = (float4 *) (B0 + (size_t) m * rg_floats);
 #pragma unroll
                 for (int j = 0; j < NBW; ++j) {
                     const int s = m * NBW + j;
                     const int ci = i0 + j;
                     pin_rec(ring[s]);
                     const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
-                    fs[ci * 64 + lane] = T.fs;
-                    if ((lane & 7) == 0) { dd[ci * 8 + r8] = T.d; if (TYPE != BAMD_Q6_K) dm[ci * 8 + r8] = T.dmin; }
-                    if (TYPE == BAMD_Q4_K && (lane & 7) < 4) pm[ci * 32 + r8 * 4 + l4] = T.pm;
-                    if (TYPE == BAMD_Q5_K && (lane & 7) == 0) pm[ci * 32 + r8 * 4] = T.pm;
-                    if (lt < total) BAMD_LOAD_NEXT(s);
+                    P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
+                    if (r0 + M + m < count) load_rec(ring[s], bbase + (long) (M + m) * rg_step + j * RECB, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -718,37 +712,36 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         STAMP(4);
         if (wave < nbatch) {
             // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
-            const float * P = B0 + (size_t) wave * rg_floats;
-            const float * fs = P, * dd = P + (size_t) nb * 64, * dm = dd + (size_t) nb * 8, * pm = dm + (size_t) nb * 8;
+            const float4 * P = (const float4 *) (B0 + (size_t) wave * rg_floats);
             RowAcc A = { 0.f, 0.f };
-            for (int i = 0; i < nb; i += 8) {                // nb % 8 == 0 here; LDS reads of 8 blocks issued together
-                float dv[8], fv[8], mv[8], pv[8];
+            for (int i = 0; i < nb; i += 8) {                // nb % 8 == 0 here; the 16-byte LDS reads of 8 blocks issued together
+                float4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    dv[u] = dd[(i + u) * 8 + r8]; fv[u] = fs[(i + u) * 64 + lane]; mv[u] = 0.f; pv[u] = 0.f;
-                    if (TYPE == BAMD_Q4_K) { mv[u] = dm[(i + u) * 8 + r8]; pv[u] = pm[(i + u) * 32 + r8 * 4 + l4]; }
-                    if (TYPE == BAMD_Q5_K) { mv[u] = dm[(i + u) * 8 + r8]; pv[u] = pm[(i + u) * 32 + r8 * 4]; }
-                }
+                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dv[u], fv[u], mv[u], pv[u]);
+                for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
             }
             const float val = finish_row<TYPE>(A);
             if ((lane & 7) == 0 && crow < nvalid) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
             STAMP(5);
         }
         batchctr += 1;
+        bbase += (long) M * rg_step;
+        if (NBUF == 1 && r0 + M < count) __syncthreads();    // single term buffer: the chains must be done before the next batch writes
     }
-#undef BAMD_LOAD_NEXT
 }
 
 template <int TYPE, typename REC, int EPI, int PRO>
 __device__ __forceinline__ void split_dispatch(const uint8_t * w, int nb, int first, int count, int stride, float * out, const float * res,
                                                const ProArgs & pa, bool do_pro, float * part0, int & rgctr, int nvalid) {
     const int nbw = nb >> 3;
-    if (nbw == 2)       split_stream<TYPE, REC, 2, 4, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
-    else if (nbw == 7)  split_stream<TYPE, REC, 7, 1, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
-    else if (nbw == 4)  split_stream<TYPE, REC, 4, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
-    else if (nbw == 1)  split_stream<TYPE, REC, 1, 8, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    // (records per wave per row-group, row-groups per batch, term buffers): the batch is the prefetch depth.  K = 14336 with M = 2
+    // (all of ffn_down's work per workgroup in flight from the first instruction, single-buffered) measured no better for Q4_K and
+    // 14 % worse for Q6_K than M = 1: the kernel is instruction-issue bound, not latency bound.
+    if (nbw == 2)       split_stream<TYPE, REC, 2, 4, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 7)  split_stream<TYPE, REC, 7, 1, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 4)  split_stream<TYPE, REC, 4, 2, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
+    else if (nbw == 1)  split_stream<TYPE, REC, 1, 8, 2, EPI, PRO>(w, nb, first, count, stride, out, res, pa, do_pro, part0, rgctr, nvalid);
     else __builtin_trap();                               // the launcher only picks this kernel for the shapes above
 }
 
@@ -1228,8 +1221,8 @@ template <int PRO>
 static void launch_mv_split(const bamd_mv_args & a, int epi, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const int nbw = nb >> 3;
-    const int M = nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8;          // must match split_dispatch
-    const size_t lds = act_lds_bytes(a.K) + 16 + 2 * (size_t) M * nb * (64 + 8 + 8 + 32) * 4;
+    const int M = nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8, NBUF = 2;                  // must match split_dispatch
+    const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) NBUF * M * nb * 256 * 4;   // 112..128 KiB of term buffers
     if (epi == BAMD_EPI_ADD) hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_ADD>),   dim3(grid), dim3(512), lds, s, a);
     else                     hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_STORE>), dim3(grid), dim3(512), lds, s, a);
 }
