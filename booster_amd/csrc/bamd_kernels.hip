@@ -56,6 +56,24 @@ __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) {
     return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false);
 #endif
 }
+// Eight independent 4 x int8 dot products with a zero accumulator.  hipcc selects v_dot4c (accumulate-into-destination) for
+// __builtin_amdgcn_sdot4(a, b, 0) and spends a v_mov 0 per product; the VOP3P form takes the zero as an inline constant.  The
+// block ends with the wait states a DOT result needs before another VALU instruction may read it (the compiler does not look
+// inside an asm statement).  Verified against the builtin by tools/dot4_probe.cpp.
+__device__ __forceinline__ void sdot4x8(int (&d)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+    asm("v_dot4_i32_i8 %0, %8, %16, 0\n\t"
+        "v_dot4_i32_i8 %1, %9, %17, 0\n\t"
+        "v_dot4_i32_i8 %2, %10, %18, 0\n\t"
+        "v_dot4_i32_i8 %3, %11, %19, 0\n\t"
+        "v_dot4_i32_i8 %4, %12, %20, 0\n\t"
+        "v_dot4_i32_i8 %5, %13, %21, 0\n\t"
+        "v_dot4_i32_i8 %6, %14, %22, 0\n\t"
+        "v_dot4_i32_i8 %7, %15, %23, 0\n\t"
+        "s_nop 2"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
 // scale (<= 8 bits) x block dot (<= 15 bits): full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
@@ -371,11 +389,15 @@ __device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane,
     T.dmin = (-ydv) * h2f(R.hd.x >> 16);
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+    const uint32_t wq[8] = { R.qs.x & 0x0f0f0f0fu, (R.qs.x >> 4) & 0x0f0f0f0fu, R.qs.y & 0x0f0f0f0fu, (R.qs.y >> 4) & 0x0f0f0f0fu,
+                             R.qs.z & 0x0f0f0f0fu, (R.qs.z >> 4) & 0x0f0f0f0fu, R.qs.w & 0x0f0f0f0fu, (R.qs.w >> 4) & 0x0f0f0f0fu };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    int dj[8]; sdot4x8(dj, wq, aq);
     int sumi = 0;
-    sumi += mul24(BYTE(sc03, 0), sdot4(R.qs.x & 0x0f0f0f0fu, a0.x)) + mul24(BYTE(sc03, 1), sdot4((R.qs.x >> 4) & 0x0f0f0f0fu, a0.y));
-    sumi += mul24(BYTE(sc03, 2), sdot4(R.qs.y & 0x0f0f0f0fu, a0.z)) + mul24(BYTE(sc03, 3), sdot4((R.qs.y >> 4) & 0x0f0f0f0fu, a0.w));
-    sumi += mul24(BYTE(sc47, 0), sdot4(R.qs.z & 0x0f0f0f0fu, a1.x)) + mul24(BYTE(sc47, 1), sdot4((R.qs.z >> 4) & 0x0f0f0f0fu, a1.y));
-    sumi += mul24(BYTE(sc47, 2), sdot4(R.qs.w & 0x0f0f0f0fu, a1.z)) + mul24(BYTE(sc47, 3), sdot4((R.qs.w >> 4) & 0x0f0f0f0fu, a1.w));
+    sumi += mul24(BYTE(sc03, 0), dj[0]) + mul24(BYTE(sc03, 1), dj[1]);
+    sumi += mul24(BYTE(sc03, 2), dj[2]) + mul24(BYTE(sc03, 3), dj[3]);
+    sumi += mul24(BYTE(sc47, 0), dj[4]) + mul24(BYTE(sc47, 1), dj[5]);
+    sumi += mul24(BYTE(sc47, 2), dj[6]) + mul24(BYTE(sc47, 3), dj[7]);
     T.fs = (float) sumi;
     const uint32_t mw = (l < 2) ? mn03 : mn47;
     const int sh = (l & 1) * 16;
@@ -395,11 +417,14 @@ __device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane,
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     const uint32_t qh = R.qh;
 #define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))
+    const uint32_t wq[8] = { Q5(R.qs.x, 0, 0), Q5(R.qs.x, 4, 1), Q5(R.qs.y, 0, 2), Q5(R.qs.y, 4, 3), Q5(R.qs.z, 0, 4), Q5(R.qs.z, 4, 5), Q5(R.qs.w, 0, 6), Q5(R.qs.w, 4, 7) };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    int dj[8]; sdot4x8(dj, wq, aq);
     int sumi = 0;
-    sumi += mul24(BYTE(sc03, 0), sdot4(Q5(R.qs.x, 0, 0), a0.x)) + mul24(BYTE(sc03, 1), sdot4(Q5(R.qs.x, 4, 1), a0.y));
-    sumi += mul24(BYTE(sc03, 2), sdot4(Q5(R.qs.y, 0, 2), a0.z)) + mul24(BYTE(sc03, 3), sdot4(Q5(R.qs.y, 4, 3), a0.w));
-    sumi += mul24(BYTE(sc47, 0), sdot4(Q5(R.qs.z, 0, 4), a1.x)) + mul24(BYTE(sc47, 1), sdot4(Q5(R.qs.z, 4, 5), a1.y));
-    sumi += mul24(BYTE(sc47, 2), sdot4(Q5(R.qs.w, 0, 6), a1.z)) + mul24(BYTE(sc47, 3), sdot4(Q5(R.qs.w, 4, 7), a1.w));
+    sumi += mul24(BYTE(sc03, 0), dj[0]) + mul24(BYTE(sc03, 1), dj[1]);
+    sumi += mul24(BYTE(sc03, 2), dj[2]) + mul24(BYTE(sc03, 3), dj[3]);
+    sumi += mul24(BYTE(sc47, 0), dj[4]) + mul24(BYTE(sc47, 1), dj[5]);
+    sumi += mul24(BYTE(sc47, 2), dj[6]) + mul24(BYTE(sc47, 3), dj[7]);
 #undef Q5
     T.fs = (float) sumi;
     // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
@@ -419,21 +444,18 @@ __device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane,
     // (q6 - 32) as int8: q6 in [0,63] -> (q6 + 0x60) ^ 0x80 per byte, no inter-byte carry
 #define Q6(lo, hb) ((((lo) | ((hb) << 4)) + 0x60606060u) ^ 0x80808080u)
 #define SB(w, k) ((int) (int8_t) ((w) >> (8 * (k))))
+    const uint32_t A0 = R.ql.x, B0 = R.ql.y, h0 = R.qh.x, A1 = R.ql.z, B1 = R.ql.w, h1 = R.qh.y;
+    const uint32_t wq[8] = { Q6(A0 & 0x0f0f0f0fu, h0 & 0x03030303u), Q6(B0 & 0x0f0f0f0fu, (h0 >> 2) & 0x03030303u),
+                             Q6((A0 >> 4) & 0x0f0f0f0fu, (h0 >> 4) & 0x03030303u), Q6((B0 >> 4) & 0x0f0f0f0fu, (h0 >> 6) & 0x03030303u),
+                             Q6(A1 & 0x0f0f0f0fu, h1 & 0x03030303u), Q6(B1 & 0x0f0f0f0fu, (h1 >> 2) & 0x03030303u),
+                             Q6((A1 >> 4) & 0x0f0f0f0fu, (h1 >> 4) & 0x03030303u), Q6((B1 >> 4) & 0x0f0f0f0fu, (h1 >> 6) & 0x03030303u) };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    int dj[8]; sdot4x8(dj, wq, aq);
     int sumi = 0;
-    {
-        const uint32_t A_ = R.ql.x, B_ = R.ql.y, h = R.qh.x, s = R.sc.x;
-        sumi += mul24(SB(s, 0), sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a0.x));
-        sumi += mul24(SB(s, 1), sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a0.y));
-        sumi += mul24(SB(s, 2), sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a0.z));
-        sumi += mul24(SB(s, 3), sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a0.w));
-    }
-    {
-        const uint32_t A_ = R.ql.z, B_ = R.ql.w, h = R.qh.y, s = R.sc.y;
-        sumi += mul24(SB(s, 0), sdot4(Q6(A_ & 0x0f0f0f0fu, h & 0x03030303u), a1.x));
-        sumi += mul24(SB(s, 1), sdot4(Q6(B_ & 0x0f0f0f0fu, (h >> 2) & 0x03030303u), a1.y));
-        sumi += mul24(SB(s, 2), sdot4(Q6((A_ >> 4) & 0x0f0f0f0fu, (h >> 4) & 0x03030303u), a1.z));
-        sumi += mul24(SB(s, 3), sdot4(Q6((B_ >> 4) & 0x0f0f0f0fu, (h >> 6) & 0x03030303u), a1.w));
-    }
+    sumi += mul24(SB(R.sc.x, 0), dj[0]) + mul24(SB(R.sc.x, 1), dj[1]);
+    sumi += mul24(SB(R.sc.x, 2), dj[2]) + mul24(SB(R.sc.x, 3), dj[3]);
+    sumi += mul24(SB(R.sc.y, 0), dj[4]) + mul24(SB(R.sc.y, 1), dj[5]);
+    sumi += mul24(SB(R.sc.y, 2), dj[6]) + mul24(SB(R.sc.y, 3), dj[7]);
 #undef Q6
 #undef SB
     T.fs = (float) sumi;
