@@ -74,6 +74,36 @@ __device__ __forceinline__ void sdot4x8(int (&d)[8], const uint32_t (&a)[8], con
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
           "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
 }
+// sum_j scale_j * dot4(w_j, a_j) over the 8 sub-blocks a lane covers in one super-block: the 8 scale bytes are the bytes of (s0, s1),
+// unsigned (Q4_K/Q5_K 6-bit scales) or signed (Q6_K int8 scales).  One asm block: 8 VOP3P dots, 8 SDWA multiplies that pick their
+// scale byte directly (no extraction instructions), 4 adds.  Every product is >= 8 instructions behind its dot: no wait states needed.
+// Exact integer arithmetic: any association gives the reference's int32 (ggml-quants.c:6950-6968, :8190-8216).
+template <bool SIGNED>
+__device__ __forceinline__ int dotscale8(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t s0, uint32_t s1) {
+    int t0, t1, t2, t3, t4, t5, t6, t7, sum;
+#define BAMD_SDWA_MUL(k, sreg, byte) "v_mul_i32_i24_sdwa %" #k ", %" #k ", " sreg " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #byte "\n\t"
+    if (SIGNED) {
+        asm("v_dot4_i32_i8 %0, %9, %17, 0\n\t" "v_dot4_i32_i8 %1, %10, %18, 0\n\t" "v_dot4_i32_i8 %2, %11, %19, 0\n\t" "v_dot4_i32_i8 %3, %12, %20, 0\n\t"
+            "v_dot4_i32_i8 %4, %13, %21, 0\n\t" "v_dot4_i32_i8 %5, %14, %22, 0\n\t" "v_dot4_i32_i8 %6, %15, %23, 0\n\t" "v_dot4_i32_i8 %7, %16, %24, 0\n\t"
+            BAMD_SDWA_MUL(0, "sext(%25)", 0) BAMD_SDWA_MUL(1, "sext(%25)", 1) BAMD_SDWA_MUL(2, "sext(%25)", 2) BAMD_SDWA_MUL(3, "sext(%25)", 3)
+            BAMD_SDWA_MUL(4, "sext(%26)", 0) BAMD_SDWA_MUL(5, "sext(%26)", 1) BAMD_SDWA_MUL(6, "sext(%26)", 2) BAMD_SDWA_MUL(7, "sext(%26)", 3)
+            "v_add3_u32 %8, %0, %1, %2\n\t" "v_add3_u32 %8, %8, %3, %4\n\t" "v_add3_u32 %8, %8, %5, %6\n\t" "v_add_u32 %8, %8, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(sum)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+              "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(s0), "v"(s1));
+    } else {
+        asm("v_dot4_i32_i8 %0, %9, %17, 0\n\t" "v_dot4_i32_i8 %1, %10, %18, 0\n\t" "v_dot4_i32_i8 %2, %11, %19, 0\n\t" "v_dot4_i32_i8 %3, %12, %20, 0\n\t"
+            "v_dot4_i32_i8 %4, %13, %21, 0\n\t" "v_dot4_i32_i8 %5, %14, %22, 0\n\t" "v_dot4_i32_i8 %6, %15, %23, 0\n\t" "v_dot4_i32_i8 %7, %16, %24, 0\n\t"
+            BAMD_SDWA_MUL(0, "%25", 0) BAMD_SDWA_MUL(1, "%25", 1) BAMD_SDWA_MUL(2, "%25", 2) BAMD_SDWA_MUL(3, "%25", 3)
+            BAMD_SDWA_MUL(4, "%26", 0) BAMD_SDWA_MUL(5, "%26", 1) BAMD_SDWA_MUL(6, "%26", 2) BAMD_SDWA_MUL(7, "%26", 3)
+            "v_add3_u32 %8, %0, %1, %2\n\t" "v_add3_u32 %8, %8, %3, %4\n\t" "v_add3_u32 %8, %8, %5, %6\n\t" "v_add_u32 %8, %8, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(sum)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+              "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(s0), "v"(s1));
+    }
+#undef BAMD_SDWA_MUL
+    return sum;
+}
 // scale (<= 8 bits) x block dot (<= 15 bits): full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
@@ -392,12 +422,7 @@ __device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane,
     const uint32_t wq[8] = { R.qs.x & 0x0f0f0f0fu, (R.qs.x >> 4) & 0x0f0f0f0fu, R.qs.y & 0x0f0f0f0fu, (R.qs.y >> 4) & 0x0f0f0f0fu,
                              R.qs.z & 0x0f0f0f0fu, (R.qs.z >> 4) & 0x0f0f0f0fu, R.qs.w & 0x0f0f0f0fu, (R.qs.w >> 4) & 0x0f0f0f0fu };
     const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-    int dj[8]; sdot4x8(dj, wq, aq);
-    int sumi = 0;
-    sumi += mul24(BYTE(sc03, 0), dj[0]) + mul24(BYTE(sc03, 1), dj[1]);
-    sumi += mul24(BYTE(sc03, 2), dj[2]) + mul24(BYTE(sc03, 3), dj[3]);
-    sumi += mul24(BYTE(sc47, 0), dj[4]) + mul24(BYTE(sc47, 1), dj[5]);
-    sumi += mul24(BYTE(sc47, 2), dj[6]) + mul24(BYTE(sc47, 3), dj[7]);
+    const int sumi = dotscale8<false>(wq, aq, sc03, sc47);
     T.fs = (float) sumi;
     const uint32_t mw = (l < 2) ? mn03 : mn47;
     const int sh = (l & 1) * 16;
@@ -419,12 +444,7 @@ __device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane,
 #define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))
     const uint32_t wq[8] = { Q5(R.qs.x, 0, 0), Q5(R.qs.x, 4, 1), Q5(R.qs.y, 0, 2), Q5(R.qs.y, 4, 3), Q5(R.qs.z, 0, 4), Q5(R.qs.z, 4, 5), Q5(R.qs.w, 0, 6), Q5(R.qs.w, 4, 7) };
     const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-    int dj[8]; sdot4x8(dj, wq, aq);
-    int sumi = 0;
-    sumi += mul24(BYTE(sc03, 0), dj[0]) + mul24(BYTE(sc03, 1), dj[1]);
-    sumi += mul24(BYTE(sc03, 2), dj[2]) + mul24(BYTE(sc03, 3), dj[3]);
-    sumi += mul24(BYTE(sc47, 0), dj[4]) + mul24(BYTE(sc47, 1), dj[5]);
-    sumi += mul24(BYTE(sc47, 2), dj[6]) + mul24(BYTE(sc47, 3), dj[7]);
+    const int sumi = dotscale8<false>(wq, aq, sc03, sc47);
 #undef Q5
     T.fs = (float) sumi;
     // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
@@ -450,12 +470,7 @@ __device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane,
                              Q6(A1 & 0x0f0f0f0fu, h1 & 0x03030303u), Q6(B1 & 0x0f0f0f0fu, (h1 >> 2) & 0x03030303u),
                              Q6((A1 >> 4) & 0x0f0f0f0fu, (h1 >> 4) & 0x03030303u), Q6((B1 >> 4) & 0x0f0f0f0fu, (h1 >> 6) & 0x03030303u) };
     const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-    int dj[8]; sdot4x8(dj, wq, aq);
-    int sumi = 0;
-    sumi += mul24(SB(R.sc.x, 0), dj[0]) + mul24(SB(R.sc.x, 1), dj[1]);
-    sumi += mul24(SB(R.sc.x, 2), dj[2]) + mul24(SB(R.sc.x, 3), dj[3]);
-    sumi += mul24(SB(R.sc.y, 0), dj[4]) + mul24(SB(R.sc.y, 1), dj[5]);
-    sumi += mul24(SB(R.sc.y, 2), dj[6]) + mul24(SB(R.sc.y, 3), dj[7]);
+    const int sumi = dotscale8<true>(wq, aq, R.sc.x, R.sc.y);
 #undef Q6
 #undef SB
     T.fs = (float) sumi;
