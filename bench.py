@@ -163,8 +163,9 @@ def main():
                                  "128-token prompt, n_ctx 512, n_kv %d..%d" % (N_PROMPT + warmup, n_past),
                         parallelism="single GPU", graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
-                        time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps, 4), other=round(MS_[2] / reps, 4)),
-                        launches_per_token=int(L_[0] / reps + 3 * L_[1] / reps + L_[2] / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
+                        time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
+                                                     other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
+                        launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                           traffic=traffic, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
