@@ -52,6 +52,7 @@ def lib():
         L.bamd_stage_token_to.argtypes = [vp, vp, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
+        L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
         L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp, ci]
@@ -70,6 +71,11 @@ def _chk(rc):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_prefill_batch(on):
+    """True (default): prompts of 2..512 tokens go through the batched prefill kernels; False: token by token (same bits)."""
+    lib().bamd_set_prefill_batch(1 if on else 0)
 
 
 def device_count():

@@ -21,6 +21,8 @@
 #include <vector>
 
 static thread_local std::string g_err;
+// BAMD_PREFILL_BATCH=0: evaluate prompts token by token through the decode kernels instead of the batched kernels (same bits)
+static int g_prefill_batch = [] { const char * e = getenv("BAMD_PREFILL_BATCH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
@@ -109,6 +111,9 @@ struct bamd_context {
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr;
+    // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
+    int bcap = 0;
+    float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -412,6 +417,71 @@ static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_ke
     return 0;
 }
 
+// ---- batched prefill: a micro-batch of T > 1 tokens through the layers at once (llama_decode with n_tokens > 1) -----------
+#define BAMD_PREFILL_CAP 512            /* the reference's default n_batch / n_ubatch */
+static bool prefill_batch_supported(const bamd_context * c) {
+    const bamd_model * m = c->m;
+    const int gq = m->H / m->Hkv;
+    return g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 2048 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8) &&
+           8 * bamd_blob_bytes(std::max(m->E, m->F)) <= 160 * 1024;
+}
+static int ensure_batch_buffers(bamd_context * c) {
+    if (c->bcap) return 0;
+    bamd_model * m = c->m;
+    const size_t T = BAMD_PREFILL_CAP, Ekv = (size_t) m->Hkv * m->hd;
+    if (dev_alloc(c->allocs, (void **) &c->bx, T * m->E * 4) || dev_alloc(c->allocs, (void **) &c->bx2, T * m->E * 4) ||
+        dev_alloc(c->allocs, (void **) &c->bqkv, T * (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->batt, T * m->E * 4) ||
+        dev_alloc(c->allocs, (void **) &c->bh, T * m->F * 4) || dev_alloc(c->allocs, (void **) &c->bblob, T * bamd_blob_bytes(std::max(m->E, m->F)))) return 1;
+    c->bcap = (int) T;
+    return 0;
+}
+// tokens already in c->forced; leaves the hidden state of the LAST token in c->x
+static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_t s) {
+    bamd_model * m = c->m;
+    const int E = m->E, F = m->F, Ekv = m->Hkv * m->hd, ldq = E + 2 * Ekv, gq = m->H / m->Hkv;
+    bamd_step_state h; memset(&h, 0, sizeof h);
+    h.pos_base = n_past; h.pos = n_past; h.n_ctx = c->n_ctx; h.step = T;
+    h.n_kv = std::min(c->n_ctx, (n_past + T + 31) / 32 * 32);
+    HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
+    bamd_launch_embed_batch(c->forced, T, m->tok_embd.raw, m->tok_embd.type, E, m->V, c->bx, s);
+    for (size_t il = 0; il < m->layers.size(); ++il) {
+        const DevLayer & ly = m->layers[il];
+        bamd_mm_args a; memset(&a, 0, sizeof a);
+        // q,k,v                                                            (llama.cpp:8810-8835)
+        bamd_launch_quantize_batch(c->bx, ly.attn_norm, m->eps, E, T, c->bblob, s);
+        seg_of(a.seg[0], ly.wq, c->bqkv); a.nseg = 1;
+        if (ly.wk.type == ly.wq.type) { a.seg[0].nrows += ly.wk.nrows; a.seg[0].nvalid += ly.wk.nrows; }
+        else { seg_of(a.seg[a.nseg], ly.wk, c->bqkv + E); a.nseg++; }
+        if (ly.wv.type == ly.wk.type) { a.seg[a.nseg - 1].nrows += ly.wv.nrows; a.seg[a.nseg - 1].nvalid += ly.wv.nrows; }
+        else { seg_of(a.seg[a.nseg], ly.wv, c->bqkv + E + Ekv); a.nseg++; }
+        a.blob = c->bblob; a.K = E; a.T = T; a.ldo = ldq;
+        if (bamd_launch_matmul_batch(a, BAMD_EPI_STORE, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        // RoPE, KV store, attention with the T>1 semantics                  (llama.cpp:8837-8849, :8318-8353)
+        bamd_attn_args t; memset(&t, 0, sizeof t);
+        t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
+        t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = 1;
+        t.batch = 1; t.ld_qkv = ldq; t.ld_out = E;
+        if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
+        // x2 = x + Wo . att
+        bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, s);
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wo, c->bx2); a.nseg = 1; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = E; a.res = c->bx;
+        if (bamd_launch_matmul_batch(a, BAMD_EPI_ADD, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        // h = silu(Wg . a) * (Wu . a)
+        bamd_launch_quantize_batch(c->bx2, ly.ffn_norm, m->eps, E, T, c->bblob, s);
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wg, c->bh); seg_of(a.seg[1], ly.wu, c->bh); a.nseg = 2; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = F;
+        if (bamd_launch_matmul_batch(a, BAMD_EPI_SILU_MUL, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        // x = x2 + Wd . h
+        bamd_launch_quantize_batch(c->bh, nullptr, 0.f, F, T, c->bblob, s);
+        memset(&a, 0, sizeof a);
+        seg_of(a.seg[0], ly.wd, c->bx); a.nseg = 1; a.blob = c->bblob; a.K = F; a.T = T; a.ldo = E; a.res = c->bx2;
+        if (bamd_launch_matmul_batch(a, BAMD_EPI_ADD, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+    }
+    HIPC(hipMemcpyAsync(c->x, c->bx + (size_t) (T - 1) * E, (size_t) E * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past) {
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) { fail("bamd_decode needs a stage that owns embedding and output"); return 1; }
@@ -420,18 +490,26 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
     hipStream_t s = c->stream;
     if (hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s) != hipSuccess) { fail("H2D tokens"); return 1; }
-    if (set_state(c, n_past, s, false)) return 1;
-    const int prefill_mode = n_tokens > 1;
-    for (int t = 0; t < n_tokens; ++t) {
-        enqueue_begin(c, n_tokens, 1, s);
-        if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
-        if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);       // n_outputs = 1: last token only (llama.cpp:14580-14593)
+    if (n_tokens > 1 && n_tokens <= BAMD_PREFILL_CAP && prefill_batch_supported(c)) {
+        // one micro-batch: every layer once for all tokens (each weight record unpacked once per 8 tokens), lm_head for the last
+        if (ensure_batch_buffers(c)) return 1;
+        if (enqueue_prefill_batch(c, n_tokens, n_past, s)) return 1;
+        enqueue_lm_head(c, s, nullptr);                                  // n_outputs = 1: last token only (llama.cpp:14580-14593)
+    } else {
+        if (set_state(c, n_past, s, false)) return 1;
+        const int prefill_mode = n_tokens > 1;
+        for (int t = 0; t < n_tokens; ++t) {
+            enqueue_begin(c, n_tokens, 1, s);
+            if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
+            if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);
+        }
     }
     if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
     return 0;
 }
+extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; }
 extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) { return c->logits_host; }
 
 static int build_graph(bamd_context * c) {

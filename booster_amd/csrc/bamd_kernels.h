@@ -39,6 +39,15 @@ struct bamd_attn_args {
     int hd, Hkv, n_ctx;
     float kq_scale;
     int prefill_mode;              // 1: KQ with the T>1 semantics of the reference (q -> f16, ggml_vec_dot_f16)
+    int batch, ld_qkv, ld_out;     // batched prefill: q/k/v and out are [T][ld_*] f32, token = blockIdx.y, position st->pos + token
+};
+
+// batched prefill mat-mul: Y[t][row] = W[row,:] . Q8_K(a_t), T tokens
+struct bamd_mm_args {
+    bamd_mv_seg seg[3]; int nseg;  // as bamd_mv_args; seg[].out = base of the [T][ldo] output of that segment's rows
+    const uint8_t * blob;          // [T][bamd_blob_bytes(K)] quantised activations (bamd_launch_quantize_batch)
+    int K, T, ldo;                 // ldo: floats between consecutive tokens in every output / residual matrix
+    const float * res;             // BAMD_EPI_ADD: residual, indexed like seg[0].out
 };
 
 void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K, hipStream_t s);
@@ -47,3 +56,8 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s);
 int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);
+size_t bamd_blob_bytes(int K);
+void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, hipStream_t s);
+int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
+void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
+int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported

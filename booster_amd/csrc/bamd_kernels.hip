@@ -821,34 +821,8 @@ __device__ __forceinline__ void get_scale_min_k4(int j, const uint8_t * q, int &
     else { d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4); }
 }
 
-__global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
-                                                         int32_t * out_tokens, const uint8_t * embd, int embd_type, int E, int V,
-                                                         float * x, int do_embed) {
-    __shared__ int tok_s;
-    if (threadIdx.x == 0) {
-        int step = st->step;
-        int tok;
-        const unsigned long long key = st->best_key;         // arg-max of the previous lm_head, 0 = none ran
-        if (key != 0ull) {
-            tok = (int) (0xffffffffu - (uint32_t) (key & 0xffffffffull));
-            out_tokens[st->n_out] = tok; st->n_out += 1;
-        } else tok = 0;
-        if (step < n_forced) tok = forced[step];
-        if (tok < 0 || tok >= V) tok = 0;
-        st->token = tok;
-        if (do_embed) {
-            st->pos = st->pos_base + step;
-            int n_kv = (st->pos + 1 + 31) / 32 * 32;
-            if (n_kv > st->n_ctx) n_kv = st->n_ctx;
-            st->n_kv = n_kv;
-            st->step = step + 1;
-        }
-        if (do_embed) st->best_key = 0ull;                   // a flush-only call leaves the key for the next generate call
-        tok_s = tok;
-    }
-    __syncthreads();
-    if (!do_embed) return;
-    const int tok = tok_s;
+// get_rows of one token (ggml.c:13186-13228 -> dequantize_row_*): row `tok` of the embedding matrix (GGUF layout) -> x[E]
+__device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, int E, int tok, float * x) {
     // get_rows: ggml.c:13186-13228 -> dequantize_row_*
     if (embd_type == BAMD_F32) {
         const float * src = (const float *) embd + (size_t) tok * E;
@@ -894,6 +868,43 @@ __global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, c
             x[i] = y;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
+                                                         int32_t * out_tokens, const uint8_t * embd, int embd_type, int E, int V,
+                                                         float * x, int do_embed) {
+    __shared__ int tok_s;
+    if (threadIdx.x == 0) {
+        int step = st->step;
+        int tok;
+        const unsigned long long key = st->best_key;         // arg-max of the previous lm_head, 0 = none ran
+        if (key != 0ull) {
+            tok = (int) (0xffffffffu - (uint32_t) (key & 0xffffffffull));
+            out_tokens[st->n_out] = tok; st->n_out += 1;
+        } else tok = 0;
+        if (step < n_forced) tok = forced[step];
+        if (tok < 0 || tok >= V) tok = 0;
+        st->token = tok;
+        if (do_embed) {
+            st->pos = st->pos_base + step;
+            int n_kv = (st->pos + 1 + 31) / 32 * 32;
+            if (n_kv > st->n_ctx) n_kv = st->n_ctx;
+            st->n_kv = n_kv;
+            st->step = step + 1;
+        }
+        if (do_embed) st->best_key = 0ull;                   // a flush-only call leaves the key for the next generate call
+        tok_s = tok;
+    }
+    __syncthreads();
+    if (!do_embed) return;
+    embed_row(embd, embd_type, E, tok_s, x);
+}
+
+// batched prefill: one workgroup per token of the micro-batch
+__global__ void __launch_bounds__(256) embed_batch_kernel(const int32_t * __restrict__ tokens, const uint8_t * embd, int embd_type, int E, int V, float * x) {
+    int tok = tokens[blockIdx.x];
+    if (tok < 0 || tok >= V) tok = 0;
+    embed_row(embd, embd_type, E, tok, x + (size_t) blockIdx.x * E);
 }
 
 // ===========================================================================================================
@@ -1088,7 +1099,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ float redf[8];
     __shared__ double redd[8];
     const bamd_step_state * st = a.st;
-    const int pos = st->pos, n_kv = st->n_kv;
+    // batched prefill (a.batch): blockIdx.y = token of the micro-batch; its K/V rows and those of the earlier tokens of the batch
+    // were stored by kv_store_batch_kernel, and masked positions are exact no-ops, so each token uses its own padded length
+    const int tokb = a.batch ? (int) blockIdx.y : 0;
+    const int pos = st->pos + tokb;
+    int n_kv = st->n_kv;
+    if (a.batch) { n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx; }
+    a.q += (size_t) tokb * a.ld_qkv; a.k += (size_t) tokb * a.ld_qkv; a.v += (size_t) tokb * a.ld_qkv; a.out += (size_t) tokb * a.ld_out;
     const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
     const int h = blockIdx.x, hk = h / gq;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
@@ -1117,7 +1134,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
     __syncthreads();
     // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
-    if (h == hk * gq) {
+    if (h == hk * gq && !a.batch) {
         for (int i = tid; i < hd; i += blockDim.x) {
             a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
             a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
@@ -1225,6 +1242,156 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ===========================================================================================================
+// Batched prefill (T > 1 tokens per call; reference: llama_decode with a micro-batch, ggml_compute_forward_mul_mat with
+// ne11 = T, ggml.c:12277-12492).  Per (row, token) the arithmetic is EXACTLY the single-token chain above — the reference
+// quantises each activation row to Q8_K and runs the same vec_dot per (row, column) — so the batched kernels reuse
+// block_terms / chain_step / finish_row unchanged and differ only in data movement: the weights of a record are unpacked once
+// and used for BAMD_TT tokens whose Q8_K activations sit in LDS.  (An MFMA formulation that keeps the per-lane chains exact —
+// f16 A = scale x quant, one 32-deep MFMA per SIMD lane e — is the next step; see DESIGN.md.)
+// ===========================================================================================================
+#define BAMD_TT 8                       /* tokens per workgroup tile */
+#define BAMD_BLOB_BYTES(nb) (BAMD_ACT_RED_OFF(nb))   /* one token's Q8_K activations in the LDS layout: q8[nb][64] | S[nb][8] | yd[nb], 16-byte padded */
+
+// one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
+template <bool NORM>
+__global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
+                                                             uint8_t * __restrict__ blob) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = K >> 8, t = blockIdx.x;
+    uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
+    double * red = (double *) (smem + BAMD_ACT_RED_OFF(nb));
+    const float * xt = x + (size_t) t * K;
+    ActPro<NORM> ap; ap.issue(xt, nw, K, wave_id()); ap.finish(xt, nw, eps, K, q8, S, yd, red);
+    const size_t bb = BAMD_BLOB_BYTES(nb);
+    const uint4 * src = (const uint4 *) smem; uint4 * dst = (uint4 *) (blob + (size_t) t * bb);
+    for (int i = threadIdx.x; i < (int) (bb / 16); i += blockDim.x) dst[i] = src[i];
+}
+
+
+template <int TYPE, typename REC, int D, int EPI>
+__device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb, int first, int count, int stride,
+                                              float * __restrict__ out, const float * __restrict__ res, int ldo, int t0, int nt,
+                                              const unsigned char * acts, size_t bb, int nvalid) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    constexpr int NPARTS = PAIR ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const long rgb = (long) nb * RECB, rg_step = (long) stride * rgb;
+    const int chunks = nb / D;
+    REC ring[D];
+    const uint8_t * rowA = wA + (long) first * rgb;
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * RECB, lane);
+    for (int r = 0; r < count; ++r) {
+        const int rg = first + r * stride;
+        const int row = rg * 8 + (lane >> 3);
+        const long rowoff = (long) rg * rgb;
+        float gate_val[BAMD_TT];
+#pragma unroll
+        for (int part = 0; part < NPARTS; ++part) {
+            const uint8_t * pbase = (part ? wB : wA) + rowoff;
+            const bool last = !(PAIR && part == 0) && r + 1 >= count;
+            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
+            RowAcc A[BAMD_TT];
+#pragma unroll
+            for (int u = 0; u < BAMD_TT; ++u) { A[u].acc = 0.f; A[u].accm = 0.f; }
+            for (int c = 0; c < chunks; ++c) {
+                const bool inrow = c + 1 < chunks;
+                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const int step = (inrow || !last) ? RECB : 0;
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    pin_rec(ring[s]);
+#pragma unroll
+                    for (int u = 0; u < BAMD_TT; ++u) {          // tokens beyond nt read stale-but-valid LDS and are never stored
+                        const unsigned char * au = acts + (size_t) u * bb;
+                        const uint32_t * q8 = (const uint32_t *) au; const int * S = (const int *) (q8 + nb * 64); const float * yd = (const float *) (S + nb * 8);
+                        const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
+                        chain_step<TYPE>(A[u], T.d, T.fs, T.dmin, T.pm);
+                    }
+                    load_rec(ring[s], nxt + s * step, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BAMD_TT; ++u) {
+                const float val = finish_row<TYPE>(A[u]);
+                if (PAIR && part == 0) { gate_val[u] = val; continue; }
+                if ((lane & 7) == 0 && row < nvalid && u < nt) {
+                    const size_t o = (size_t) (t0 + u) * ldo + row;
+                    float y = val;
+                    if (PAIR) y = v_silu(gate_val[u]) * val;
+                    if (EPI == BAMD_EPI_ADD) y = val + res[o];
+                    out[o] = y;
+                }
+            }
+        }
+    }
+}
+
+// grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = a.K >> 8;
+    const size_t bb = BAMD_BLOB_BYTES(nb);
+    const int t0 = blockIdx.x * BAMD_TT;
+    const int nt = a.T - t0 < BAMD_TT ? a.T - t0 : BAMD_TT;
+    {   // this tile's activations -> LDS (rows past T: repeat the last token; results discarded)
+        const int n16 = (int) (bb / 16);
+        for (int i = threadIdx.x; i < n16 * BAMD_TT; i += blockDim.x) {
+            const int u = i / n16, k = i - u * n16;
+            const int tu = t0 + (u < nt ? u : nt - 1);
+            ((uint4 *) smem)[(size_t) u * n16 + k] = ((const uint4 *) (a.blob + (size_t) tu * bb))[k];
+        }
+    }
+    __syncthreads();
+    const int wave = wave_id(), nwaves = blockDim.x >> 6;
+    const int slot = blockIdx.y + gridDim.y * wave, stride = gridDim.y * nwaves;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    int off = 0;
+    const int nseg = PAIR ? 1 : a.nseg;
+    for (int s = 0; s < nseg; ++s) {
+        const int nrg = a.seg[s].nrows >> 3;
+        const int k0 = off <= slot ? 0 : (off - slot + stride - 1) / stride;
+        const int g0 = slot + k0 * stride;
+        const int count = g0 < off + nrg ? (off + nrg - 1 - g0) / stride + 1 : 0;
+        if (count > 0) {
+            const int t = a.seg[s].type;
+            const uint8_t * wA = (const uint8_t *) a.seg[s].w;
+            const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
+            const int nv = a.seg[s].nvalid > 0 ? a.seg[s].nvalid : a.seg[s].nrows;
+            // ring depth 4 when it divides the row (it does for every K % 1024 == 0), else 1
+            if ((nb & 3) == 0) {
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+            } else {
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+            }
+        }
+        off += nrg;
+    }
+}
+
+// batched prefill: RoPE(K) + KV store of every token of the micro-batch, before any of them attends (grid (Hkv, T))
+__global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    const int hk = blockIdx.x, tokb = blockIdx.y;
+    const int pos = a.st->pos + tokb;
+    const int hd = a.hd, Ekv = a.Hkv * hd, n_ctx = a.n_ctx;
+    const float * k = a.k + (size_t) tokb * a.ld_qkv, * v = a.v + (size_t) tokb * a.ld_qkv;
+    rope_heads(k + (size_t) hk * hd, a.rope + (size_t) pos * hd, hd, 1, nullptr, nullptr, k16t);
+    __syncthreads();
+    for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+        a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+        a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(v[hk * hd + i]);
+    }
+}
+
+// ===========================================================================================================
 // launchers
 // ===========================================================================================================
 static size_t act_lds_bytes(int K) {
@@ -1284,6 +1451,43 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
     }
     if (pro == BAMD_PRO_NORM) launch_mv_epi<BAMD_PRO_NORM>(a, epi, grid, s);
     else                      launch_mv_epi<BAMD_PRO_PLAIN>(a, epi, grid, s);
+}
+
+// ---- batched prefill launchers ------------------------------------------------------------------------------------------
+size_t bamd_blob_bytes(int K) { return BAMD_BLOB_BYTES(K >> 8); }
+void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, hipStream_t s) {
+    if (nw) hipLaunchKernelGGL((quantize_batch_kernel<true>),  dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob);
+    else    hipLaunchKernelGGL((quantize_batch_kernel<false>), dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob);
+}
+int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s) {
+    int nrg = 0;
+    if (epi == BAMD_EPI_SILU_MUL) nrg = a.seg[0].nrows >> 3; else for (int i = 0; i < a.nseg; ++i) nrg += a.seg[i].nrows >> 3;
+    const size_t lds = (size_t) BAMD_TT * BAMD_BLOB_BYTES(a.K >> 8);
+    if (lds > 160 * 1024) return 1;                           // K > 17920: would need a K-split of the activation tile
+    const int tiles = (a.T + BAMD_TT - 1) / BAMD_TT;
+    // row slots: enough workgroups to fill the chip a few times over, at least one row-group per wave
+    int gy = (4 * (n_cu > 0 ? n_cu : 256) + tiles - 1) / tiles;
+    if (gy * 8 > nrg) gy = (nrg + 7) / 8;
+    if (gy < 1) gy = 1;
+    dim3 grid(tiles, gy);
+    switch (epi) {
+        case BAMD_EPI_STORE:    hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_STORE>),    grid, dim3(512), lds, s, a); break;
+        case BAMD_EPI_ADD:      hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_ADD>),      grid, dim3(512), lds, s, a); break;
+        case BAMD_EPI_SILU_MUL: hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_SILU_MUL>), grid, dim3(512), lds, s, a); break;
+        default: return 1;
+    }
+    return 0;
+}
+void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s) {
+    hipLaunchKernelGGL(embed_batch_kernel, dim3(T), dim3(256), 0, s, tokens, (const uint8_t *) embd, embd_type, E, V, x);
+}
+// attention of a micro-batch of T tokens (a.batch = 1, a.ld_qkv / a.ld_out set): KV store for all tokens, then (head, token) workgroups
+int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
+    if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_FUSED_MAX || !a.batch) return 1;
+    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), 0, s, a, gq);
+    return 0;
 }
 
 #ifdef BAMD_TIMING

@@ -89,6 +89,11 @@ int bamd_vocab_is_eog(const bamd_vocab * v, int id);                    /* llama
 int bamd_vocab_eos(const bamd_vocab * v);
 int bamd_vocab_eot(const bamd_vocab * v);
 
+/* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
+ * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
+ * kernels.  Bit-identical results.  Contexts with n_ctx > 2048 use the token-by-token path regardless (round 1). */
+void bamd_set_prefill_batch(int on);
+
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.
  * classes: 0 matvec (all weight streaming), 1 attention (qk+softmax+pv), 2 step-begin/other.

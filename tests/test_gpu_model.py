@@ -119,3 +119,25 @@ def test_pipeline_schedule_single_gpu(bamd, tmp_path):
         lg = ctx.decode([t], n_past); n_past += 1
     assert fed[0] == want and fed[1] == want
     ctx.close(); m.close()
+
+
+def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
+    """SURVEY §8 a8 (ne11 = T): a micro-batch through the batched kernels == the same tokens one by one (T>1 attention semantics
+    in both), bit for bit — ragged tile (T % 8 != 0), a second micro-batch on top of the first, mixed Q4_K/Q6_K fused QKV."""
+    p = str(tmp_path / "synb.gguf")
+    gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=2, L=3, F=1792, V=1024, seed=21)
+    m = bamd.Model(p)
+    toks = [(7919 * i + 13) % 1024 for i in range(37 + 22)]
+    out = {}
+    for mode in (1, 0):
+        bamd.set_prefill_batch(mode)
+        ctx = bamd.Context(m, 128)
+        l1 = ctx.decode(toks[:37], 0).copy()
+        l2 = ctx.decode(toks[37:], 37).copy()
+        l3 = ctx.decode([5], 59).copy()                      # a decode step on top of the batched KV cache
+        out[mode] = (l1, l2, l3)
+        ctx.close()
+    bamd.set_prefill_batch(1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(bits(a), bits(b)), "max |d| = %g" % np.abs(a - b).max()
+    m.close()
