@@ -127,7 +127,10 @@ def main():
         m = booster_amd.Model(path, device=0)
         ctx = booster_amd.Context(m, N_CTX)
         sys.stderr.write("[bench] model resident: %.3f GB of matmul weights, load %.1f s\n" % (m.weight_bytes / 1e9, time.time() - t0))
-        ctx.decode(prompt, 0)                                              # prefill (untimed)
+        ctx.decode(prompt[:8], 0)                                          # allocate the batched-prefill buffers
+        tp0 = time.perf_counter()
+        ctx.decode(prompt, 0)                                              # prefill: one micro-batch through the batched kernels (not part of `value`)
+        prefill_tok_s = len(prompt) / (time.perf_counter() - tp0)
         n_past = N_PROMPT
         if warmup > 0:
             ctx.generate_greedy(n_past, warmup); n_past += warmup
@@ -165,7 +168,7 @@ def main():
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
-                        launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
+                        prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                           traffic=traffic, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),

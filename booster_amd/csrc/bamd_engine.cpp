@@ -422,7 +422,7 @@ static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_ke
 static bool prefill_batch_supported(const bamd_context * c) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
-    return g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 2048 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8) &&
+    return g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 8192 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8) &&
            8 * bamd_blob_bytes(std::max(m->E, m->F)) <= 160 * 1024;
 }
 static int ensure_batch_buffers(bamd_context * c) {

@@ -1088,14 +1088,19 @@ __global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
     }
 }
 
-// ---- short / medium contexts (n_kv <= BAMD_ATTN_FUSED_MAX): ONE launch per layer, one workgroup per QUERY head -------------
+// ---- ONE launch per layer, one workgroup per QUERY head (and per token of a prefill micro-batch) ---------------------------
+// scores and probabilities live in dynamic LDS (2 x n_ctx floats).  Single-token decode uses this kernel up to
+// BAMD_ATTN_FUSED_MAX positions (beyond that one workgroup per head no longer has the bandwidth: three-kernel path);
+// batched prefill, with T x H workgroups, up to BAMD_ATTN_BATCH_MAX.
 #define BAMD_ATTN_FUSED_MAX 2048
+#define BAMD_ATTN_BATCH_MAX 8192
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
     __shared__ __attribute__((aligned(16))) float qt[256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
-    __shared__ __attribute__((aligned(16))) float sc[BAMD_ATTN_FUSED_MAX];   // scores, then exp values (natural order)
-    __shared__ __attribute__((aligned(16))) float pt[BAMD_ATTN_FUSED_MAX];   // probabilities in V^T position order
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
+    float * sc = (float *) attn_dyn;                                         // [n_ctx] scores, then exp values (natural order)
+    float * pt = sc + a.n_ctx;                                               // [n_ctx] probabilities in V^T position order
     __shared__ float redf[8];
     __shared__ double redd[8];
     const bamd_step_state * st = a.st;
@@ -1483,10 +1488,10 @@ void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, i
 }
 // attention of a micro-batch of T tokens (a.batch = 1, a.ld_qkv / a.ld_out set): KV store for all tokens, then (head, token) workgroups
 int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
-    if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_FUSED_MAX || !a.batch) return 1;
+    if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_BATCH_MAX || !a.batch) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), 0, s, a, gq);
+    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
     return 0;
 }
 
@@ -1504,7 +1509,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     if (a.n_ctx <= BAMD_ATTN_FUSED_MAX && max_tiles >= 0) {
         // context fits the LDS score buffer: one fused launch per layer, one workgroup per query head
-        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), 0, s, a, gq);
+        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
         return 0;
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;

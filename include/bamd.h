@@ -91,7 +91,7 @@ int bamd_vocab_eot(const bamd_vocab * v);
 
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
- * kernels.  Bit-identical results.  Contexts with n_ctx > 2048 use the token-by-token path regardless (round 1). */
+ * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */
 void bamd_set_prefill_batch(int on);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
