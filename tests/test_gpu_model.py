@@ -141,3 +141,31 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
     for a, b in zip(out[1], out[0]):
         assert np.array_equal(bits(a), bits(b)), "max |d| = %g" % np.abs(a - b).max()
     m.close()
+
+
+@pytest.mark.parametrize("cfg", ["mistral-q6k-8k", "70b-proportions-q5k"])
+def test_baseline_config_shapes_vs_oracle(bamd, po, tmp_path, cfg):
+    """BASELINE.json configs 4 and 5 as parity cases at reduced width: (5) every tensor Q6_K, theta 10000, n_ctx 8192 (the
+    long-context three-kernel attention in decode, batched prefill with the large score buffer); (4) GQA 8:1 with attn_v in Q5_K
+    (three differently typed segments in the fused QKV mat-vec) and an FFN width that is not a multiple of 2048 (ring depth 4)."""
+    p = str(tmp_path / "cfg.gguf")
+    if cfg == "mistral-q6k-8k":
+        gguf.write_synthetic_llama(p, E=512, H=8, Hkv=2, L=2, F=1024, V=512, theta=10000.0, seed=31, type_fn=lambda n, il: gguf.Q6_K, embd_type=gguf.Q6_K)
+        n_ctx, prompt = 8192, [(31 * i + 7) % 512 for i in range(45)]
+    else:
+        def tf(name, il):
+            return gguf.Q5_K if name == "attn_v" else gguf.Q6_K if name in ("output", "ffn_down") else gguf.Q4_K
+        gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=1, L=2, F=3584, V=512, seed=33, type_fn=tf)
+        n_ctx, prompt = 256, [(17 * i + 3) % 512 for i in range(21)]
+    r = gguf.GGUFReader(p)
+    om = po.OracleModel(r); oc = po.OracleContext(om, n_ctx, nthreads=8)
+    m = bamd.Model(p); ctx = bamd.Context(m, n_ctx)
+    lg_o = oc.decode(prompt, 0); lg_g = ctx.decode(prompt, 0)
+    assert np.array_equal(bits(lg_g), bits(lg_o)), "prefill: max |d| = %g" % np.abs(lg_g - lg_o).max()
+    n_past = len(prompt)
+    for s in range(24):
+        t = int(np.argmax(lg_o))
+        lg_o = oc.decode([t], n_past); lg_g = ctx.decode([t], n_past)
+        n_past += 1
+        assert np.array_equal(bits(lg_g), bits(lg_o)), "step %d: max |d| = %g" % (s, np.abs(lg_g - lg_o).max())
+    oc.close(); ctx.close(); m.close()
