@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-smoke", action="store_true", help="run the N > 1 code path (layer-split pipeline, RCCL group) with a single rank")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
@@ -108,11 +109,13 @@ def main():
     if rank == 0:
         bbuild.build()
     dist = None
-    if N > 1:
+    if N > 1 or args.pipeline_smoke:
         import torch.distributed as dist
         assert world == N, "launch with torch.distributed.run --nproc-per-node %d" % N
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     path = model_path()
     ensure_model(path, rank)
     if dist is not None:
@@ -122,7 +125,7 @@ def main():
     prompt = [(7919 * i + 13) % CFG_8B["V"] for i in range(N_PROMPT)]
     result = {}
 
-    if N == 1:
+    if N == 1 and not args.pipeline_smoke:
         t0 = time.time()
         m = booster_amd.Model(path, device=0)
         ctx = booster_amd.Context(m, N_CTX)

@@ -57,8 +57,9 @@ class HipStage:
         self.model.close()
 
 
-def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq):
-    """Greedy decode of n_seq sequences (same prompt) through `world` stages.
+def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset=0):
+    """Greedy decode of n_seq sequences (same prompt) through `world` stages.  pos_offset: KV position of prompt[0] (a call can
+    continue sequences whose first pos_offset positions are already in the stages' KV caches).
 
     Global schedule in ROUNDS: with period P = max(n_seq, world), rank r computes (sequence s, position pos) at round
     k = pos*P + s + r.  Every message is sent AND received in the same round — the hidden state of (s, pos) leaves rank r at
@@ -122,7 +123,7 @@ def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq):
             tok_host, tok_dev = int(prompt[pos]), None
         else:
             tok_host, tok_dev = 0, None
-        stage.step(s, tok_host, tok_dev, pos, hin[s], hout[s], want_logits, prefill_mode if is_prompt else 0)
+        stage.step(s, tok_host, tok_dev, pos + pos_offset, hin[s], hout[s], want_logits, prefill_mode if is_prompt else 0)
         if want_logits:
             stage.token_to(s, tok[s])                # last rank (world > 1: held until rank 0's round; world == 1: fed next)
     stage.sync()
@@ -135,31 +136,27 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
     ranges = split_layers(cfg["L"], N)
     stage = HipStage(booster_amd, torch, path, local, ranges[rank], rank == 0, rank == N - 1, n_ctx, N)
     dist.barrier()
-    # warm-up + prompt: every sequence through the prompt and `warmup` decode steps (untimed)
-    # (the pipeline is re-run from position 0 for the timed leg on fresh KV positions beyond: simpler — time a second call)
-    run_pipeline(stage, dist, rank, N, prompt, max(warmup, 1), N)
+    # untimed: every sequence through the prompt and `warmup` + 1 decode steps.  All sequences are identical, so the token fed at
+    # the last position is known on rank 0; the timed call re-feeds it at the same position (T = 1 semantics, identical KV row)
+    # and then runs EXACTLY `steps` decode steps per sequence on top of the warm caches.
+    fed = run_pipeline(stage, dist, rank, N, prompt, warmup + 1, N)
+    pos0 = len(prompt) + warmup
+    carry = [fed[0][-1] if rank == 0 else 0]
     dist.barrier(); stage.sync()
     t0 = time.perf_counter()
-    run_pipeline(stage, dist, rank, N, prompt, steps, N)
+    run_pipeline(stage, dist, rank, N, carry, steps, N, pos_offset=pos0)
     stage.sync(); dist.barrier()
-    dt_all = time.perf_counter() - t0
-    # the timed call re-processes the prompt; subtract a prompt-only run measured the same way
-    dist.barrier(); stage.sync()
-    t0 = time.perf_counter()
-    run_pipeline(stage, dist, rank, N, prompt, 1, N)
-    stage.sync(); dist.barrier()
-    dt_prompt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0
     # single sequence in flight (latency-bound, the reference's batch-1 layer-split behaviour)
     k1 = min(steps, 32)
     dist.barrier(); stage.sync()
     t0 = time.perf_counter()
-    run_pipeline(stage, dist, rank, N, prompt[:8], k1, 1)
+    run_pipeline(stage, dist, rank, N, carry, k1, 1, pos_offset=pos0)
     stage.sync(); dist.barrier()
     dt_single = time.perf_counter() - t0
-    t = torch.tensor([dt_all, dt_prompt, dt_single], dtype=torch.float64, device=stage.device)
+    t = torch.tensor([dt, dt_single], dtype=torch.float64, device=stage.device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_all, dt_prompt, dt_single = [float(v) for v in t.tolist()]
-    dt = max(dt_all - dt_prompt, 1e-9) * steps / max(steps - 1, 1)
+    dt, dt_single = [float(v) for v in t.tolist()]
     value = N * steps / dt
     stage.close()
     return dict(value=round(value, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",

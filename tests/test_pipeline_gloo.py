@@ -63,8 +63,12 @@ def worker(rank, world, port, n_seq, q):
     ranges = pipeline.split_layers(5, world)
     st = FakeStage(list(range(*ranges[rank])), rank == 0, rank == world - 1)
     fed = pipeline.run_pipeline(st, dist, rank, world, [3, 1, 4, 1, 5], 7, n_seq)
+    # the bench's two-phase use: 4 steps, then continue from the last fed token at its own position (pos_offset)
+    fed1 = pipeline.run_pipeline(st, dist, rank, world, [3, 1, 4, 1, 5], 4, n_seq)
+    carry = [fed1[0][-1] if rank == 0 else 0]
+    fed2 = pipeline.run_pipeline(st, dist, rank, world, carry, 3, n_seq, pos_offset=5 + 3)
     if rank == 0:
-        q.put(fed)
+        q.put((fed, [a + b for a, b in zip(fed1, fed2)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,13 +80,13 @@ def test_layer_split_world2(n_seq):
     port = 29600 + n_seq + (os.getpid() % 200)
     procs = [ctx.Process(target=worker, args=(r, 2, port, n_seq, q)) for r in range(2)]
     for p in procs: p.start()
-    fed = q.get(timeout=120)
+    fed, fed_two_phase = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     want = reference([3, 1, 4, 1, 5], 7, 5)
-    assert len(fed) == n_seq
-    for f in fed:
+    assert len(fed) == n_seq and len(fed_two_phase) == n_seq
+    for f in fed + fed_two_phase:
         assert f == want
 
 
