@@ -158,6 +158,10 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, dt_single = [float(v) for v in t.tolist()]
     value = N * steps / dt
+    wbytes = float(getattr(stage.model, "weight_bytes", 0))         # this rank's slice of the mat-mul weights
+    t = torch.tensor([wbytes], dtype=torch.float64, device=stage.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    per_gpu_gbs = float(t.item()) / N * value / 1e9                 # every token of every sequence streams each stage's slice once
     stage.close()
     return dict(value=round(value, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
                 config=dict(workload="Llama-3-8B Q4_K_M shapes (synthetic GGUF), greedy decode, layer-split over %d MI355X, %d sequences in flight, "
@@ -165,4 +169,5 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
                             parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state per boundary per token" % N,
                             layer_ranges=ranges, single_sequence_tokens_per_s=round(k1 / max(dt_single, 1e-9), 2),
                             note="single_sequence = one request through all stages (stages idle in turn, the reference's batch-1 behaviour)"),
-                roofline=None)
+                roofline=dict(bound="hbm", achieved=round(per_gpu_gbs, 1), peak=8000.0, unit="GB/s", frac=round(per_gpu_gbs / 8000.0, 4), traffic=None,
+                              kernel="per-GPU average over the timed region: (weight bytes of a stage) x (tokens/s through it); per-launch figures are the N=1 line's"))
