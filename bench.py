@@ -67,9 +67,29 @@ def split_layers(L, n):
     return list(zip(first, cuts))
 
 
+def cpu_baseline_reference(path, nthreads):
+    """The GENUINE reference CPU path (oracle/_ref/ref_bench: ggml + llama.cpp of gotzmann/booster compiled in place by
+    oracle/Makefile with Booster's `make cpu` flags, -march=x86-64-v3) on the same GGUF, all 32 layers: a 16-token prefill and
+    12 single-token llama_decode steps; the metric is the reference's own t_eval definition.  None if the binary is not there."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    if not os.path.exists(exe):
+        return None
+    n_prompt, n_decode = 16, 12
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    out = subprocess.run([exe, path, str(nthreads), str(n_prompt), str(n_decode), "512"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         timeout=600, env=env, check=True).stdout.decode()
+    m = re.search(r"tokens_per_s=([0-9.]+) ms_per_token=([0-9.]+) prompt_tokens_per_s=([0-9.]+)", out)
+    return dict(value=round(float(m.group(1)), 4), unit="tokens/s", cores=nthreads, kind="reference",
+                sample="genuine reference CPU path (gotzmann/booster's ggml + llama.cpp built by oracle/Makefile, `make cpu` flags with -march=x86-64-v3, "
+                       "%d threads) on the same GGUF, all 32 layers: %d-token prefill (%.1f tok/s) + %d greedy single-token llama_decode steps, %.1f ms per token"
+                       % (nthreads, n_prompt, float(m.group(3)), n_decode, float(m.group(2))))
+
+
 def cpu_baseline(path, nthreads):
-    """The oracle (port of the reference CPU path) on a bounded sample: decode steps through the first 1 and 2 layers
-    + lm_head, extrapolated to 32 layers.  Checker code only — never part of the measured GPU path."""
+    """Fallback when oracle/_ref is absent: the oracle (port of the reference CPU path) on a bounded sample: decode steps through
+    the first 1 and 2 layers + lm_head, extrapolated to 32 layers.  Checker code only — never part of the measured GPU path."""
     from oracle import pyoracle as po
     from booster_amd.gguf import GGUFReader
     r = GGUFReader(path)
@@ -151,7 +171,13 @@ def main():
         for i in range(reps):
             l, ms, b = ctx.profile_step(n_past - 1)
             L_ += l[:3]; MS_ += ms[:3]; B_ += b[:3]; ev_over.append(ms[3])
-        ev_overhead_ms = float(np.median(ev_over))                       # an empty event pair on the same stream
+        ev_empty_ms = float(np.median(ev_over))                          # what an EMPTY event pair reads on the same stream
+        # An event pair around a kernel adds less than an empty pair reads (the second record overlaps the kernel's tail), so the
+        # per-launch overhead is calibrated against the timed region itself: the eager per-launch times of one step, minus the
+        # overhead, must add up to the step time the hipGraph replay measured above.  (Check: rocprofv3's mean mat-vec duration
+        # for the same workload, profiles/r01_kernel_stats.csv.)
+        step_ms = dt / steps * 1e3
+        ev_overhead_ms = min(max((float(MS_.sum()) / reps - step_ms) / (float(L_.sum()) / reps), 0.0), ev_empty_ms)
         mv_bytes_per_launch = B_[0] / L_[0]
         mv_ms_per_launch = max(MS_[0] / L_[0] - ev_overhead_ms, 1e-6)
         achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
@@ -171,7 +197,7 @@ def main():
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
-                        prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3)),
+                        prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3), empty_event_pair_us=round(ev_empty_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                           traffic=traffic, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
@@ -182,7 +208,13 @@ def main():
                     ncpu = len(os.sched_getaffinity(0))
                 except AttributeError:
                     ncpu = os.cpu_count() or 1
-                result["cpu_baseline"] = cpu_baseline(path, max(1, min(ncpu, 32)))
+                nthr = max(1, min(ncpu, 32))
+                try:
+                    ref = cpu_baseline_reference(path, nthr)
+                except Exception as e:
+                    sys.stderr.write("[bench] reference cpu baseline failed (%r); falling back to the oracle port\n" % (e,))
+                    ref = None
+                result["cpu_baseline"] = ref if ref is not None else cpu_baseline(path, nthr)
             except Exception as e:      # the checker must never take the bench down
                 result["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=0, kind="port", sample="failed: %r" % (e,))
         ctx.close(); m.close()
