@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "bamd_formats.h"
 #include "bamd_kernels.h"
 
@@ -1445,7 +1446,10 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
     const int cus = n_cu > 0 ? n_cu : 256;
     // few row-groups: split K over the 8 waves of a workgroup (mode B); otherwise one wave per row-group (mode A)
     const bool can_split = (epi == BAMD_EPI_STORE || epi == BAMD_EPI_ADD) && split_supported(a.K >> 8);
-    const bool split = a.mode == 2 ? can_split : a.mode == 1 ? false : (can_split && nrg < 8 * cus);
+    // differently typed segments (wq|wk Q4_K + wv Q6_K): a split-K workgroup would stream them one after the other, each with its
+    // own ring fill; with one wave per row-group every wave has a single row-group of a single type
+    const bool mixed = a.nseg > 1 && epi == BAMD_EPI_STORE && nrg <= 8 * cus;
+    const bool split = a.mode == 2 ? can_split : a.mode == 1 ? false : (can_split && nrg < 8 * cus && !mixed);
     int grid = cus;                                          // one 8-wave workgroup per CU
     if (grid > nrg) grid = nrg;
     if (grid < 1) grid = 1;
