@@ -125,6 +125,41 @@ void init_janus(Pod & p) {                        // cpp/janus.cpp:410-490
 struct Cand { int id; float logit, p; };
 
 // cpp/janus.cpp:191-331 + llama_sample_token (llama-sampling.cpp:32-58, :610-631)
+// The shortlist of sample_janus_token (janus.cpp:262-300): ALL candidates sorted by logit (std::sort, descending), the cut-off
+// chosen from the top token, then everything from the first candidate with logit / topLogit < cutoff dropped.
+//   slow path: exactly that — a full sort of the vocabulary (≈10 ms at V = 128256, several times a decode step on the GPU);
+//   fast path: when the top logit is positive and unique, logit / top is monotone along the sorted order, so the shortlist is the
+//     set { logit / top >= cutoff } — two linear passes and a sort of the (typically tiny) shortlist.  Equal logits inside the
+//     shortlist would make the order depend on std::sort's internals over the whole array: then the slow path runs.
+// Same result in every case (bamd_janus_shortlist_test compares the two).
+template <typename CutoffFn>
+static void janus_shortlist(const float * logits, size_t V, CutoffFn cutoff_of, bool allow_fast, std::vector<Cand> & cand) {
+    cand.clear();
+    if (allow_fast && V > 0) {
+        size_t top = 0; size_t ntop = 1;
+        for (size_t id = 1; id < V; id++) {
+            if (logits[id] > logits[top]) { top = id; ntop = 1; }
+            else if (logits[id] == logits[top]) ++ntop;
+        }
+        const float topLogit = logits[top];
+        if (topLogit > 0.0f && ntop == 1) {
+            const float cutoff = cutoff_of((int) top);
+            for (size_t id = 0; id < V; id++) if (!(logits[id] / topLogit < cutoff)) cand.push_back(Cand{ (int) id, logits[id], 0.0f });
+            std::sort(cand.data(), cand.data() + cand.size(), [](const Cand & a, const Cand & b) { return a.logit > b.logit; });
+            bool ties = cand.empty() || cand[0].id != (int) top;
+            for (size_t i = 1; i < cand.size() && !ties; i++) ties = !(cand[i].logit < cand[i - 1].logit);   // equal, or a NaN that broke the ordering
+            if (!ties) return;
+            cand.clear();
+        }
+    }
+    cand.reserve(V);
+    for (int id = 0; id < (int) V; id++) cand.push_back(Cand{ id, logits[id], 0.0f });
+    std::sort(cand.data(), cand.data() + cand.size(), [](const Cand & a, const Cand & b) { return a.logit > b.logit; });
+    const float topLogit = cand[0].logit;
+    const float cutoff = cutoff_of(cand[0].id);
+    for (size_t i = 1; i < cand.size(); i++) if (cand[i].logit / topLogit < cutoff) { cand.resize(i); break; }
+}
+
 int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, size_t promptLen, size_t pos, size_t max) {
     const size_t V = (size_t) p.n_vocab, ctxSize = last_tokens.size();
     const int lastToken = last_tokens[ctxSize - 1];
@@ -141,13 +176,11 @@ int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, 
         const float curType = p.types[id];
         if ((lastType == SPACE_RU || lastType == LANG_RU) && (curType == LANG_EN || curType == LANG_OTHER)) logits[id] *= 0.5;
     }
-    std::vector<Cand> cand; cand.reserve(V);
-    for (int id = 0; id < (int) V; id++) cand.push_back(Cand{ id, logits[id], 0.0f });
-    std::sort(cand.data(), cand.data() + cand.size(), [](const Cand & a, const Cand & b) { return a.logit > b.logit; });
-    const int topToken = cand[0].id; const float topType = p.types[(size_t) topToken], topLogit = cand[0].logit;
-    float cutoff = p.jp.lo;
-    if (is_pedantic(p.vocab.token_to_piece(topToken)) || topType == LANG_RU || topType == LANG_EN) cutoff = p.jp.hi;
-    for (size_t i = 1; i < cand.size(); i++) if (cand[i].logit / topLogit < cutoff) { cand.resize(i); break; }
+    std::vector<Cand> cand;
+    janus_shortlist(logits, V, [&](int topToken) {
+        const float topType = p.types[(size_t) topToken];
+        return (is_pedantic(p.vocab.token_to_piece(topToken)) || topType == LANG_RU || topType == LANG_EN) ? p.jp.hi : p.jp.lo;
+    }, true, cand);
     // softmax over the (sorted) shortlist, then one draw from std::discrete_distribution on the pod's mt19937
     const float max_l = cand[0].logit; float cum = 0.0f;
     for (auto & c : cand) { c.p = expf(c.logit - max_l); cum += c.p; }
@@ -346,6 +379,14 @@ BAMD_API int64_t timing(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); re
 BAMD_API uint32_t getSeed(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].seed; }
 
 // ---- test hooks (not part of the cgo surface): tokenizer and Janus as pure functions -------------------------------------------
+// test hook: the Janus shortlist of `logits` with a fixed cut-off, through the fast (1) or the full-sort (0) path -> ids, count
+BAMD_API int bamd_janus_shortlist_test(const float * logits, int V, float cutoff, int fast, int32_t * ids, int cap) {
+    std::vector<Cand> cand;
+    janus_shortlist(logits, (size_t) V, [&](int) { return cutoff; }, fast != 0, cand);
+    for (size_t i = 0; i < cand.size() && (int) i < cap; ++i) ids[i] = cand[i].id;
+    return (int) cand.size();
+}
+
 BAMD_API int bamd_bridge_tokenize(void * ctx, const char * text, int add_special, int parse_special, int32_t * out, int cap) {
     Pod & p = *(Pod *) ctx;
     const std::vector<int> t = p.vocab.tokenize(text, add_special != 0, parse_special != 0);

@@ -89,6 +89,11 @@ int bamd_vocab_is_eog(const bamd_vocab * v, int id);                    /* llama
 int bamd_vocab_eos(const bamd_vocab * v);
 int bamd_vocab_eot(const bamd_vocab * v);
 
+/* Test hook, CPU only: the candidate shortlist of the Janus sampler (janus.cpp:262-300 — full descending sort, cut at the first
+ * candidate with logit / top < cutoff) through the linear-time path (fast = 1; falls back by itself when ties or a non-positive top
+ * make the order depend on the full sort) or the full-sort path (fast = 0).  Writes up to `cap` ids in order, returns the count. */
+int bamd_janus_shortlist_test(const float * logits, int n_vocab, float cutoff, int fast, int32_t * ids, int cap);
+
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
  * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */
