@@ -57,6 +57,7 @@ def lib():
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
         L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp, ci]
         L.bamd_op_ffn_gate_up.argtypes = [ci, vp, vp, ci, ci, vp, vp, cf, vp]
+        L.bamd_op_mul_mat_batch.argtypes = [ci, vp, ci, ci, vp, ci, vp, cf, vp, vp, ci]
         L.bamd_op_get_row.argtypes = [ci, vp, ci, ci, ci, vp]
         L.bamd_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.bamd_op_rope_row.argtypes = [ci, ci, cf, cf, vp, vp]
@@ -75,7 +76,7 @@ def _p(a):
 
 def set_prefill_batch(on):
     """True (default): prompts of 2..512 tokens go through the batched prefill kernels; False: token by token (same bits)."""
-    lib().bamd_set_prefill_batch(1 if on else 0)
+    lib().bamd_set_prefill_batch(int(on))      # 2: batched without the MFMA kernel
 
 
 def device_count():
@@ -171,6 +172,17 @@ def op_mul_mat_vec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=Non
     res = None if residual is None else np.ascontiguousarray(residual, np.float32)
     y = np.zeros(nrows, np.float32)
     _chk(lib().bamd_op_mul_mat_vec(ttype, _p(w_raw), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y), mode))
+    return y
+
+
+def op_mul_mat_batch(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, impl=0):
+    """Y[t] = W . Q8_K(x[t]) for T rows at once through the prefill kernels: impl 0 = integer-dot kernel, 1 = MFMA kernel (Q4_K)."""
+    w_raw = np.ascontiguousarray(w_raw, np.uint8); x = np.ascontiguousarray(x, np.float32)
+    T = x.shape[0]
+    nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
+    res = None if residual is None else np.ascontiguousarray(residual, np.float32)
+    y = np.zeros((T, nrows), np.float32)
+    _chk(lib().bamd_op_mul_mat_batch(ttype, _p(w_raw), nrows, k, _p(x), T, _p(nw), eps, _p(res), _p(y), impl))
     return y
 
 

@@ -23,6 +23,8 @@
 static thread_local std::string g_err;
 // BAMD_PREFILL_BATCH=0: evaluate prompts token by token through the decode kernels instead of the batched kernels (same bits)
 static int g_prefill_batch = [] { const char * e = getenv("BAMD_PREFILL_BATCH"); return (e && e[0] == '0') ? 0 : 1; }();
+// BAMD_PREFILL_MFMA=0: Q4_K mat-muls of the batched prefill on the integer-dot kernel instead of the MFMA kernel (same bits)
+static int g_prefill_mfma = [] { const char * e = getenv("BAMD_PREFILL_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
@@ -113,7 +115,7 @@ struct bamd_context {
     hipGraphExec_t graph = nullptr;
     // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
     int bcap = 0;
-    float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr;
+    float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr, * bu = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -431,8 +433,38 @@ static int ensure_batch_buffers(bamd_context * c) {
     const size_t T = BAMD_PREFILL_CAP, Ekv = (size_t) m->Hkv * m->hd;
     if (dev_alloc(c->allocs, (void **) &c->bx, T * m->E * 4) || dev_alloc(c->allocs, (void **) &c->bx2, T * m->E * 4) ||
         dev_alloc(c->allocs, (void **) &c->bqkv, T * (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->batt, T * m->E * 4) ||
-        dev_alloc(c->allocs, (void **) &c->bh, T * m->F * 4) || dev_alloc(c->allocs, (void **) &c->bblob, T * bamd_blob_bytes(std::max(m->E, m->F)))) return 1;
+        dev_alloc(c->allocs, (void **) &c->bh, T * m->F * 4) || dev_alloc(c->allocs, (void **) &c->bu, T * m->F * 4) ||
+        dev_alloc(c->allocs, (void **) &c->bblob, T * bamd_blob_bytes(std::max(m->E, m->F))) ||
+        dev_alloc(c->allocs, (void **) &c->bblob16, T * bamd_blob16_bytes(std::max(m->E, m->F)))) return 1;
     c->bcap = (int) T;
+    return 0;
+}
+// one batched mat-mul: Q4_K segments on the MFMA kernel, the rest on the integer-dot kernel (identical bits either way)
+static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_t s) {
+    bamd_model * m = c->m;
+    const bool mfma_ok = g_prefill_mfma && (a.K % 1024) == 0;
+    if (epi == BAMD_EPI_SILU_MUL) {
+        if (mfma_ok && a.seg[0].type == BAMD_Q4_K && a.seg[1].type == BAMD_Q4_K) {
+            const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
+            if (bamd_launch_matmul_mfma(a.seg[0].w, BAMD_Q4_K, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, a.ldo, s)) return 1;   // gate -> h
+            if (bamd_launch_matmul_mfma(a.seg[1].w, BAMD_Q4_K, nv, a.seg[1].nrows, a.K, c->bblob16, T, c->bu, nullptr, a.ldo, s)) return 1;          // up
+            bamd_launch_silu_mul(a.seg[0].out, c->bu, a.seg[0].out, (size_t) T * a.ldo, s);
+            return 0;
+        }
+        return bamd_launch_matmul_batch(a, epi, m->n_cu, s);
+    }
+    bamd_mm_args rest = a; rest.nseg = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        if (mfma_ok && a.seg[i].type == BAMD_Q4_K) {
+            const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
+            const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
+            if (bamd_launch_matmul_mfma(a.seg[i].w, BAMD_Q4_K, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, a.ldo, s)) return 1;
+        } else rest.seg[rest.nseg++] = a.seg[i];
+    }
+    if (rest.nseg) {
+        if (epi == BAMD_EPI_ADD) rest.res = a.res + (rest.seg[0].out - a.seg[0].out);
+        return bamd_launch_matmul_batch(rest, epi, m->n_cu, s);
+    }
     return 0;
 }
 // tokens already in c->forced; leaves the hidden state of the LAST token in c->x
@@ -448,14 +480,14 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         const DevLayer & ly = m->layers[il];
         bamd_mm_args a; memset(&a, 0, sizeof a);
         // q,k,v                                                            (llama.cpp:8810-8835)
-        bamd_launch_quantize_batch(c->bx, ly.attn_norm, m->eps, E, T, c->bblob, s);
+        bamd_launch_quantize_batch(c->bx, ly.attn_norm, m->eps, E, T, c->bblob, c->bblob16, s);
         seg_of(a.seg[0], ly.wq, c->bqkv); a.nseg = 1;
         if (ly.wk.type == ly.wq.type) { a.seg[0].nrows += ly.wk.nrows; a.seg[0].nvalid += ly.wk.nrows; }
         else { seg_of(a.seg[a.nseg], ly.wk, c->bqkv + E); a.nseg++; }
         if (ly.wv.type == ly.wk.type) { a.seg[a.nseg - 1].nrows += ly.wv.nrows; a.seg[a.nseg - 1].nvalid += ly.wv.nrows; }
         else { seg_of(a.seg[a.nseg], ly.wv, c->bqkv + E + Ekv); a.nseg++; }
         a.blob = c->bblob; a.K = E; a.T = T; a.ldo = ldq;
-        if (bamd_launch_matmul_batch(a, BAMD_EPI_STORE, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        if (batch_mm(c, a, BAMD_EPI_STORE, T, s)) return fail("batched mat-mul: unsupported shape");
         // RoPE, KV store, attention with the T>1 semantics                  (llama.cpp:8837-8849, :8318-8353)
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
@@ -463,20 +495,20 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         t.batch = 1; t.ld_qkv = ldq; t.ld_out = E;
         if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
         // x2 = x + Wo . att
-        bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, s);
+        bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wo, c->bx2); a.nseg = 1; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = E; a.res = c->bx;
-        if (bamd_launch_matmul_batch(a, BAMD_EPI_ADD, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        if (batch_mm(c, a, BAMD_EPI_ADD, T, s)) return fail("batched mat-mul: unsupported shape");
         // h = silu(Wg . a) * (Wu . a)
-        bamd_launch_quantize_batch(c->bx2, ly.ffn_norm, m->eps, E, T, c->bblob, s);
+        bamd_launch_quantize_batch(c->bx2, ly.ffn_norm, m->eps, E, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wg, c->bh); seg_of(a.seg[1], ly.wu, c->bh); a.nseg = 2; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = F;
-        if (bamd_launch_matmul_batch(a, BAMD_EPI_SILU_MUL, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        if (batch_mm(c, a, BAMD_EPI_SILU_MUL, T, s)) return fail("batched mat-mul: unsupported shape");
         // x = x2 + Wd . h
-        bamd_launch_quantize_batch(c->bh, nullptr, 0.f, F, T, c->bblob, s);
+        bamd_launch_quantize_batch(c->bh, nullptr, 0.f, F, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wd, c->bx); a.nseg = 1; a.blob = c->bblob; a.K = F; a.T = T; a.ldo = E; a.res = c->bx2;
-        if (bamd_launch_matmul_batch(a, BAMD_EPI_ADD, m->n_cu, s)) return fail("batched mat-mul: unsupported shape");
+        if (batch_mm(c, a, BAMD_EPI_ADD, T, s)) return fail("batched mat-mul: unsupported shape");
     }
     HIPC(hipMemcpyAsync(c->x, c->bx + (size_t) (T - 1) * E, (size_t) E * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -509,7 +541,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
     return 0;
 }
-extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; }
+extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; g_prefill_mfma = on == 2 ? 0 : 1; }
 extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) { return c->logits_host; }
 
 static int build_graph(bamd_context * c) {
@@ -700,6 +732,33 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
                                    const float * residual, float * y, int mode) {
     return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, mode);
+}
+// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = MFMA kernel (Q4_K)
+extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int type, const void * w_raw, int nrows, int k, const float * x, int T, const float * norm_w,
+                                                                              float eps, const float * residual, float * y, int impl) {
+    if (need_device()) return 1;
+    if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0 || T <= 0) return fail("bad type/shape");
+    const int nrows_pad = (nrows + 7) / 8 * 8;
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_row_bytes(type, k) * (size_t) nrows_pad;
+    void * raw = t.up(w_raw, wb), * str = t.up(nullptr, wbp);
+    float * dx = (float *) t.up(x, (size_t) T * k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr;
+    float * dres = residual ? (float *) t.up(residual, (size_t) T * nrows * 4) : nullptr; float * dy = (float *) t.up(nullptr, (size_t) T * nrows * 4);
+    void * blob = t.up(nullptr, (size_t) T * bamd_blob_bytes(k)), * blob16 = t.up(nullptr, (size_t) T * bamd_blob16_bytes(k));
+    if (!raw || !str || !dx || !dy || !blob || !blob16 || (norm_w && !dw) || (residual && !dres)) return fail("device alloc/copy failed");
+    HIPC(hipMemset(str, 0, wbp));
+    bamd_launch_repack(raw, str, type, nrows, k, nullptr);
+    bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
+    if (impl == 1) {
+        if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
+    } else {
+        bamd_mm_args a; memset(&a, 0, sizeof a);
+        a.seg[0].w = str; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows_pad; a.seg[0].nvalid = nrows; a.nseg = 1;
+        a.blob = (const uint8_t *) blob; a.K = k; a.T = T; a.ldo = nrows; a.res = dres;
+        if (bamd_launch_matmul_batch(a, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, n_cu0(), nullptr)) return fail("batched mat-mul: unsupported shape");
+    }
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(y, dy, (size_t) T * nrows * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
                                    float eps, float * y) {

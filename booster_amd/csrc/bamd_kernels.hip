@@ -1259,9 +1259,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #define BAMD_BLOB_BYTES(nb) (BAMD_ACT_RED_OFF(nb))   /* one token's Q8_K activations in the LDS layout: q8[nb][64] | S[nb][8] | yd[nb], 16-byte padded */
 
 // one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
+// f16 copy of a token's Q8_K row for the MFMA path: per super-block 8 (e) x 4 (g) groups of 8 halves, group (e, g) = the int8 of
+// sub-blocks 2g and 2g+1, chunk e, as exact f16 — one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane; then yd[nb] f32 and
+// S[nb][8] i32 as in the int8 blob.
+#define BAMD_BLOB16_BYTES(nb) ((size_t) (nb) * (512 + 4 + 32))
 template <bool NORM>
 __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
-                                                             uint8_t * __restrict__ blob) {
+                                                             uint8_t * __restrict__ blob, uint8_t * __restrict__ blob16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nb = K >> 8, t = blockIdx.x;
     uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
@@ -1269,8 +1273,23 @@ __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __res
     const float * xt = x + (size_t) t * K;
     ActPro<NORM> ap; ap.issue(xt, nw, K, wave_id()); ap.finish(xt, nw, eps, K, q8, S, yd, red);
     const size_t bb = BAMD_BLOB_BYTES(nb);
-    const uint4 * src = (const uint4 *) smem; uint4 * dst = (uint4 *) (blob + (size_t) t * bb);
-    for (int i = threadIdx.x; i < (int) (bb / 16); i += blockDim.x) dst[i] = src[i];
+    if (blob) {
+        const uint4 * src = (const uint4 *) smem; uint4 * dst = (uint4 *) (blob + (size_t) t * bb);
+        for (int i = threadIdx.x; i < (int) (bb / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    if (blob16) {
+        uint8_t * o = blob16 + (size_t) t * BAMD_BLOB16_BYTES(nb);
+        for (int i = threadIdx.x; i < nb * 64; i += blockDim.x) {          // q8[ci*64 + e*8 + c] = sub-block c, chunk e, 4 int8
+            const int ci = i >> 6, e = (i >> 3) & 7, c = i & 7;
+            const uint32_t w = q8[i];
+            const unsigned short h0 = f2h((float) (int8_t) (w)), h1 = f2h((float) (int8_t) (w >> 8)), h2 = f2h((float) (int8_t) (w >> 16)), h3 = f2h((float) (int8_t) (w >> 24));
+            uint2 v; v.x = (uint32_t) h0 | ((uint32_t) h1 << 16); v.y = (uint32_t) h2 | ((uint32_t) h3 << 16);
+            *(uint2 *) (o + (size_t) ((ci * 8 + e) * 4 + (c >> 1)) * 16 + (c & 1) * 8) = v;
+        }
+        float * oyd = (float *) (o + (size_t) nb * 512); int * oS = (int *) (o + (size_t) nb * 516);
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) oyd[i] = yd[i];
+        for (int i = threadIdx.x; i < nb * 8; i += blockDim.x) oS[i] = S[i];
+    }
 }
 
 
@@ -1333,6 +1352,119 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
             }
         }
     }
+}
+
+// ---- Q4_K x Q8_K on the matrix cores, exact ---------------------------------------------------------------------------
+// The reference's per-lane integer sums  isum_e = sum_j sc_j * sum_u w[j,e,u] * x[j,e,u]  (e = SIMD lane, j = 32-element sub-block,
+// u = 0..3) are 32-term dot products per (row, token, super-block, e).  With A = sc_j * w (<= 63 * 15 = 945: exact in f16), B = x
+// (int8: exact in f16) and f32 accumulation of integers < 2^24, ONE v_mfma_f32_16x16x32_f16 per e yields the sixteen-by-sixteen
+// (row, token) tile of isum_e exactly; the f32 chains acc_e = fma(d_x * d_y, isum_e, acc_e), the min terms and the final hsum tree
+// then run on the VALU in the reference's order (ggml-quants.c:6937-6978) — bit-identical to the integer-dot kernels above.
+// MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3);
+// C/D rows 4g + i, token m (cdna_hip_programming.md, fragment layout).  One wave = 16 rows x 16 tokens over the whole K.
+typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
+typedef float bamd_f4 __attribute__((ext_vector_type(4)));
+struct bamd_mma_args {
+    const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
+    const uint8_t * blob16; int K, T, nrows, nrows_pad, ldo;
+};
+__device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2, uint32_t & sc03, uint32_t & sc47, uint32_t & mn03, uint32_t & mn47) {
+    sc03 = u0 & 0x3f3f3f3fu; mn03 = u1 & 0x3f3f3f3fu;                                    // ggml-quants.c:6928-6933
+    sc47 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+    mn47 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+}
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
+    const int lane = threadIdx.x & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    const int nb = a.K >> 8;
+    const int rt = blockIdx.y * 8 + wave;                    // row tile: rows rt*16 .. rt*16+15 = record groups 2rt, 2rt+1
+    if (rt * 16 >= a.nrows_pad) return;
+    const int t0 = blockIdx.x * 16;
+    const int tB = t0 + m < a.T ? t0 + m : a.T - 1;          // tokens past T: recompute the last one, never stored
+    const size_t b16 = BAMD_BLOB16_BYTES(nb);
+    const uint8_t * blob = a.blob16 + (size_t) tB * b16;
+    const float * ydp = (const float *) (blob + (size_t) nb * 512); const int * Sp = (const int *) (blob + (size_t) nb * 516);
+    // A side: row m of the tile
+    const uint8_t * recA = a.w + (size_t) (rt * 2 + (m >> 3)) * nb * 1152 + (size_t) ((m & 7) * 8) * 16 + g * 4;
+    const uint8_t * hdrA = a.w + (size_t) (rt * 2 + (m >> 3)) * nb * 1152 + 1024 + (m & 7) * 16;
+    // C side: rows 4g + i of the tile
+    const uint8_t * hdrC[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; hdrC[i] = a.w + (size_t) (rt * 2 + (r >> 3)) * nb * 1152 + 1024 + (r & 7) * 16; }
+    bamd_f4 acc[8], accm[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int l = 0; l < 4; ++l) accm[l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    for (int ci = 0; ci < nb; ++ci) {
+        const size_t ro = (size_t) ci * 1152;
+        // scales of MY A row for sub-blocks 2g, 2g+1 as f16 pairs (s, s) and (-1024 s, -1024 s)
+        const uint4 ha = *(const uint4 *) (hdrA + ro);
+        uint32_t sc03, sc47, mn03, mn47; unpack_k4_(ha.y, ha.z, ha.w, sc03, sc47, mn03, mn47);
+        const uint32_t scw = (g < 2 ? sc03 : sc47) >> (16 * (g & 1));
+        const _Float16 s_lo = (_Float16) (float) (scw & 0xffu), s_hi = (_Float16) (float) ((scw >> 8) & 0xffu);
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
+        const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
+        // d, dmin, mins of the four C rows; yd, S of my token
+        float D[4], Dm[4]; uint32_t mn[4][2];
+        const float ydv = ydp[ci];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 hc = *(const uint4 *) (hdrC[i] + ro);
+            D[i] = ydv * h2f(hc.x & 0xffffu);
+            Dm[i] = (-ydv) * h2f(hc.x >> 16);
+            uint32_t c03, c47; unpack_k4_(hc.y, hc.z, hc.w, c03, c47, mn[i][0], mn[i][1]);
+        }
+        const int4 S0 = *(const int4 *) (Sp + ci * 8), S1 = *(const int4 *) (Sp + ci * 8 + 4);
+        const int Sv[8] = { S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t wq = __builtin_nontemporal_load((const uint32_t *) (recA + ro + e * 16));
+            const uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+            // bytes -> (1024 + n) as f16 pairs, then (1024 + n) * s - 1024 * s = n * s exactly (one rounding of an exact value)
+            const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
+            const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), p3 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
+            union { uint32_t u; h2_t h; } c0, c1, c2, c3; c0.u = p0; c1.u = p1; c2.u = p2; c3.u = p3;
+            const h2_t a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2), a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
+            const h2_t a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2), a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+            bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
+            const bamd_h8 bv = *(const bamd_h8 *) (blob + (size_t) ((ci * 8 + e) * 4 + g) * 16);
+            const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+            const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[e][i] = fmaf(D[i], si[i], acc[e][i]);
+        }
+        // min terms: pm_l = m_{2l} S_{2l} + m_{2l+1} S_{2l+1}; accm_l = fma(dmin, pm_l, accm_l)   (block_terms / :6937-6941)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t mw = l < 2 ? mn[i][0] : mn[i][1];
+                const int ma = (int) ((mw >> ((l & 1) * 16)) & 0xffu), mb = (int) ((mw >> ((l & 1) * 16 + 8)) & 0xffu);
+                const float pm = (float) (mul24(ma, Sv[2 * l]) + mul24(mb, Sv[2 * l + 1]));
+                accm[l][i] = fmaf(Dm[i], pm, accm[l][i]);
+            }
+        }
+    }
+    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
+    const int t = t0 + m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = ((acc[0][i] + acc[4][i]) + (acc[2][i] + acc[6][i])) + ((acc[1][i] + acc[5][i]) + (acc[3][i] + acc[7][i]));
+        const float mm = (accm[0][i] + accm[2][i]) + (accm[1][i] + accm[3][i]);
+        const float val = v + mm;
+        const int row = rt * 16 + 4 * g + i;
+        if (t < a.T && row < a.nrows) {
+            const size_t o = (size_t) t * a.ldo + row;
+            a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+        }
+    }
+}
+// h[t][i] = silu(gate[t][i]) * up[t][i] — the SILU_MUL epilogue of the mat-vec kernels as its own pass (ggml_v_silu op for op)
+__global__ void __launch_bounds__(256) silu_mul_kernel(const float * __restrict__ gate, const float * __restrict__ up, float * __restrict__ h, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = v_silu(gate[i]) * up[i];
 }
 
 // grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile
@@ -1464,9 +1596,10 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 
 // ---- batched prefill launchers ------------------------------------------------------------------------------------------
 size_t bamd_blob_bytes(int K) { return BAMD_BLOB_BYTES(K >> 8); }
-void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, hipStream_t s) {
-    if (nw) hipLaunchKernelGGL((quantize_batch_kernel<true>),  dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob);
-    else    hipLaunchKernelGGL((quantize_batch_kernel<false>), dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob);
+size_t bamd_blob16_bytes(int K) { return BAMD_BLOB16_BYTES(K >> 8); }
+void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, void * blob16, hipStream_t s) {
+    if (nw) hipLaunchKernelGGL((quantize_batch_kernel<true>),  dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob, (uint8_t *) blob16);
+    else    hipLaunchKernelGGL((quantize_batch_kernel<false>), dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob, (uint8_t *) blob16);
 }
 int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s) {
     int nrg = 0;
@@ -1486,6 +1619,18 @@ int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStrea
         default: return 1;
     }
     return 0;
+}
+int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
+                            hipStream_t s) {
+    if (type != BAMD_Q4_K || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
+    bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
+    dim3 grid((T + 15) / 16, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
+    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), 0, s, a);
+    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), 0, s, a);
+    return 0;
+}
+void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, gate, up, h, n);
 }
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s) {
     hipLaunchKernelGGL(embed_batch_kernel, dim3(T), dim3(256), 0, s, tokens, (const uint8_t *) embd, embd_type, E, V, x);

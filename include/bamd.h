@@ -97,7 +97,7 @@ int bamd_janus_shortlist_test(const float * logits, int n_vocab, float cutoff, i
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
  * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */
-void bamd_set_prefill_batch(int on);
+void bamd_set_prefill_batch(int on);   /* 2 = batched, but Q4_K mat-muls on the integer-dot kernel instead of the MFMA kernel */
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.
@@ -117,6 +117,10 @@ int bamd_op_quantize_q8_K(const float * x, int64_t k, const float * norm_w, floa
 /* y[nrows] = W . Q8_K(act) (+ residual), W = GGUF-layout blocks [nrows][k] of `type`  (ggml_compute_forward_mul_mat, ggml.c:12277) */
 int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,
                         const float * residual, float * y, int mode /* 0 auto, 1 wave-per-row-group, 2 split-K */);
+/* Y[T][nrows] = rows of W . Q8_K(act_t) (+ residual[T][nrows]) for T activation rows x[T][k] through the batched prefill kernels
+ * (ggml_compute_forward_mul_mat with ne11 = T): impl 0 = integer-dot kernel (any K-quant), 1 = MFMA kernel (Q4_K, k % 1024 == 0) */
+int bamd_op_mul_mat_batch(int type, const void * w_raw, int nrows, int k, const float * x, int T, const float * norm_w, float eps,
+                          const float * residual, float * y, int impl);
 /* y[nrows] = silu(Wg . a) * (Wu . a)  (llm_build_ffn LLM_FFN_SILU/LLM_FFN_PAR, llama.cpp:7960-8085) */
 int bamd_op_ffn_gate_up(int type, const void * wg_raw, const void * wu_raw, int nrows, int k, const float * x, const float * norm_w,
                         float eps, float * y);

@@ -129,7 +129,7 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
     m = bamd.Model(p)
     toks = [(7919 * i + 13) % 1024 for i in range(37 + 22)]
     out = {}
-    for mode in (1, 0):
+    for mode in (1, 2, 0):                                   # batched with MFMA for Q4_K | batched, integer-dot only | token by token
         bamd.set_prefill_batch(mode)
         ctx = bamd.Context(m, 128)
         l1 = ctx.decode(toks[:37], 0).copy()
@@ -138,8 +138,9 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
         out[mode] = (l1, l2, l3)
         ctx.close()
     bamd.set_prefill_batch(1)
-    for a, b in zip(out[1], out[0]):
-        assert np.array_equal(bits(a), bits(b)), "max |d| = %g" % np.abs(a - b).max()
+    for mode in (1, 2):
+        for a, b in zip(out[mode], out[0]):
+            assert np.array_equal(bits(a), bits(b)), "mode %d: max |d| = %g" % (mode, np.abs(a - b).max())
     m.close()
 
 

@@ -185,3 +185,20 @@ def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
             got = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill)
         assert np.array_equal(kc, kc2) and np.array_equal(vc, vc2), "KV store differs at pos %d" % pos
         assert_bits(got, want, "attention out pos %d" % pos)
+
+
+@pytest.mark.parametrize("t,K,rows,T,impl", [(12, 1024, 64, 5, 0), (14, 2048, 40, 19, 0), (13, 1024, 24, 9, 0),
+                                               (12, 1024, 64, 16, 1), (12, 2048, 40, 21, 1), (12, 4096, 528, 37, 1), (12, 14336, 32, 16, 1)])
+def test_mul_mat_batch(bamd, po, t, K, rows, T, impl):
+    """batched prefill mat-mul (impl 0: integer-dot kernel, 1: MFMA kernel) == the reference's mul_mat per activation row, bit for bit;
+    ragged token tiles, rows % 16 != 0, residual epilogue"""
+    rng = np.random.default_rng(77 * t + K + T)
+    W = random_kquant_tensor(t, K, rows, rng)
+    X = (rng.standard_normal((T, K)) * 3).astype(np.float32)
+    res = rng.standard_normal((T, rows)).astype(np.float32) if T % 2 else None
+    got = bamd.op_mul_mat_batch(t, W, rows, K, X, residual=res, impl=impl)
+    for i in range(T):
+        want = po.mul_mat_q(t, W, rows, K, X[i], nthreads=8)[0]
+        if res is not None:
+            want = want + res[i]
+        assert_bits(got[i], want, "mul_mat_batch type %d K %d T %d impl %d token %d" % (t, K, T, impl, i))

@@ -12,7 +12,7 @@ if not os.path.exists(path):
 m = b.Model(path)
 toks = [(7919 * i + 13) % 128256 for i in range(n)]
 res = {}
-for mode, reps in ((1, 3), (0, 1)):
+for mode, reps in ((1, 3), (2, 2), (0, 1)):
     b.set_prefill_batch(mode)
     ctx = b.Context(m, 2048 if n <= 2044 else 4096)
     ctx.decode(toks[:16], 0)                               # warm-up (buffer allocation)
@@ -24,7 +24,7 @@ for mode, reps in ((1, 3), (0, 1)):
         best = min(best, time.perf_counter() - t0)
     res[mode] = (best, lg.copy())
     ctx.close()
-    print("%-16s %4d tokens: %8.1f ms  %9.1f tok/s" % ("batched" if mode else "token-by-token", n, best * 1e3, n / best))
-print("logits bit-identical:", bool(np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))))
+    print("%-22s %4d tokens: %8.1f ms  %9.1f tok/s" % ({1: "batched (MFMA Q4_K)", 2: "batched (integer dot)", 0: "token-by-token"}[mode], n, best * 1e3, n / best))
+print("logits bit-identical:", bool(np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))) and bool(np.array_equal(res[2][1].view(np.uint32), res[0][1].view(np.uint32))))
 flops = 2 * 6.979e9 * n
 print("batched: %.1f TFLOP/s of mat-mul work (13.96 GFLOP/token, SURVEY 8d)" % (flops / res[1][0] / 1e12))
