@@ -1259,10 +1259,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #define BAMD_BLOB_BYTES(nb) (BAMD_ACT_RED_OFF(nb))   /* one token's Q8_K activations in the LDS layout: q8[nb][64] | S[nb][8] | yd[nb], 16-byte padded */
 
 // one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
-// f16 copy of a token's Q8_K row for the MFMA path: per super-block 8 (e) x 4 (g) groups of 8 halves, group (e, g) = the int8 of
-// sub-blocks 2g and 2g+1, chunk e, as exact f16 — one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane; then yd[nb] f32 and
-// S[nb][8] i32 as in the int8 blob.
-#define BAMD_BLOB16_BYTES(nb) ((size_t) (nb) * (512 + 4 + 32))
+// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block 528 B: 8 (e) x 4 (g) groups of 8 halves — group (e, g) = the
+// int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane — followed by
+// the four i16 pairs (S_2l, S_2l+1) of the block sums; after the nb super-blocks, yd[nb] f32.  (528 B = 132 dwords: the MFMA
+// kernel stages these records in LDS, and 132 = 4 mod 64 makes its 16-byte reads bank-conflict free.)
+#define BAMD_B16_REC 528
+#define BAMD_BLOB16_BYTES(nb) ((size_t) (nb) * (BAMD_B16_REC + 4))
 template <bool NORM>
 __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
                                                              uint8_t * __restrict__ blob, uint8_t * __restrict__ blob16) {
@@ -1284,11 +1286,14 @@ __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __res
             const uint32_t w = q8[i];
             const unsigned short h0 = f2h((float) (int8_t) (w)), h1 = f2h((float) (int8_t) (w >> 8)), h2 = f2h((float) (int8_t) (w >> 16)), h3 = f2h((float) (int8_t) (w >> 24));
             uint2 v; v.x = (uint32_t) h0 | ((uint32_t) h1 << 16); v.y = (uint32_t) h2 | ((uint32_t) h3 << 16);
-            *(uint2 *) (o + (size_t) ((ci * 8 + e) * 4 + (c >> 1)) * 16 + (c & 1) * 8) = v;
+            *(uint2 *) (o + (size_t) ci * BAMD_B16_REC + (size_t) (e * 4 + (c >> 1)) * 16 + (c & 1) * 8) = v;
         }
-        float * oyd = (float *) (o + (size_t) nb * 512); int * oS = (int *) (o + (size_t) nb * 516);
+        for (int i = threadIdx.x; i < nb * 4; i += blockDim.x) {           // (S_2l, S_2l+1) as i16 pairs: |S| <= 32 * 127
+            const int ci = i >> 2, l = i & 3;
+            *(uint32_t *) (o + (size_t) ci * BAMD_B16_REC + 512 + l * 4) = ((uint32_t) S[ci * 8 + 2 * l] & 0xffffu) | ((uint32_t) S[ci * 8 + 2 * l + 1] << 16);
+        }
+        float * oyd = (float *) (o + (size_t) nb * BAMD_B16_REC);
         for (int i = threadIdx.x; i < nb; i += blockDim.x) oyd[i] = yd[i];
-        for (int i = threadIdx.x; i < nb * 8; i += blockDim.x) oS[i] = S[i];
     }
 }
 
@@ -1373,91 +1378,168 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
     sc47 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
     mn47 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
 }
+// Workgroup = 8 waves = 8 consecutive row tiles (128 rows) x one tile of 32 tokens (each wave: 16 rows x 2 x 16 tokens, so every A
+// fragment is built once for two MFMAs).  Per super-block:
+//   - the 32 tokens' B records (528 B each) are staged in LDS by the whole workgroup, double-buffered (one barrier per super-block);
+//   - each wave loads its two weight records in the wave-stream layout (two coalesced 16-byte-per-lane loads, prefetched one
+//     super-block ahead), transposes them into the MFMA A layout through a private, padded LDS tile, and lanes 0..15 unpack the
+//     16 row headers ONCE (d, dmin, scales, mins as i16 pairs) into LDS for the other lanes;
+//   - 8 (e) x 2 (token tiles) MFMAs; chains, min terms (v_dot2_i32_i16) and the final trees on the VALU.
+#define BAMD_MMA_NT 2
+#define BAMD_MMA_TOK (16 * BAMD_MMA_NT)
+#define BAMD_MMA_STAGE (BAMD_MMA_TOK * BAMD_B16_REC + BAMD_MMA_TOK * 4)          /* B records + yd */
+#define BAMD_MMA_WAVE_LDS (2 * 288 * 4 + 16 * 32)                                /* transposed A tile + row headers */
 template <int EPI>
 __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
-    const int lane = threadIdx.x & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
     const int nb = a.K >> 8;
     const int rt = blockIdx.y * 8 + wave;                    // row tile: rows rt*16 .. rt*16+15 = record groups 2rt, 2rt+1
-    if (rt * 16 >= a.nrows_pad) return;
-    const int t0 = blockIdx.x * 16;
-    const int tB = t0 + m < a.T ? t0 + m : a.T - 1;          // tokens past T: recompute the last one, never stored
+    const bool live = rt * 16 < a.nrows_pad;                 // dead waves still take part in the staging and the barriers
+    const int t0 = blockIdx.x * BAMD_MMA_TOK;
     const size_t b16 = BAMD_BLOB16_BYTES(nb);
-    const uint8_t * blob = a.blob16 + (size_t) tB * b16;
-    const float * ydp = (const float *) (blob + (size_t) nb * 512); const int * Sp = (const int *) (blob + (size_t) nb * 516);
-    // A side: row m of the tile
-    const uint8_t * recA = a.w + (size_t) (rt * 2 + (m >> 3)) * nb * 1152 + (size_t) ((m & 7) * 8) * 16 + g * 4;
-    const uint8_t * hdrA = a.w + (size_t) (rt * 2 + (m >> 3)) * nb * 1152 + 1024 + (m & 7) * 16;
-    // C side: rows 4g + i of the tile
-    const uint8_t * hdrC[4];
+    unsigned char * stage = smem;                                            // [2][BAMD_MMA_STAGE]
+    uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
+    uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
+    // staging plan: 33 uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
+    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = 4 * g + i; hdrC[i] = a.w + (size_t) (rt * 2 + (r >> 3)) * nb * 1152 + 1024 + (r & 7) * 16; }
-    bamd_f4 acc[8], accm[4];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-    for (int l = 0; l < 4; ++l) accm[l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
-    for (int ci = 0; ci < nb; ++ci) {
-        const size_t ro = (size_t) ci * 1152;
-        // scales of MY A row for sub-blocks 2g, 2g+1 as f16 pairs (s, s) and (-1024 s, -1024 s)
-        const uint4 ha = *(const uint4 *) (hdrA + ro);
-        uint32_t sc03, sc47, mn03, mn47; unpack_k4_(ha.y, ha.z, ha.w, sc03, sc47, mn03, mn47);
-        const uint32_t scw = (g < 2 ? sc03 : sc47) >> (16 * (g & 1));
-        const _Float16 s_lo = (_Float16) (float) (scw & 0xffu), s_hi = (_Float16) (float) ((scw >> 8) & 0xffu);
-        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-        const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
-        const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
-        // d, dmin, mins of the four C rows; yd, S of my token
-        float D[4], Dm[4]; uint32_t mn[4][2];
-        const float ydv = ydp[ci];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 hc = *(const uint4 *) (hdrC[i] + ro);
-            D[i] = ydv * h2f(hc.x & 0xffffu);
-            Dm[i] = (-ydv) * h2f(hc.x >> 16);
-            uint32_t c03, c47; unpack_k4_(hc.y, hc.z, hc.w, c03, c47, mn[i][0], mn[i][1]);
-        }
-        const int4 S0 = *(const int4 *) (Sp + ci * 8), S1 = *(const int4 *) (Sp + ci * 8 + 4);
-        const int Sv[8] = { S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w };
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t wq = __builtin_nontemporal_load((const uint32_t *) (recA + ro + e * 16));
-            const uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
-            // bytes -> (1024 + n) as f16 pairs, then (1024 + n) * s - 1024 * s = n * s exactly (one rounding of an exact value)
-            const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u), p1 = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
-            const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u), p3 = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
-            union { uint32_t u; h2_t h; } c0, c1, c2, c3; c0.u = p0; c1.u = p1; c2.u = p2; c3.u = p3;
-            const h2_t a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2), a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
-            const h2_t a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2), a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
-            bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
-            const bamd_h8 bv = *(const bamd_h8 *) (blob + (size_t) ((ci * 8 + e) * 4 + g) * 16);
-            const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
-            const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, z, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[e][i] = fmaf(D[i], si[i], acc[e][i]);
-        }
-        // min terms: pm_l = m_{2l} S_{2l} + m_{2l+1} S_{2l+1}; accm_l = fma(dmin, pm_l, accm_l)   (block_terms / :6937-6941)
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t mw = l < 2 ? mn[i][0] : mn[i][1];
-                const int ma = (int) ((mw >> ((l & 1) * 16)) & 0xffu), mb = (int) ((mw >> ((l & 1) * 16 + 8)) & 0xffu);
-                const float pm = (float) (mul24(ma, Sv[2 * l]) + mul24(mb, Sv[2 * l + 1]));
-                accm[l][i] = fmaf(Dm[i], pm, accm[l][i]);
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < BAMD_MMA_TOK * 33) {
+                const int tok = idx / 33, q = idx - tok * 33;
+                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
             }
         }
-    }
-    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
-    const int t = t0 + m;
+        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    };
+    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
+        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float v = ((acc[0][i] + acc[4][i]) + (acc[2][i] + acc[6][i])) + ((acc[1][i] + acc[5][i]) + (acc[3][i] + acc[7][i]));
-        const float mm = (accm[0][i] + accm[2][i]) + (accm[1][i] + accm[3][i]);
-        const float val = v + mm;
-        const int row = rt * 16 + 4 * g + i;
-        if (t < a.T && row < a.nrows) {
-            const size_t o = (size_t) t * a.ldo + row;
-            a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
+        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
+    };
+    const int rtc = live ? rt : 0;
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1152, * rec1 = rec0 + (size_t) nb * 1152;     // record groups of rows 0-7 / 8-15
+    const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + 1024 + (m & 7) * 16;                                    // header of row m (lanes g == 0)
+    bamd_f4 acc[BAMD_MMA_NT][8], accm[BAMD_MMA_NT][4];
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int l = 0; l < 4; ++l) accm[n][l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    }
+    // prologue: stage super-block 0, prefetch the weights of super-block 0
+    uint4 sr[3]; float sy = 0.f;
+    stage_issue(0, sr, sy);
+    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
+    stage_commit(0, sr, sy);
+    __syncthreads();
+    for (int ci = 0; ci < nb; ++ci) {
+        const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
+        const bool more = ci + 1 < nb;
+        if (more) stage_issue(ci + 1, sr, sy);               // global loads of the next stage in flight during the math
+        // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
+        {
+            const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
+            *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
+            *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
+            if (g == 0) {                                    // lanes 0..15: row m
+                uint32_t sc03, sc47, mn03, mn47; unpack_k4_(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+                uint4 h0, h1;
+                h0.x = hd.x; h0.y = sc03; h0.z = sc47; h0.w = 0u;
+                h1.x = __builtin_amdgcn_perm(0u, mn03, 0x0c010c00u); h1.y = __builtin_amdgcn_perm(0u, mn03, 0x0c030c02u);
+                h1.z = __builtin_amdgcn_perm(0u, mn47, 0x0c010c00u); h1.w = __builtin_amdgcn_perm(0u, mn47, 0x0c030c02u);
+                *(uint4 *) (hl + m * 8) = h0; *(uint4 *) (hl + m * 8 + 4) = h1;
+            }
+        }
+        if (more) {                                          // prefetch the next super-block's weights
+            const uint32_t ro = (uint32_t) (ci + 1) * 1152u;
+            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
+        }
+        // headers of the four C rows 4g + i; d products per token tile
+        float D[BAMD_MMA_NT][4], Dm[BAMD_MMA_NT][4]; uint4 mp[4];
+        {
+            float dw[4], dmw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t dd = hl[(4 * g + i) * 8];
+                dw[i] = h2f(dd & 0xffffu); dmw[i] = h2f(dd >> 16);
+                mp[i] = *(const uint4 *) (hl + (4 * g + i) * 8 + 4);
+            }
+#pragma unroll
+            for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                const float ydv = *(const float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + (n * 16 + m) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { D[n][i] = ydv * dw[i]; Dm[n][i] = (-ydv) * dmw[i]; }
+            }
+        }
+        // A fragment of row m per e (scales of sub-blocks 2g, 2g+1 as f16; A = (1024 + n) * s - 1024 * s = n * s exactly), used for
+        // both token tiles, then the chains
+        {
+            const uint32_t scw = hl[m * 8 + 1 + (g >> 1)] >> (16 * (g & 1));
+            const _Float16 s_lo = (_Float16) (float) (scw & 0xffu), s_hi = (_Float16) (float) ((scw >> 8) & 0xffu);
+            const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
+            const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
+            const uint32_t * wrow = wl + (m >> 3) * 288 + (m & 7) * 36 + g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t wq = wrow[e * 4];
+                const uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+                union { uint32_t u; h2_t h; } c0, c1, c2, c3;
+                c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
+                c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
+                const h2_t a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2), a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
+                const h2_t a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2), a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+                const bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                    const bamd_h8 bv = *(const bamd_h8 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + (e * 4 + g) * 16);
+                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, z, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], si[i], acc[n][e][i]);
+                }
+            }
+        }
+        // min terms: pm_l = m_2l S_2l + m_2l+1 S_2l+1 (one v_dot2_i32_i16); accm_l = fma(dmin, pm_l, accm_l)   (:6937-6941)
+#pragma unroll
+        for (int n = 0; n < BAMD_MMA_NT; ++n) {
+            const uint4 sp = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 512);
+            const uint32_t spl[4] = { sp.x, sp.y, sp.z, sp.w };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t mpl[4] = { mp[i].x, mp[i].y, mp[i].z, mp[i].w };
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l];
+                    const float pm = (float) __builtin_amdgcn_sdot2(ma.v, sb.v, 0, false);
+                    accm[n][l][i] = fmaf(Dm[n][i], pm, accm[n][l][i]);
+                }
+            }
+        }
+        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        __syncthreads();                                     // next stage visible; this stage and the wave tiles free again
+    }
+    if (!live) return;
+    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+        const int t = t0 + n * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
+            const float mm = (accm[n][0][i] + accm[n][2][i]) + (accm[n][1][i] + accm[n][3][i]);
+            const float val = v + mm;
+            const int row = rt * 16 + 4 * g + i;
+            if (t < a.T && row < a.nrows) {
+                const size_t o = (size_t) t * a.ldo + row;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+            }
         }
     }
 }
@@ -1624,9 +1706,10 @@ int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrow
                             hipStream_t s) {
     if (type != BAMD_Q4_K || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
     bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
-    dim3 grid((T + 15) / 16, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
-    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), 0, s, a);
-    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), 0, s, a);
+    dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
+    const size_t lds = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
+    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds, s, a);
+    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds, s, a);
     return 0;
 }
 void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s) {
