@@ -47,37 +47,13 @@ __device__ unsigned long long g_stamps[64 * 16];
 
 __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short) bits16)); }
 __device__ __forceinline__ unsigned short f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
-// v_dot4_i32_i8 with an inline-constant 0 accumulator (the builtin lowers to v_dot4c + a v_mov 0 per call)
-__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) {
-#ifdef BAMD_ASM_DOT4
-    int r;
-    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false);
-#endif
-}
-// Eight independent 4 x int8 dot products with a zero accumulator.  hipcc selects v_dot4c (accumulate-into-destination) for
-// __builtin_amdgcn_sdot4(a, b, 0) and spends a v_mov 0 per product; the VOP3P form takes the zero as an inline constant.  The
-// block ends with the wait states a DOT result needs before another VALU instruction may read it (the compiler does not look
-// inside an asm statement).  Verified against the builtin by tools/dot4_probe.cpp.
-__device__ __forceinline__ void sdot4x8(int (&d)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {
-    asm("v_dot4_i32_i8 %0, %8, %16, 0\n\t"
-        "v_dot4_i32_i8 %1, %9, %17, 0\n\t"
-        "v_dot4_i32_i8 %2, %10, %18, 0\n\t"
-        "v_dot4_i32_i8 %3, %11, %19, 0\n\t"
-        "v_dot4_i32_i8 %4, %12, %20, 0\n\t"
-        "v_dot4_i32_i8 %5, %13, %21, 0\n\t"
-        "v_dot4_i32_i8 %6, %14, %22, 0\n\t"
-        "v_dot4_i32_i8 %7, %15, %23, 0\n\t"
-        "s_nop 2"
-        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
-          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
-}
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false); }
 // sum_j scale_j * dot4(w_j, a_j) over the 8 sub-blocks a lane covers in one super-block: the 8 scale bytes are the bytes of (s0, s1),
 // unsigned (Q4_K/Q5_K 6-bit scales) or signed (Q6_K int8 scales).  One asm block: 8 VOP3P dots, 8 SDWA multiplies that pick their
 // scale byte directly (no extraction instructions), 4 adds.  Every product is >= 8 instructions behind its dot: no wait states needed.
+// hipcc selects v_dot4c (accumulate-into-destination) for __builtin_amdgcn_sdot4(a, b, 0) and spends a v_mov 0 per product and a
+// v_bfe per scale byte; the VOP3P form takes the zero as an inline constant (checked against the builtin by tools/dot4_probe.cpp; a
+// DOT result needs 3 wait states before another VALU instruction reads it, which the 8-instruction distance provides).
 // Exact integer arithmetic: any association gives the reference's int32 (ggml-quants.c:6950-6968, :8190-8216).
 template <bool SIGNED>
 __device__ __forceinline__ int dotscale8(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t s0, uint32_t s1) {
