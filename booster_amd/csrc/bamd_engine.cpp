@@ -444,10 +444,10 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     bamd_model * m = c->m;
     const bool mfma_ok = g_prefill_mfma && (a.K % 1024) == 0;
     if (epi == BAMD_EPI_SILU_MUL) {
-        if (mfma_ok && a.seg[0].type == BAMD_Q4_K && a.seg[1].type == BAMD_Q4_K) {
+        if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
             const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
-            if (bamd_launch_matmul_mfma(a.seg[0].w, BAMD_Q4_K, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, a.ldo, s)) return 1;   // gate -> h
-            if (bamd_launch_matmul_mfma(a.seg[1].w, BAMD_Q4_K, nv, a.seg[1].nrows, a.K, c->bblob16, T, c->bu, nullptr, a.ldo, s)) return 1;          // up
+            if (bamd_launch_matmul_mfma(a.seg[0].w, a.seg[0].type, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, a.ldo, s)) return 1;   // gate -> h
+            if (bamd_launch_matmul_mfma(a.seg[1].w, a.seg[1].type, nv, a.seg[1].nrows, a.K, c->bblob16, T, c->bu, nullptr, a.ldo, s)) return 1;          // up
             bamd_launch_silu_mul(a.seg[0].out, c->bu, a.seg[0].out, (size_t) T * a.ldo, s);
             return 0;
         }
@@ -455,10 +455,10 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     }
     bamd_mm_args rest = a; rest.nseg = 0;
     for (int i = 0; i < a.nseg; ++i) {
-        if (mfma_ok && a.seg[i].type == BAMD_Q4_K) {
+        if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q6_K)) {
             const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
             const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
-            if (bamd_launch_matmul_mfma(a.seg[i].w, BAMD_Q4_K, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, a.ldo, s)) return 1;
+            if (bamd_launch_matmul_mfma(a.seg[i].w, a.seg[i].type, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, a.ldo, s)) return 1;
         } else rest.seg[rest.nseg++] = a.seg[i];
     }
     if (rest.nseg) {

@@ -1519,6 +1519,153 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         }
     }
 }
+// ---- Q6_K x Q8_K on the matrix cores, exact: same skeleton as matmul_mfma_q4k_kernel -----------------------------------------
+// scale (int8) x (q6 - 32) reaches 4096 in magnitude: not every such integer is an f16.  With u = q6 in [0, 63]:
+//   q6 - 32 = 2 (u >> 1) - 32 + (u & 1) = 2 vh + vl,  vh = (u >> 1) - 16 in [-16, 15],  vl = u & 1,
+// so A_h = scale * vh (|.| <= 2048) and A_l = scale * vl (|.| <= 128) are exact f16, TWO MFMAs per e give S_h, S_l (< 2^24), and
+// isum = 2 S_h + S_l (< 2^24) is exact as fmaf(2, S_h, S_l).  Scales are per 16 elements: for SIMD lane e the sub-block c uses
+// scales[2c + (e >= 4)] (ggml-quants.c:8145-8216); no min terms.  Wave-stream Q6_K record: bamd_formats.h.
+#define BAMD_MMA6_WAVE_LDS ((2 * 288 + 2 * 144 + 16 * 8) * 4)                    /* ql tile + qh tile + row headers */
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    const int nb = a.K >> 8;
+    const int rt = blockIdx.y * 8 + wave;
+    const bool live = rt * 16 < a.nrows_pad;
+    const int t0 = blockIdx.x * BAMD_MMA_TOK;
+    const size_t b16 = BAMD_BLOB16_BYTES(nb);
+    unsigned char * stage = smem;
+    uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA6_WAVE_LDS);    // ql tile [2][288]
+    uint32_t * ql2 = wl + 2 * 288;                                                           // qh tile [2][144]
+    uint32_t * hl = ql2 + 2 * 144;                                                           // row headers [16][8]
+    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < BAMD_MMA_TOK * 33) {
+                const int tok = idx / 33, q = idx - tok * 33;
+                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
+            }
+        }
+        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    };
+    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
+        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
+        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
+    };
+    const int rtc = live ? rt : 0;
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = rec0 + (size_t) nb * 1680;
+    const uint8_t * recm = m < 8 ? rec0 : rec1;                                             // record group of row m (lanes g == 0)
+    bamd_f4 acc[BAMD_MMA_NT][8];
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    }
+    uint4 sr[3]; float sy = 0.f;
+    stage_issue(0, sr, sy);
+    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u);
+    uint2 qa = ldnt<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldnt<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
+    uint4 hsc = *(const uint4 *) (recm + 1536 + (m & 7) * 16); uint32_t hd = *(const unsigned short *) (recm + 1664 + (m & 7) * 2);
+    stage_commit(0, sr, sy);
+    __syncthreads();
+    for (int ci = 0; ci < nb; ++ci) {
+        const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
+        const bool more = ci + 1 < nb;
+        if (more) stage_issue(ci + 1, sr, sy);
+        {
+            const int r = lane >> 3, e = lane & 7;
+            *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
+            *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
+            *(uint2 *) (ql2 + 0 * 144 + r * 18 + e * 2) = qa;
+            *(uint2 *) (ql2 + 1 * 144 + r * 18 + e * 2) = qb;
+            if (g == 0) { *(uint4 *) (hl + m * 8) = hsc; hl[m * 8 + 4] = hd; }
+        }
+        if (more) {
+            const uint32_t ro = (uint32_t) (ci + 1) * 1680u;
+            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u);
+            qa = ldnt<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldnt<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
+            hsc = *(const uint4 *) (recm + ro + 1536 + (m & 7) * 16); hd = *(const unsigned short *) (recm + ro + 1664 + (m & 7) * 2);
+        }
+        float D[BAMD_MMA_NT][4];
+        {
+            float dw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[i] = h2f(hl[(4 * g + i) * 8 + 4]);
+#pragma unroll
+            for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                const float ydv = *(const float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + (n * 16 + m) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) D[n][i] = ydv * dw[i];
+            }
+        }
+        {
+            // int8 scales of sub-blocks c = 2g, 2g+1 for the two e-halves: header byte hi*8 + c
+            h2_t sA[2], sB[2];
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const uint32_t w = hl[m * 8 + hi * 2 + (g >> 1)] >> (16 * (g & 1));
+                const _Float16 s0 = (_Float16) (float) (int) (int8_t) (w & 0xffu), s1 = (_Float16) (float) (int) (int8_t) ((w >> 8) & 0xffu);
+                sA[hi] = (h2_t) { s0, s0 }; sB[hi] = (h2_t) { s1, s1 };
+            }
+            const h2_t k1040 = { (_Float16) 1040.f, (_Float16) 1040.f };
+            const us2_t one16 = { 0x3c00, 0x3c00 };
+            const int sh = 4 * (g & 1);
+            const uint32_t * wq = wl + (m >> 3) * 288 + (m & 7) * 36 + 2 * (g >> 1);
+            const uint32_t * hq = ql2 + (m >> 3) * 144 + (m & 7) * 18 + (g >> 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint2 ab = *(const uint2 *) (wq + e * 4);
+                const uint32_t h = hq[e * 2];
+                const uint32_t uA = ((ab.x >> sh) & 0x0f0f0f0fu) | (((h >> sh) & 0x03030303u) << 4);          // q6 of sub-block 2g, chunk e
+                const uint32_t uB = ((ab.y >> sh) & 0x0f0f0f0fu) | (((h >> (sh + 2)) & 0x03030303u) << 4);    // sub-block 2g + 1
+                const uint32_t hA = (uA >> 1) & 0x1f1f1f1fu, hB = (uB >> 1) & 0x1f1f1f1fu, lA = uA & 0x01010101u, lB = uB & 0x01010101u;
+                const h2_t sa = sA[e >> 2], sb = sB[e >> 2];
+                union { uint32_t u; h2_t h; us2_t s; } c0, c1, c2, c3, d0, d1, d2, d3;
+                c0.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04030402u);
+                c2.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04030402u);
+                d0.u = __builtin_amdgcn_perm(0u, lA, 0x0c010c00u); d1.u = __builtin_amdgcn_perm(0u, lA, 0x0c030c02u);   // 0 / 1 as u16 pairs
+                d2.u = __builtin_amdgcn_perm(0u, lB, 0x0c010c00u); d3.u = __builtin_amdgcn_perm(0u, lB, 0x0c030c02u);
+                d0.s = d0.s * one16; d1.s = d1.s * one16; d2.s = d2.s * one16; d3.s = d3.s * one16;                       // -> f16 0.0 / 1.0
+                const h2_t ah0 = (c0.h - k1040) * sa, ah1 = (c1.h - k1040) * sa, ah2 = (c2.h - k1040) * sb, ah3 = (c3.h - k1040) * sb;   // exact, |.| <= 2048
+                const h2_t al0 = d0.h * sa, al1 = d1.h * sa, al2 = d2.h * sb, al3 = d3.h * sb;
+                const bamd_h8 avh = { ah0.x, ah0.y, ah1.x, ah1.y, ah2.x, ah2.y, ah3.x, ah3.y };
+                const bamd_h8 avl = { al0.x, al0.y, al1.x, al1.y, al2.x, al2.y, al3.x, al3.y };
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                    const bamd_h8 bv = *(const bamd_h8 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + (e * 4 + g) * 16);
+                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    const bamd_f4 sh_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bv, z, 0, 0, 0);
+                    const bamd_f4 sl_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bv, z, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], fmaf(2.0f, sh_[i], sl_[i]), acc[n][e][i]);
+                }
+            }
+        }
+        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        __syncthreads();
+    }
+    if (!live) return;
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+        const int t = t0 + n * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float val = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
+            const int row = rt * 16 + 4 * g + i;
+            if (t < a.T && row < a.nrows) {
+                const size_t o = (size_t) t * a.ldo + row;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+            }
+        }
+    }
+}
 // h[t][i] = silu(gate[t][i]) * up[t][i] — the SILU_MUL epilogue of the mat-vec kernels as its own pass (ggml_v_silu op for op)
 __global__ void __launch_bounds__(256) silu_mul_kernel(const float * __restrict__ gate, const float * __restrict__ up, float * __restrict__ h, size_t n) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1680,9 +1827,15 @@ int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStrea
 }
 int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
                             hipStream_t s) {
-    if (type != BAMD_Q4_K || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
+    if ((type != BAMD_Q4_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
     bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
     dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
+    if (type == BAMD_Q6_K) {
+        const size_t lds6 = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA6_WAVE_LDS;
+        if (res) hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds6, s, a);
+        else     hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds6, s, a);
+        return 0;
+    }
     const size_t lds = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
     if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds, s, a);
     else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds, s, a);
