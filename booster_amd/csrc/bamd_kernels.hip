@@ -1719,6 +1719,128 @@ __global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
     }
 }
 
+// ---- batched prefill attention: one workgroup per (KV head, token) computes ALL GQH query heads that share the KV head -------
+// Same arithmetic per (token, head) as attn_fused_kernel in its T > 1 mode (q rounded to f16, ggml_vec_dot_f16 order for the scores,
+// softmax with the reference's 8-wide partial sums, tinyBLAS chains for P.V), but every K row and V^T chunk is loaded once for the
+// GQH heads, and the token's own K/V are already in the cache (kv_store_batch_kernel).  Dynamic LDS: GQH x 2 x n_ctx floats.
+template <int GQH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_kernel(bamd_attn_args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[GQH][256];
+    __shared__ float redf[GQH][8];
+    __shared__ double redd[GQH][8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
+    float * sc = (float *) attn_dyn;                                         // [GQH][n_ctx] scores, then exp values
+    float * pt = sc + (size_t) GQH * a.n_ctx;                                // [GQH][n_ctx] probabilities in V^T position order
+    const bamd_step_state * st = a.st;
+    const int tokb = blockIdx.y;
+    const int pos = st->pos + tokb;
+    int n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    const int hk = blockIdx.x, h0 = hk * GQH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    const int r_pos = wave * 8 + (lane >> 3);
+    const float * q = a.q + (size_t) tokb * a.ld_qkv + (size_t) h0 * hd;
+    const float * rope = a.rope + (size_t) pos * hd;
+    // RoPE of the GQH query heads -> f16, chain-major (rope_heads arithmetic; only the f16 copy is needed at T > 1)
+    for (int i = tid; i < GQH * (hd / 2); i += blockDim.x) {
+        const int hh = i / (hd / 2), p = i - hh * (hd / 2);
+        const float c = rope[2 * p], sn = rope[2 * p + 1];
+        const float x0 = q[hh * hd + 2 * p], x1 = q[hh * hd + 2 * p + 1];
+        const float t0 = x0 * c, t1 = x1 * sn, t2 = x0 * sn, t3 = x1 * c;
+        q16t[hh][kperm(2 * p, L)] = f2h(t0 - t1); q16t[hh][kperm(2 * p + 1, L)] = f2h(t2 + t3);
+    }
+    __syncthreads();
+    // ---- scores: K row i once, GQH chains ----
+    for (int t0 = 0; t0 < n_kv; t0 += 64) {
+        const int i = t0 + r_pos;
+        const bool valid = i < n_kv && i <= pos;
+        uint4 kl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kl[g] = (valid && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int hh = 0; hh < GQH; ++hh) {
+            float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
+            if (valid) v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
+            if (e == 0 && i < n_kv) sc[(size_t) hh * n_ctx + i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- softmax per head (ggml.c:13682-13778 + :2619-2671) ----
+    const float scale = a.kq_scale;
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        const float * s_ = sc + (size_t) hh * n_ctx;
+        float mx = -INFINITY;
+        for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s_[i] * scale; mx = w > mx ? w : mx; }
+        uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        u = wave_max_u32(u);
+        if (lane == 0) redf[hh][wave] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        float * s_ = sc + (size_t) hh * n_ctx;
+        float mx = redf[hh][0];
+        for (int w = 1; w < 8; ++w) mx = redf[hh][w] > mx ? redf[hh][w] : mx;
+        double sum = 0.0;
+        for (int i = tid; i < n_kv; i += blockDim.x) {             // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+            const float w = s_[i] * scale;
+            const float val = v_expf(w - mx);
+            s_[i] = val;
+            const float c = hsum8_tinyblas(val);
+            if (e == 0) sum += (double) c;
+        }
+        sum = wave_sum_f64(sum);
+        if (lane == 0) redd[hh][wave] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        const float * s_ = sc + (size_t) hh * n_ctx; float * p_ = pt + (size_t) hh * n_ctx;
+        double tot = 0.0;
+        for (int w = 0; w < 8; ++w) tot += redd[hh][w];
+        const float fs = (float) (1.0 / tot);
+        for (int i = tid; i < n_kv; i += blockDim.x) p_[vperm(i)] = s_[i] * fs;
+        for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) p_[vperm(i)] = 0.f;   // half-filled last block: exact no-ops
+    }
+    __syncthreads();
+    // ---- P.V: V^T chunk once, GQH chains; lane (d, e) carries Cv[e] of output d, up to 4 rows d per lane ----
+    float acc[GQH][4];
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) { acc[hh][0] = 0.f; acc[hh][1] = 0.f; acc[hh][2] = 0.f; acc[hh][3] = 0.f; }
+    for (int b0 = 0; b0 < n_kv; b0 += 64) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            if (r_pos + 64 * dd < hd) {
+                const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
+                const uint32_t w[4] = { vv.x, vv.y, vv.z, vv.w };
+                float vf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vf[u] = h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+#pragma unroll
+                for (int hh = 0; hh < GQH; ++hh) {
+                    const float * p_ = pt + (size_t) hh * n_ctx + b0 + e * 8;
+                    const float4 pa = *(const float4 *) p_, pb = *(const float4 *) (p_ + 4);
+                    const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+                    float c = acc[hh][dd];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c = fmaf(vf[u], pv[u], c);
+                    acc[hh][dd] = c;
+                }
+            }
+        }
+    }
+    float * out = a.out + (size_t) tokb * a.ld_out + (size_t) h0 * hd;
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = r_pos + 64 * dd;
+            if (d < hd) { const float v = hsum8_tinyblas(acc[hh][dd]); if (e == 0) out[(size_t) hh * hd + d] = v; }
+        }
+    }
+}
+
 // batched prefill: RoPE(K) + KV store of every token of the micro-batch, before any of them attends (grid (Hkv, T))
 __global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
@@ -1852,7 +1974,13 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_BATCH_MAX || !a.batch) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+    // all query heads of a KV head in one workgroup while their score buffers fit the LDS; else one workgroup per query head
+    const size_t lds_g = (size_t) gq * a.n_ctx * 8;
+    if (lds_g <= 144 * 1024 && (gq == 2 || gq == 4 || gq == 8)) {
+        if (gq == 2)      hipLaunchKernelGGL((attn_batch_kernel<2>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+        else if (gq == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+        else              hipLaunchKernelGGL((attn_batch_kernel<8>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+    } else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
     return 0;
 }
 

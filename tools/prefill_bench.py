@@ -24,7 +24,7 @@ for mode, reps in ((1, 3), (2, 2), (0, 1)):
         best = min(best, time.perf_counter() - t0)
     res[mode] = (best, lg.copy())
     ctx.close()
-    print("%-22s %4d tokens: %8.1f ms  %9.1f tok/s" % ({1: "batched (MFMA Q4_K)", 2: "batched (integer dot)", 0: "token-by-token"}[mode], n, best * 1e3, n / best))
+    print("%-22s %4d tokens: %8.1f ms  %9.1f tok/s" % ({1: "batched (MFMA)", 2: "batched (integer dot)", 0: "token-by-token"}[mode], n, best * 1e3, n / best))
 print("logits bit-identical:", bool(np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))) and bool(np.array_equal(res[2][1].view(np.uint32), res[0][1].view(np.uint32))))
 flops = 2 * 6.979e9 * n
 print("batched: %.1f TFLOP/s of mat-mul work (13.96 GFLOP/token, SURVEY 8d)" % (flops / res[1][0] / 1e12))
