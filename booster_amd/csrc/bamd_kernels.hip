@@ -177,13 +177,15 @@ struct ActPro {
 
     // the loads of this wave's first batch of blocks: issued at kernel entry, AHEAD of the bulk weight prefetch, so the
     // (tiny, latency-critical) activation read is not queued behind megabytes of weight requests
-    __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0) {
-        const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, nb = K >> 8;
+    // blocks i0, i0 + bstride, ... below blimit (defaults: this wave's share of the whole vector, interleaved over the waves)
+    __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0, int bstride = 0, int blimit = 0) {
+        const int lane = threadIdx.x & 63;
+        if (bstride == 0) { bstride = blockDim.x >> 6; blimit = K >> 8; }
 #pragma unroll
         for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
-            const int i = i0 + b * nwaves;
-            v[b] = i < nb ? *(const float4 *) (x + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NORM) w[b] = i < nb ? *(const float4 *) (nw + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = i0 + b * bstride;
+            v[b] = i < blimit ? *(const float4 *) (x + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORM) w[b] = i < blimit ? *(const float4 *) (nw + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 
@@ -194,8 +196,9 @@ struct ActPro {
     //     0x400000 offset do not touch that byte), and MIN(127, .) (:3617) never binds for |iscale * x| <= 127(1 + 2^-23);
     //   - the sum of the four signed bytes is one v_dot4 against 0x01010101;
     //   - the four wave-max chains are interleaved step by step (DPP results need wait states); row_bcast leaves the result in lane 63.
-    __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd) {
-        const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, nb = K >> 8;
+    __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd, int bstride = 0, int blimit = 0) {
+        const int lane = threadIdx.x & 63;
+        const int nwaves = bstride ? bstride : (int) (blockDim.x >> 6), nb = bstride ? blimit : (K >> 8);
         uint32_t amaxb[BAMD_ACT_BATCH];
 #pragma unroll
         for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
@@ -680,8 +683,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     const long rg_step = (long) stride * rgb;
     const int i0 = wave * NBW;                               // this wave's first super-block inside a row
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
-    ActPro<PRO == BAMD_PRO_NORM> ap;
-    if (do_pro) BAMD_PRO_ISSUE(ap, pa);                      // activation loads go out FIRST
+    // PLAIN prologue: wave w consumes only the activations of its own K-slice (blocks i0 .. i0+NBW-1), so it quantises exactly
+    // those — no workgroup barrier, and a wave starts on its records as soon as ITS blocks are done.  (NORM needs the sum of
+    // squares of the whole vector: shared prologue as in mode A.)
+    constexpr bool OWN = PRO == BAMD_PRO_PLAIN;
+    ActPro<PRO == BAMD_PRO_NORM> ap, ap2;
+    if (do_pro) {
+        if (OWN) { ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + NBW); if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + NBW); }
+        else BAMD_PRO_ISSUE(ap, pa);                         // activation loads go out FIRST
+    }
     // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
     // r0+M+m, i.e. a constant M*rg_step further on: the loader needs one wave-uniform base per batch and nothing per record
     const uint8_t * bbase = w + (long) first * rgb + (long) i0 * RECB;
@@ -695,7 +705,13 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         }
     }
     STAMP(1);
-    if (do_pro) BAMD_PRO_FINISH(ap, pa);
+    if (do_pro) {
+        if (OWN) {
+            static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");
+            ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
+            if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
+        } else BAMD_PRO_FINISH(ap, pa);
+    }
     STAMP(2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     for (int r0 = 0; r0 < count; r0 += M) {
