@@ -25,6 +25,8 @@ static thread_local std::string g_err;
 static int g_prefill_batch = [] { const char * e = getenv("BAMD_PREFILL_BATCH"); return (e && e[0] == '0') ? 0 : 1; }();
 // BAMD_PREFILL_MFMA=0: Q4_K mat-muls of the batched prefill on the integer-dot kernel instead of the MFMA kernel (same bits)
 static int g_prefill_mfma = [] { const char * e = getenv("BAMD_PREFILL_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
+// BAMD_STAGE_GRAPH=0: bamd_stage_step enqueues its kernels one by one instead of replaying a captured hipGraph
+static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
@@ -113,6 +115,9 @@ struct bamd_context {
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr;
+    // stage-step graphs (bamd_stage_step): one per (want_logits, prefill_mode), valid for the pointers it was captured with
+    struct StageGraph { hipGraphExec_t exec = nullptr; const void * token_src = nullptr, * hin = nullptr; void * hout = nullptr; };
+    StageGraph sgraph[2][2];
     // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
     int bcap = 0;
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr, * bu = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
@@ -328,6 +333,7 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     if (!c) return;
     if (c->m) hipSetDevice(c->m->device);
     if (c->graph) hipGraphExecDestroy(c->graph);
+    for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
     if (c->logits_host) hipHostFree(c->logits_host);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -419,6 +425,8 @@ static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_ke
     return 0;
 }
 
+extern "C" int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev, void * hidden_out_dev, int want_logits,
+                               int prefill_mode, void * hip_stream);
 // ---- batched prefill: a micro-batch of T > 1 tokens through the layers at once (llama_decode with n_tokens > 1) -----------
 #define BAMD_PREFILL_CAP 512            /* the reference's default n_batch / n_ubatch */
 static bool prefill_batch_supported(const bamd_context * c) {
@@ -527,6 +535,9 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
         if (ensure_batch_buffers(c)) return 1;
         if (enqueue_prefill_batch(c, n_tokens, n_past, s)) return 1;
         enqueue_lm_head(c, s, nullptr);                                  // n_outputs = 1: last token only (llama.cpp:14580-14593)
+    } else if (n_tokens == 1) {
+        // single token: the captured stage-step graph (state and token are two small host copies, then one graph launch)
+        if (bamd_stage_step(c, tokens[0], nullptr, n_past, nullptr, nullptr, 1, 0, s)) return 1;
     } else {
         if (set_state(c, n_past, s, false)) return 1;
         const int prefill_mode = n_tokens > 1;
@@ -594,15 +605,36 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     const int32_t * forced = c->forced;
     if (token_dev) forced = (const int32_t *) token_dev;
     else HIPC(hipMemcpyAsync(c->forced, &token, 4, hipMemcpyHostToDevice, s));
-    if (m->with_embd) bamd_launch_step_begin(c->st, forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, s);
-    else {
-        // no embedding on this stage: still advance the device state (pos, n_kv), then take the hidden state
-        bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, s);
-        HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
+    // everything after the two small host copies is a fixed launch sequence for given pointers: replay it as one hipGraph
+    // (a stage of 4 layers is ~22 launches at ~8 us of host time each; the layer-split pipeline is host-bound without this)
+    auto enqueue = [&](hipStream_t q) -> int {
+        if (m->with_embd) bamd_launch_step_begin(c->st, forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, q);
+        else {
+            // no embedding on this stage: still advance the device state (pos, n_kv), then take the hidden state
+            bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, q);
+            HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
+        }
+        if (enqueue_layers(c, prefill_mode, q, nullptr)) return 1;
+        if (m->with_output) { if (want_logits) enqueue_lm_head(c, q, nullptr); }
+        else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
+        return 0;
+    };
+    if (!g_stage_graph || s == nullptr) return enqueue(s);           // the legacy default stream cannot be captured
+    bamd_context::StageGraph & sg = c->sgraph[want_logits ? 1 : 0][prefill_mode ? 1 : 0];
+    if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+    if (!sg.exec) {
+        hipGraph_t g = nullptr;
+        HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(s);
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(std::string("stage graph capture: ") + hipGetErrorString(e));
+        const hipError_t e2 = hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e2 != hipSuccess) { sg.exec = nullptr; return fail(std::string("stage graph instantiate: ") + hipGetErrorString(e2)); }
+        sg.token_src = forced; sg.hin = hidden_in_dev; sg.hout = hidden_out_dev;
     }
-    if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
-    if (m->with_output) { if (want_logits) enqueue_lm_head(c, s, nullptr); }
-    else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, s));
+    HIPC(hipGraphLaunch(sg.exec, s));
     return 0;
 }
 // write the arg-max token of the last lm_head of this (last) stage into a device int32 — no host round trip

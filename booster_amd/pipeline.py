@@ -33,6 +33,11 @@ class HipStage:
         self.ctx = [booster_amd.Context(self.model, n_ctx) for _ in range(n_seq)]
         self.n_embd = self.model.n_embd
         self.device = torch.device("cuda", device)
+        # a side stream: stage steps replay captured hipGraphs, and the legacy default stream cannot be captured
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
 
     def new_hidden(self):
         return self.torch.zeros(self.n_embd, dtype=self.torch.float32, device=self.device)
@@ -71,6 +76,12 @@ def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset=0
 
     Returns, on rank 0, for every sequence the list of tokens FED after the prompt (n_decode of them); elsewhere empty lists.
     """
+    import contextlib
+    with (stage.stream_ctx() if hasattr(stage, "stream_ctx") else contextlib.nullcontext()):
+        return _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset)
+
+
+def _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset):
     n_prompt = len(prompt)
     total = n_prompt + n_decode                      # positions processed per sequence
     first, last = rank == 0, rank == world - 1
