@@ -22,6 +22,19 @@ def split_layers(n_layer, n_stage):
     return list(zip([0] + cuts[:-1], cuts))
 
 
+def split_layers_balanced(n_layer, n_stage, head_cost=1.35):
+    """`gpus:` weights chosen so that stage TIMES are even: the last stage also runs output_norm + lm_head, which costs about
+    `head_cost` layers of decode time on the 8B shape (431 MB of Q6_K against ~146-161 MB per layer)."""
+    if n_stage == 1:
+        return [(0, n_layer)]
+    target = (n_layer + head_cost) / n_stage
+    cuts = [int(round(target * (i + 1))) for i in range(n_stage - 1)] + [n_layer]
+    for i in range(n_stage - 1):                     # strictly increasing, at least one layer per stage (also the last one)
+        lo = (cuts[i - 1] if i else 0) + 1
+        cuts[i] = min(max(cuts[i], lo), n_layer - (n_stage - 1 - i))
+    return list(zip([0] + cuts[:-1], cuts))
+
+
 class HipStage:
     """One pipeline stage on one MI355X: booster_amd.Model slice + one Context (KV cache) per sequence in flight."""
 
@@ -144,7 +157,7 @@ def _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset)
 def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch):
     """bench.py's N > 1 leg.  Returns the dict bench.py prints (value = whole-job tokens/s with N sequences in flight)."""
     import booster_amd
-    ranges = split_layers(cfg["L"], N)
+    ranges = split_layers_balanced(cfg["L"], N)
     stage = HipStage(booster_amd, torch, path, local, ranges[rank], rank == 0, rank == N - 1, n_ctx, N)
     dist.barrier()
     # untimed: every sequence through the prompt and `warmup` + 1 decode steps.  All sequences are identical, so the token fed at

@@ -96,3 +96,7 @@ def test_split_layers():
     assert pipeline.split_layers(32, 1) == [(0, 32)]
     r = pipeline.split_layers(80, 8)
     assert r[0][0] == 0 and r[-1][1] == 80 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    for L, n in ((32, 1), (32, 2), (32, 4), (32, 8), (80, 8), (8, 8), (9, 8)):
+        b = pipeline.split_layers_balanced(L, n)
+        assert len(b) == n and b[0][0] == 0 and b[-1][1] == L and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(y > x for x, y in b)
+    assert pipeline.split_layers_balanced(32, 8)[-1] == (29, 32)           # the stage that also runs lm_head gets fewer layers
