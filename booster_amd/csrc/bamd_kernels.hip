@@ -863,7 +863,7 @@ __device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, i
     }
 }
 
-__global__ void __launch_bounds__(256) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
+__global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
                                                          int32_t * out_tokens, const uint8_t * embd, int embd_type, int E, int V,
                                                          float * x, int do_embed) {
     __shared__ int tok_s;
@@ -2006,7 +2006,7 @@ void bamd_read_stamps(unsigned long long * host) { hipMemcpyFromSymbol(host, HIP
 
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s) {
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed);
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed);
 }
 
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
