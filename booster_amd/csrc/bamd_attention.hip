@@ -1,0 +1,456 @@
+// bamd_attention.hip — attention kernels: fused single-launch (decode, n_ctx <= 2048), three-launch long-context path, batched
+// prefill attention with all query heads of a KV head per workgroup, batched KV store.  Helpers and layout: bamd_device.h.
+#include "bamd_device.h"
+
+// ---- long contexts: three launches (scores | softmax | P.V), positions / rows spread over many workgroups ------------------
+// grid (Hkv, tiles of 64 positions), block 512 = 8 waves x (8 positions x 8 lanes); the GQ query heads of a KV head share K
+template <int GQ>
+__global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
+    __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    const bamd_step_state * st = a.st;
+    const int pos = st->pos, n_kv = st->n_kv;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    const int hk = blockIdx.x;
+    const float * rope = a.rope + (size_t) pos * hd;
+    rope_heads(a.q + (size_t) hk * GQ * hd, rope, hd, GQ, qt, q16t, nullptr);
+    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
+    __syncthreads();
+    // KV store by the block that owns the tile of `pos` — llm_build_kv_store, llama.cpp:7830-7875
+    if ((int) blockIdx.y == ((pos >> 6) % (int) gridDim.y)) {
+        for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = wave_id(), e = lane & 7;
+    const int tiles = (n_kv + 63) >> 6;
+    for (int tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
+        const int i = tile * 64 + wave * 8 + (lane >> 3);        // position
+        if (i >= n_kv) continue;
+        float sc[GQ];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) sc[g] = -INFINITY;          // masked (KQ_mask, llama.cpp:14152-14200)
+        if (i <= pos) {
+            uint4 kreg[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                kreg[g] = make_uint4(0, 0, 0, 0);
+                if (g * 8 < L) kreg[g] = i == pos ? *(const uint4 *) (k16t + e * L + g * 8) : *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8);
+            }
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) {
+                const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * L) : kq_chain<false>(kreg, L, qt + g * hd + e * L, nullptr);
+                sc[g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
+            }
+        }
+        if (e == 0) {
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + i] = sc[g];
+        }
+    }
+}
+
+// softmax over n_kv scores of one head: grid (H), block 256.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
+// Probabilities are written back in the V^T position order (vperm) so the P.V lanes read them contiguously.
+__global__ void __launch_bounds__(256) attn_softmax_kernel(bamd_attn_args a) {
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    const bamd_step_state * st = a.st;
+    const int n_kv = st->n_kv, n_ctx = a.n_ctx;
+    const int h = blockIdx.x;
+    float * s = a.scores + (size_t) h * n_ctx;
+    const float scale = a.kq_scale;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) { const float w = s[i] * scale; mx = w > mx ? w : mx; }
+    for (int o = 32; o; o >>= 1) { const float om = __shfl_xor(mx, o); mx = om > mx ? om : mx; }
+    if (lane == 0) redf[wave] = mx;
+    __syncthreads();
+    mx = redf[0]; for (int w = 1; w < 4; ++w) mx = redf[w] > mx ? redf[w] : mx;
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) {
+        const float w = s[i] * scale;
+        const float val = v_expf(w - mx);
+        s[i] = val;                                              // same index this thread just read: no hazard
+        const float c = hsum8_tinyblas(val);                     // the reference's 8-wide partial sum (same tree shape)
+        if ((lane & 7) == 0) sum += (double) c;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) redd[wave] = sum;
+    __syncthreads();
+    double tot = 0.0; for (int w = 0; w < 4; ++w) tot += redd[w];
+    const float fs = (float) (1.0 / tot);
+    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) a.probs[(size_t) h * n_ctx + vperm(i)] = s[i] * fs;
+}
+
+// P.V: grid (Hkv, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d) for the GQ heads
+// that share this KV head.  sgemm.cpp:405-431 with A = V^T rows (f16), B = p (f32).
+template <int GQ>
+__global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
+    const bamd_step_state * st = a.st;
+    const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
+    const int hk = blockIdx.x;
+    const int lane = threadIdx.x, e = lane & 7;
+    const int d = blockIdx.y * 8 + (lane >> 3);
+    const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx;
+    const float * p = a.probs + (size_t) (hk * GQ) * n_ctx;
+    float acc[GQ];
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) acc[g] = 0.f;
+    for (int b0 = 0; b0 < n_kv; b0 += 64) {                      // one 64-position block = 8 chain steps per lane
+        const uint4 vv = *(const uint4 *) (vrow + b0 + e * 8);
+        const uint32_t w[4] = { vv.x, vv.y, vv.z, vv.w };
+        const int nstep = n_kv - b0 >= 64 ? 8 : (n_kv - b0) >> 3;
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            const float4 pa = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8), pb = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8 + 4);
+            const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < nstep) acc[g] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc[g]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+        const float v = hsum8_tinyblas(acc[g]);
+        if (e == 0) a.out[(size_t) (hk * GQ + g) * hd + d] = v;
+    }
+}
+
+// ---- ONE launch per layer, one workgroup per QUERY head (and per token of a prefill micro-batch) ---------------------------
+// scores and probabilities live in dynamic LDS (2 x n_ctx floats).  Single-token decode uses this kernel up to
+// BAMD_ATTN_FUSED_MAX positions (beyond that one workgroup per head no longer has the bandwidth: three-kernel path);
+// batched prefill, with T x H workgroups, up to BAMD_ATTN_BATCH_MAX.
+#define BAMD_ATTN_FUSED_MAX 2048
+#define BAMD_ATTN_BATCH_MAX 8192
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
+    __shared__ __attribute__((aligned(16))) float qt[256];
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
+    float * sc = (float *) attn_dyn;                                         // [n_ctx] scores, then exp values (natural order)
+    float * pt = sc + a.n_ctx;                                               // [n_ctx] probabilities in V^T position order
+    __shared__ float redf[8];
+    __shared__ double redd[8];
+    const bamd_step_state * st = a.st;
+    // batched prefill (a.batch): blockIdx.y = token of the micro-batch; its K/V rows and those of the earlier tokens of the batch
+    // were stored by kv_store_batch_kernel, and masked positions are exact no-ops, so each token uses its own padded length
+    const int tokb = a.batch ? (int) blockIdx.y : 0;
+    const int pos = st->pos + tokb;
+    int n_kv = st->n_kv;
+    if (a.batch) { n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx; }
+    a.q += (size_t) tokb * a.ld_qkv; a.k += (size_t) tokb * a.ld_qkv; a.v += (size_t) tokb * a.ld_qkv; a.out += (size_t) tokb * a.ld_out;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    const int h = blockIdx.x, hk = h / gq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    const float * rope = a.rope + (size_t) pos * hd;
+    STAMP(0);
+    // requests that do not depend on RoPE go out first: this lane's K chunks of the first 4 x 64 positions and its V^T chunks
+    const int r_pos = wave * 8 + (lane >> 3);                     // position inside a 64-tile (scores) / d inside a 64-block (P.V)
+    uint4 kreg[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = t * 64 + r_pos;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kreg[t][g] = (i < n_kv && i < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+    }
+    // ... and its V^T chunks: the first 4 blocks of 64 positions of rows d = r_pos and r_pos + 64 (consumed after the softmax)
+    uint4 vreg[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const int d = r_pos + 64 * dd;
+            vreg[t][dd] = (t * 64 < n_kv && d < hd) ? *(const uint4 *) (a.vc + (size_t) (hk * hd + d) * n_ctx + t * 64 + e * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    rope_heads(a.q + (size_t) h * hd, rope, hd, 1, qt, q16t, nullptr);
+    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
+    __syncthreads();
+    // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
+    if (h == hk * gq && !a.batch) {
+        for (int i = tid; i < hd; i += blockDim.x) {
+            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
+        }
+    }
+    STAMP(1);
+    // ---- scores ----
+#define BAMD_SCORE_TILE(t0_, KL_) do { \
+        const int i = (t0_) + r_pos; \
+        float v = -INFINITY;                                       /* masked (KQ_mask, llama.cpp:14152-14200) */ \
+        if (i < n_kv && i <= pos) { \
+            if (i == pos) {                                        /* this token's K row is not visible in the cache yet */ \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) if (g * 8 < L) KL_[g] = *(const uint4 *) (k16t + e * L + g * 8); \
+            } \
+            v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(KL_, L, nullptr, q16t + e * L)) : hsum8_tinyblas(kq_chain<false>(KL_, L, qt + e * L, nullptr)); \
+        } \
+        if (e == 0 && i < n_kv) sc[i] = v; \
+    } while (0)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { if (t * 64 < n_kv) BAMD_SCORE_TILE(t * 64, kreg[t]); }
+    for (int t0 = 256; t0 < n_kv; t0 += 64) {
+        const int i2 = t0 + r_pos;
+        uint4 kl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kl[g] = (i2 < n_kv && i2 < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i2 * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+        BAMD_SCORE_TILE(t0, kl);
+    }
+#undef BAMD_SCORE_TILE
+    __syncthreads();
+    STAMP(2);
+    // ---- softmax (ggml.c:13682-13778 + :2619-2671): wp = s*scale (+mask), max, exp, 8-chunk f32 sums, double total ----
+    const float scale = a.kq_scale;
+    float mx = -INFINITY;
+    for (int i = tid; i < n_kv; i += blockDim.x) { const float w = sc[i] * scale; mx = w > mx ? w : mx; }
+    {   // -inf..inf floats: order-preserving key for an unsigned max
+        uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        u = wave_max_u32(u);
+        if (lane == 0) redf[wave] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+    __syncthreads();
+    mx = redf[0];
+    for (int w = 1; w < 8; ++w) mx = redf[w] > mx ? redf[w] : mx;
+    double sum = 0.0;
+    for (int i = tid; i < n_kv; i += blockDim.x) {                 // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+        const float w = sc[i] * scale;
+        const float val = v_expf(w - mx);
+        sc[i] = val;
+        const float c = hsum8_tinyblas(val);
+        if (e == 0) sum += (double) c;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) redd[wave] = sum;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < 8; ++w) tot += redd[w];
+    const float fs = (float) (1.0 / tot);
+    for (int i = tid; i < n_kv; i += blockDim.x) pt[vperm(i)] = sc[i] * fs;
+    // half-filled last block (n_kv % 64 == 32): p = 0 for the missing positions, so the chain steps there are exact no-ops
+    for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) pt[vperm(i)] = 0.f;
+    __syncthreads();
+    STAMP(3);
+    // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (A = V^T row, B = p), up to 4 rows d per lane ----
+    const unsigned short vcur[4] = { f2h(a.v[hk * hd + (r_pos < hd ? r_pos : 0)]), f2h(a.v[hk * hd + (r_pos + 64 < hd ? r_pos + 64 : 0)]),
+                                     f2h(a.v[hk * hd + (r_pos + 128 < hd ? r_pos + 128 : 0)]), f2h(a.v[hk * hd + (r_pos + 192 < hd ? r_pos + 192 : 0)]) };
+    float acc4[4] = { 0.f, 0.f, 0.f, 0.f };
+    const int pblk = pos & ~63, pe = pos & 7, pl = (pos & 63) >> 3;   // where this token's own V element sits
+#define BAMD_PV_BLOCK(b0_, dd_, VV_) do { \
+        const float4 pa = *(const float4 *) (pt + (b0_) + e * 8), pb = *(const float4 *) (pt + (b0_) + e * 8 + 4); \
+        const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w }; \
+        uint32_t w[4] = { (VV_).x, (VV_).y, (VV_).z, (VV_).w }; \
+        if ((b0_) == pblk && e == pe) {                            /* column `pos` is being written by another workgroup: splice it in */ \
+            const uint32_t keep = (pl & 1) ? 0x0000ffffu : 0xffff0000u, ins = (pl & 1) ? (uint32_t) vcur[dd_] << 16 : (uint32_t) vcur[dd_]; \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j == (pl >> 1)) w[j] = (w[j] & keep) | ins; \
+        } \
+        float acc = acc4[dd_]; \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc); \
+        acc4[dd_] = acc; \
+    } while (0)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                                  // blocks whose V chunks were requested at kernel entry
+        if (t * 64 < n_kv) {
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) if (r_pos + 64 * dd < hd) BAMD_PV_BLOCK(t * 64, dd, vreg[t][dd]);
+#pragma unroll
+            for (int dd = 2; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {  // hd > 128
+                const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + t * 64 + e * 8);
+                BAMD_PV_BLOCK(t * 64, dd, vv);
+            }
+        }
+    }
+    for (int b0 = 256; b0 < n_kv; b0 += 64) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {
+            const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
+            BAMD_PV_BLOCK(b0, dd, vv);
+        }
+    }
+#undef BAMD_PV_BLOCK
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        const int d = r_pos + 64 * dd;
+        if (d < hd) { const float v = hsum8_tinyblas(acc4[dd]); if (e == 0) a.out[(size_t) h * hd + d] = v; }
+    }
+    STAMP(4);
+}
+
+// ---- batched prefill attention: one workgroup per (KV head, token) computes ALL GQH query heads that share the KV head -------
+// Same arithmetic per (token, head) as attn_fused_kernel in its T > 1 mode (q rounded to f16, ggml_vec_dot_f16 order for the scores,
+// softmax with the reference's 8-wide partial sums, tinyBLAS chains for P.V), but every K row and V^T chunk is loaded once for the
+// GQH heads, and the token's own K/V are already in the cache (kv_store_batch_kernel).  Dynamic LDS: GQH x 2 x n_ctx floats.
+template <int GQH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_kernel(bamd_attn_args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short q16t[GQH][256];
+    __shared__ float redf[GQH][8];
+    __shared__ double redd[GQH][8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
+    float * sc = (float *) attn_dyn;                                         // [GQH][n_ctx] scores, then exp values
+    float * pt = sc + (size_t) GQH * a.n_ctx;                                // [GQH][n_ctx] probabilities in V^T position order
+    const bamd_step_state * st = a.st;
+    const int tokb = blockIdx.y;
+    const int pos = st->pos + tokb;
+    int n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx;
+    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    const int hk = blockIdx.x, h0 = hk * GQH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    const int r_pos = wave * 8 + (lane >> 3);
+    const float * q = a.q + (size_t) tokb * a.ld_qkv + (size_t) h0 * hd;
+    const float * rope = a.rope + (size_t) pos * hd;
+    // RoPE of the GQH query heads -> f16, chain-major (rope_heads arithmetic; only the f16 copy is needed at T > 1)
+    for (int i = tid; i < GQH * (hd / 2); i += blockDim.x) {
+        const int hh = i / (hd / 2), p = i - hh * (hd / 2);
+        const float c = rope[2 * p], sn = rope[2 * p + 1];
+        const float x0 = q[hh * hd + 2 * p], x1 = q[hh * hd + 2 * p + 1];
+        const float t0 = x0 * c, t1 = x1 * sn, t2 = x0 * sn, t3 = x1 * c;
+        q16t[hh][kperm(2 * p, L)] = f2h(t0 - t1); q16t[hh][kperm(2 * p + 1, L)] = f2h(t2 + t3);
+    }
+    __syncthreads();
+    // ---- scores: K row i once, GQH chains ----
+    for (int t0 = 0; t0 < n_kv; t0 += 64) {
+        const int i = t0 + r_pos;
+        const bool valid = i < n_kv && i <= pos;
+        uint4 kl[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kl[g] = (valid && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int hh = 0; hh < GQH; ++hh) {
+            float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
+            if (valid) v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
+            if (e == 0 && i < n_kv) sc[(size_t) hh * n_ctx + i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- softmax per head (ggml.c:13682-13778 + :2619-2671) ----
+    const float scale = a.kq_scale;
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        const float * s_ = sc + (size_t) hh * n_ctx;
+        float mx = -INFINITY;
+        for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s_[i] * scale; mx = w > mx ? w : mx; }
+        uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        u = wave_max_u32(u);
+        if (lane == 0) redf[hh][wave] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        float * s_ = sc + (size_t) hh * n_ctx;
+        float mx = redf[hh][0];
+        for (int w = 1; w < 8; ++w) mx = redf[hh][w] > mx ? redf[hh][w] : mx;
+        double sum = 0.0;
+        for (int i = tid; i < n_kv; i += blockDim.x) {             // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+            const float w = s_[i] * scale;
+            const float val = v_expf(w - mx);
+            s_[i] = val;
+            const float c = hsum8_tinyblas(val);
+            if (e == 0) sum += (double) c;
+        }
+        sum = wave_sum_f64(sum);
+        if (lane == 0) redd[hh][wave] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+        const float * s_ = sc + (size_t) hh * n_ctx; float * p_ = pt + (size_t) hh * n_ctx;
+        double tot = 0.0;
+        for (int w = 0; w < 8; ++w) tot += redd[hh][w];
+        const float fs = (float) (1.0 / tot);
+        for (int i = tid; i < n_kv; i += blockDim.x) p_[vperm(i)] = s_[i] * fs;
+        for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) p_[vperm(i)] = 0.f;   // half-filled last block: exact no-ops
+    }
+    __syncthreads();
+    // ---- P.V: V^T chunk once, GQH chains; lane (d, e) carries Cv[e] of output d, up to 4 rows d per lane ----
+    float acc[GQH][4];
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) { acc[hh][0] = 0.f; acc[hh][1] = 0.f; acc[hh][2] = 0.f; acc[hh][3] = 0.f; }
+    for (int b0 = 0; b0 < n_kv; b0 += 64) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            if (r_pos + 64 * dd < hd) {
+                const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
+                const uint32_t w[4] = { vv.x, vv.y, vv.z, vv.w };
+                float vf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vf[u] = h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+#pragma unroll
+                for (int hh = 0; hh < GQH; ++hh) {
+                    const float * p_ = pt + (size_t) hh * n_ctx + b0 + e * 8;
+                    const float4 pa = *(const float4 *) p_, pb = *(const float4 *) (p_ + 4);
+                    const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+                    float c = acc[hh][dd];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c = fmaf(vf[u], pv[u], c);
+                    acc[hh][dd] = c;
+                }
+            }
+        }
+    }
+    float * out = a.out + (size_t) tokb * a.ld_out + (size_t) h0 * hd;
+#pragma unroll
+    for (int hh = 0; hh < GQH; ++hh) {
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = r_pos + 64 * dd;
+            if (d < hd) { const float v = hsum8_tinyblas(acc[hh][dd]); if (e == 0) out[(size_t) hh * hd + d] = v; }
+        }
+    }
+}
+
+// batched prefill: RoPE(K) + KV store of every token of the micro-batch, before any of them attends (grid (Hkv, T))
+__global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    const int hk = blockIdx.x, tokb = blockIdx.y;
+    const int pos = a.st->pos + tokb;
+    const int hd = a.hd, Ekv = a.Hkv * hd, n_ctx = a.n_ctx;
+    const float * k = a.k + (size_t) tokb * a.ld_qkv, * v = a.v + (size_t) tokb * a.ld_qkv;
+    rope_heads(k + (size_t) hk * hd, a.rope + (size_t) pos * hd, hd, 1, nullptr, nullptr, k16t);
+    __syncthreads();
+    for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+        a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
+        a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(v[hk * hd + i]);
+    }
+}
+
+
+// ===========================================================================================================
+// launchers
+// ===========================================================================================================
+// attention of a micro-batch of T tokens (a.batch = 1, a.ld_qkv / a.ld_out set): KV store for all tokens, then (head, token) workgroups
+int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
+    if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_BATCH_MAX || !a.batch) return 1;
+    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
+    // all query heads of a KV head in one workgroup while their score buffers fit the LDS; else one workgroup per query head
+    const size_t lds_g = (size_t) gq * a.n_ctx * 8;
+    if (lds_g <= 144 * 1024 && (gq == 2 || gq == 4 || gq == 8)) {
+        if (gq == 2)      hipLaunchKernelGGL((attn_batch_kernel<2>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+        else if (gq == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+        else              hipLaunchKernelGGL((attn_batch_kernel<8>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
+    } else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+    return 0;
+}
+
+int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
+    if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
+    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    if (a.n_ctx <= BAMD_ATTN_FUSED_MAX && max_tiles >= 0) {
+        // context fits the LDS score buffer: one fused launch per layer, one workgroup per query head
+        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+        return 0;
+    }
+    int ty = max_tiles < 0 ? -max_tiles : max_tiles;
+    if (ty < 1) ty = 1;
+    dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
+    switch (gq) {
+#define CASE(G) case G: \
+        hipLaunchKernelGGL((attn_qk_kernel<G>), g1, dim3(512), 0, s, a); \
+        hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(256), 0, s, a); \
+        hipLaunchKernelGGL((attn_pv_kernel<G>), g3, dim3(64), 0, s, a); break;
+        CASE(1) CASE(2) CASE(4) CASE(8)
+#undef CASE
+        default: return 1;
+    }
+    return 0;
+}

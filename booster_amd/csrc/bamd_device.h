@@ -1,0 +1,595 @@
+// bamd_device.h — device-side building blocks shared by the kernel files (bamd_matvec.hip, bamd_attention.hip, bamd_prefill.hip):
+// numerics helpers, the Q8_K activation prologue, wave-stream records and their block terms, the f32 chains, attention chain
+// helpers.  Everything here is __device__ __forceinline__ (or a macro / type): including it in several translation units is safe.
+//
+//
+// NUMERICS CONTRACT.  Every kernel reproduces, operation for operation, the IEEE-754 arithmetic of the
+// reference's CPU path as built for x86 AVX2+FMA+F16C with GGML_USE_LLAMAFILE (what Booster ships):
+// integer block dot products are exact; every f32 operation (which products are fused, which sums are
+// sequential chains over super-blocks, the shape of each horizontal reduction tree) is the one the
+// reference's 256-bit code performs, with one wave lane standing for one SIMD lane.  Compiled with
+// -ffp-contract=off; fused multiply-adds are explicit fmaf().  Do NOT build with -ffast-math.
+// The only deliberate deviation: the two double-precision sums (RMSNorm sum of squares, softmax denominator)
+// are tree-reduced in a fixed order instead of sequentially; their result is rounded to f32 right after, so
+// this cannot be observed except with probability ~1e-8 per reduction.
+//
+// Reference functions restated here (cpp/ = /root/reference/cpp):
+//   quantize_row_q8_K_ref            ggml/src/ggml-quants.c:3593-3630
+//   ggml_vec_dot_q4_K_q8_K (AVX2)    ggml/src/ggml-quants.c:6914-6978
+//   ggml_vec_dot_q5_K_q8_K (AVX2)    ggml/src/ggml-quants.c:7487-7564
+//   ggml_vec_dot_q6_K_q8_K (AVX2)    ggml/src/ggml-quants.c:8145-8222
+//   ggml_compute_forward_rms_norm    ggml/src/ggml.c:11850-11896
+//   ggml_compute_forward_rope_f32    ggml/src/ggml.c:14043-14167 (NORM mode)
+//   ggml_compute_forward_soft_max    ggml/src/ggml.c:13682-13778, ggml_v_expf :2490-2522
+//   ggml_v_silu / ggml_vec_silu_f32  ggml/src/ggml.c:2524-2531, :2595-2617
+//   tinyBLAS<8,..,fp16,float,float>  ggml/src/llamafile/sgemm.cpp:405-431 (KQ at T=1, KQV always)
+//   ggml_vec_dot_f16                 ggml/src/ggml.c:2038-2079 (KQ at T>1)
+//   dequantize_row_q{4,5,6}_K        ggml/src/ggml-quants.c:2548, :2756, :2970 (embedding get_rows)
+//   CUDA counterparts replaced       ggml/src/ggml-cuda/mmvq.cu:50-130, quantize.cu:4-38, norm.cu:101-131,
+//                                    rope.cu:31-69, softmax.cu:14-116, cpy.cu:33-59, unary.cu:25-32
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "bamd_formats.h"
+#include "bamd_kernels.h"
+
+#define WAVE 64
+#ifndef BAMD_SCHED_GROUP
+#define BAMD_SCHED_GROUP 1      /* records the scheduler may interleave between barriers (power of two) */
+#endif
+
+// optional in-kernel phase stamps (build with -DBAMD_TIMING): block 0 / lane 0 of each wave writes s_memtime
+#ifdef BAMD_TIMING
+static __device__ unsigned long long g_stamps[64 * 16];      // one copy per translation unit: tools/timing_*.cpp include the .hip they time
+static inline void bamd_read_stamps(unsigned long long * host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16); }
+#define STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short) bits16)); }
+__device__ __forceinline__ unsigned short f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot4((int) a, (int) b, 0, false); }
+// sum_j scale_j * dot4(w_j, a_j) over the 8 sub-blocks a lane covers in one super-block: the 8 scale bytes are the bytes of (s0, s1),
+// unsigned (Q4_K/Q5_K 6-bit scales) or signed (Q6_K int8 scales).  One asm block: 8 VOP3P dots, 8 SDWA multiplies that pick their
+// scale byte directly (no extraction instructions), 4 adds.  Every product is >= 8 instructions behind its dot: no wait states needed.
+// hipcc selects v_dot4c (accumulate-into-destination) for __builtin_amdgcn_sdot4(a, b, 0) and spends a v_mov 0 per product and a
+// v_bfe per scale byte; the VOP3P form takes the zero as an inline constant (checked against the builtin by tools/dot4_probe.cpp; a
+// DOT result needs 3 wait states before another VALU instruction reads it, which the 8-instruction distance provides).
+// Exact integer arithmetic: any association gives the reference's int32 (ggml-quants.c:6950-6968, :8190-8216).
+template <bool SIGNED>
+__device__ __forceinline__ int dotscale8(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t s0, uint32_t s1) {
+    int t0, t1, t2, t3, t4, t5, t6, t7, sum;
+#define BAMD_SDWA_MUL(k, sreg, byte) "v_mul_i32_i24_sdwa %" #k ", %" #k ", " sreg " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #byte "\n\t"
+    if (SIGNED) {
+        asm("v_dot4_i32_i8 %0, %9, %17, 0\n\t" "v_dot4_i32_i8 %1, %10, %18, 0\n\t" "v_dot4_i32_i8 %2, %11, %19, 0\n\t" "v_dot4_i32_i8 %3, %12, %20, 0\n\t"
+            "v_dot4_i32_i8 %4, %13, %21, 0\n\t" "v_dot4_i32_i8 %5, %14, %22, 0\n\t" "v_dot4_i32_i8 %6, %15, %23, 0\n\t" "v_dot4_i32_i8 %7, %16, %24, 0\n\t"
+            BAMD_SDWA_MUL(0, "sext(%25)", 0) BAMD_SDWA_MUL(1, "sext(%25)", 1) BAMD_SDWA_MUL(2, "sext(%25)", 2) BAMD_SDWA_MUL(3, "sext(%25)", 3)
+            BAMD_SDWA_MUL(4, "sext(%26)", 0) BAMD_SDWA_MUL(5, "sext(%26)", 1) BAMD_SDWA_MUL(6, "sext(%26)", 2) BAMD_SDWA_MUL(7, "sext(%26)", 3)
+            "v_add3_u32 %8, %0, %1, %2\n\t" "v_add3_u32 %8, %8, %3, %4\n\t" "v_add3_u32 %8, %8, %5, %6\n\t" "v_add_u32 %8, %8, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(sum)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+              "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(s0), "v"(s1));
+    } else {
+        asm("v_dot4_i32_i8 %0, %9, %17, 0\n\t" "v_dot4_i32_i8 %1, %10, %18, 0\n\t" "v_dot4_i32_i8 %2, %11, %19, 0\n\t" "v_dot4_i32_i8 %3, %12, %20, 0\n\t"
+            "v_dot4_i32_i8 %4, %13, %21, 0\n\t" "v_dot4_i32_i8 %5, %14, %22, 0\n\t" "v_dot4_i32_i8 %6, %15, %23, 0\n\t" "v_dot4_i32_i8 %7, %16, %24, 0\n\t"
+            BAMD_SDWA_MUL(0, "%25", 0) BAMD_SDWA_MUL(1, "%25", 1) BAMD_SDWA_MUL(2, "%25", 2) BAMD_SDWA_MUL(3, "%25", 3)
+            BAMD_SDWA_MUL(4, "%26", 0) BAMD_SDWA_MUL(5, "%26", 1) BAMD_SDWA_MUL(6, "%26", 2) BAMD_SDWA_MUL(7, "%26", 3)
+            "v_add3_u32 %8, %0, %1, %2\n\t" "v_add3_u32 %8, %8, %3, %4\n\t" "v_add3_u32 %8, %8, %5, %6\n\t" "v_add_u32 %8, %8, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(sum)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+              "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(s0), "v"(s1));
+    }
+#undef BAMD_SDWA_MUL
+    return sum;
+}
+// scale (<= 8 bits) x block dot (<= 15 bits): full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+
+// ggml-quants.c:1632-1637
+__device__ __forceinline__ int nearest_int(float fval) {
+    float val = fval + 12582912.f;
+    return (__float_as_int(val) & 0x007fffff) - 0x00400000;
+}
+
+// ===========================================================================================================
+// Activation prologue: f32 vector [K] -> Q8_K in LDS, optionally RMSNorm * weight first.
+//   q8[i*64 + e*8 + c] : dword = the 4 int8 of elements 32c+4e..32c+4e+3 of super-block i  (lane e reads 32 B)
+//   S [i*8 + c]        : int   = sum of the 32 int8 of chunk c  (= bsums[2c] + bsums[2c+1])
+//   yd[i]              : f32   = block scale d
+// ===========================================================================================================
+// ---- cross-lane helpers: DPP (no LDS-crossbar latency) for everything inside a row of 16 lanes, v_readlane across rows ----
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ int dpp_z(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }   // old = 0: foldable into add / umax
+#define DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141  /* lane i <-> 7-i inside each group of 8 */
+#define DPP_MIRROR 0x140       /* lane i <-> 15-i inside each row of 16 */
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {             // wave-uniform result
+    v = umax_(v, (uint32_t) dpp_z<DPP_XOR1>((int) v)); v = umax_(v, (uint32_t) dpp_z<DPP_XOR2>((int) v));
+    v = umax_(v, (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) v)); v = umax_(v, (uint32_t) dpp_z<DPP_MIRROR>((int) v));
+    const uint32_t r0 = (uint32_t) __builtin_amdgcn_readlane((int) v, 15), r1 = (uint32_t) __builtin_amdgcn_readlane((int) v, 31);
+    const uint32_t r2 = (uint32_t) __builtin_amdgcn_readlane((int) v, 47), r3 = (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+    return umax_(umax_(r0, r1), umax_(r2, r3));
+}
+__device__ __forceinline__ int group8_sum(int v) {                          // sum over aligned groups of 8 lanes, in every lane
+    v += dpp_z<DPP_XOR1>(v); v += dpp_z<DPP_XOR2>(v); v += dpp_z<DPP_HALF_MIRROR>(v);
+    return v;
+}
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum_f64(double s) {                  // fixed order; wave-uniform result
+    s += dpp_d<DPP_XOR1>(s); s += dpp_d<DPP_XOR2>(s); s += dpp_d<DPP_HALF_MIRROR>(s); s += dpp_d<DPP_MIRROR>(s);
+    return ((readlane_d(s, 15) + readlane_d(s, 31)) + readlane_d(s, 47)) + readlane_d(s, 63);
+}
+
+// One wave quantises BATCH super-blocks at a time (independent dependency chains interleave); lane l holds the 4
+// consecutive elements 4l..4l+3 of a block.  quantize_row_q8_K_ref semantics (ggml-quants.c:3593-3630): the scale comes
+// from the FIRST element of largest magnitude (strict > scan), so ties resolve to the lowest lane, lowest element.
+#define BAMD_ACT_BATCH 4
+// LDS layout of the quantised activations of one mat-vec: q8[nb][64] u32 | S[nb][8] i32 | yd[nb] f32 | (16-byte aligned) red[16] f64
+#define BAMD_ACT_RED_OFF(nb) ((((size_t) (nb) * (256 + 32 + 4)) + 15) & ~(size_t) 15)
+template <bool NORM>
+struct ActPro {
+    float4 v[BAMD_ACT_BATCH], w[BAMD_ACT_BATCH];
+
+    // the loads of this wave's first batch of blocks: issued at kernel entry, AHEAD of the bulk weight prefetch, so the
+    // (tiny, latency-critical) activation read is not queued behind megabytes of weight requests
+    // blocks i0, i0 + bstride, ... below blimit (defaults: this wave's share of the whole vector, interleaved over the waves)
+    __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0, int bstride = 0, int blimit = 0) {
+        const int lane = threadIdx.x & 63;
+        if (bstride == 0) { bstride = blockDim.x >> 6; blimit = K >> 8; }
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const int i = i0 + b * bstride;
+            v[b] = i < blimit ? *(const float4 *) (x + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORM) w[b] = i < blimit ? *(const float4 *) (nw + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // Issue-bound code (every CU quantises the whole activation vector: ~1/3 of a decode step's VALU work), so the instruction
+    // count per block is what matters here:
+    //   - the two IEEE divisions per block (iscale = -127/max, d = 1/iscale) run ONCE per batch: block b's operand sits in lane b;
+    //   - nearest_int(v) & 0xff is the low byte of the bits of v + 12582912.f (ggml-quants.c:1632-1637: the mask and the
+    //     0x400000 offset do not touch that byte), and MIN(127, .) (:3617) never binds for |iscale * x| <= 127(1 + 2^-23);
+    //   - the sum of the four signed bytes is one v_dot4 against 0x01010101;
+    //   - the four wave-max chains are interleaved step by step (DPP results need wait states); row_bcast leaves the result in lane 63.
+    __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd, int bstride = 0, int blimit = 0) {
+        const int lane = threadIdx.x & 63;
+        const int nwaves = bstride ? bstride : (int) (blockDim.x >> 6), nb = bstride ? blimit : (K >> 8);
+        uint32_t amaxb[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            if (NORM) {                                  // y = (x*scale)*w : ggml_vec_scale_f32 then ggml_mul (llama.cpp:7940-7950)
+                v[b].x = (v[b].x * scale) * w[b].x; v[b].y = (v[b].y * scale) * w[b].y;
+                v[b].z = (v[b].z * scale) * w[b].z; v[b].w = (v[b].w * scale) * w[b].w;
+            }
+            const float a = fmaxf(fmaxf(fmaxf(fabsf(v[b].x), fabsf(v[b].y)), fabsf(v[b].z)), fabsf(v[b].w));
+            amaxb[b] = __float_as_uint(a);               // non-negative floats order like their bit patterns
+        }
+        uint32_t t[BAMD_ACT_BATCH], wmax[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(amaxb[b], (uint32_t) dpp_z<DPP_XOR1>((int) amaxb[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_XOR2>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_MIRROR>((int) t[b]));
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x142, 0xa, 0xf, false));   // row_bcast:15
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x143, 0xc, 0xf, false));   // row_bcast:31
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) wmax[b] = (uint32_t) __builtin_amdgcn_readlane((int) t[b], 63);
+        // the scale comes from the FIRST element of largest magnitude (strict > scan of the reference): lowest lane, lowest element
+        float mine[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const float M = __uint_as_float(wmax[b]);
+            const bool ex = fabsf(v[b].x) == M, ey = fabsf(v[b].y) == M, ez = fabsf(v[b].z) == M;
+            float m = v[b].w;                            // branch-free selects, lowest element wins
+            m = ez ? v[b].z : m; m = ey ? v[b].y : m; m = ex ? v[b].x : m;
+            mine[b] = m;
+        }
+        int mxv = __float_as_int(1.0f);
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const unsigned long long who = __ballot(amaxb[b] == wmax[b]);
+            const int first = __ffsll((long long) who) - 1;
+            const int mxb = __builtin_amdgcn_readlane(__float_as_int(mine[b]), first);
+            mxv = lane == b ? mxb : mxv;
+        }
+        const float isc = -127.f / __int_as_float(mxv);  // lane b: block b (other lanes: -127)
+        const float dd = 1.0f / isc;
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            const int i = i0 + b * nwaves;
+            if (i < nb) {                                // wave-uniform
+                const float iscale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isc), b));
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dd), b));
+                const bool nz = wmax[b] != 0u;           // all-zero block: q = 0, d = 0 (ggml-quants.c:3607-3612)
+                const float t0 = iscale * v[b].x + 12582912.f, t1 = iscale * v[b].y + 12582912.f;
+                const float t2 = iscale * v[b].z + 12582912.f, t3 = iscale * v[b].w + 12582912.f;
+                const uint32_t p01 = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x0c0c0400u);
+                const uint32_t p23 = __builtin_amdgcn_perm(__float_as_uint(t3), __float_as_uint(t2), 0x0c0c0400u);
+                uint32_t packed = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                packed = nz ? packed : 0u;
+                const int s4 = group8_sum(sdot4(packed, 0x01010101u));
+                q8[i * 64 + (lane & 7) * 8 + (lane >> 3)] = packed;
+                if ((lane & 7) == 0) S[i * 8 + (lane >> 3)] = s4;
+                if (lane == 0) yd[i] = nz ? d : 0.f;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
+                                           uint32_t * q8, int * S, float * yd, double * red) {
+        const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
+        const int step = nwaves * BAMD_ACT_BATCH;
+        float scale = 1.0f;
+        if (NORM) {
+            // sum of squares in double (ggml.c:11874-11877), fixed tree order instead of the reference's sequential order
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                s += (double) (v[b].x * v[b].x); s += (double) (v[b].y * v[b].y); s += (double) (v[b].z * v[b].z); s += (double) (v[b].w * v[b].w);
+            }
+            for (int i0 = wave + step; i0 < nb; i0 += step) {          // only for K > 256 * 4 * nwaves
+                ActPro<NORM> t; t.issue(x, nw, K, i0);
+#pragma unroll
+                for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                    s += (double) (t.v[b].x * t.v[b].x); s += (double) (t.v[b].y * t.v[b].y); s += (double) (t.v[b].z * t.v[b].z); s += (double) (t.v[b].w * t.v[b].w);
+                }
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) red[wave] = s;
+            __syncthreads();
+            double tot = 0.0;
+            for (int w2 = 0; w2 < nwaves; ++w2) tot += red[w2];
+            const float mean = (float) (tot / (double) K);
+            scale = 1.0f / sqrtf(mean + eps);
+        }
+        quantize_batch(scale, K, wave, q8, S, yd);
+        for (int i0 = wave + step; i0 < nb; i0 += step) {
+            ActPro<NORM> t; t.issue(x, nw, K, i0);
+            t.quantize_batch(scale, K, i0, q8, S, yd);
+        }
+        __syncthreads();
+    }
+};
+
+// ===========================================================================================================
+// Quantised mat-vec: y = W . Q8_K(x).  One wave = 8 rows at a time (lane = r*8+e), rows streamed sequentially
+// over super-blocks so each lane carries exactly the f32 chain of SIMD lane e of the reference.
+// ===========================================================================================================
+struct RowAcc { float acc, accm; };
+
+// ---- per-record arithmetic -----------------------------------------------------------------------------
+struct RecQ4K { uint4 qs, hd; };
+struct RecQ5K { uint4 qs, hd; uint32_t qh; };
+struct RecQ6K { uint4 ql; uint2 qh, sc; uint32_t d; };
+
+// Pin a loaded register at its point of use: without this, LLVM folds the first ALU op on a ring register into
+// the loop PHI (i.e. executes it right after the load, one iteration early), which forces s_waitcnt vmcnt(0) at
+// the loop tail and serialises the whole prefetch ring.
+__device__ __forceinline__ void pin(uint32_t & x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(uint2 & x) { pin(x.x); pin(x.y); }
+__device__ __forceinline__ void pin(uint4 & x) { pin(x.x); pin(x.y); pin(x.z); pin(x.w); }
+__device__ __forceinline__ void pin_rec(RecQ4K & R) { pin(R.qs); pin(R.hd); }
+__device__ __forceinline__ void pin_rec(RecQ5K & R) { pin(R.qs); pin(R.hd); pin(R.qh); }
+__device__ __forceinline__ void pin_rec(RecQ6K & R) { pin(R.ql); pin(R.qh); pin(R.sc); pin(R.d); }
+
+// `rec` is wave-uniform (SGPR pair); the per-lane part is a 32-bit offset, so the loads take the saddr form and need no
+// 64-bit VALU address arithmetic.  Weights are read exactly once per token: non-temporal loads keep them out of the way
+// of the L2-resident activations (MI355X_MICROARCH.md, row nt-weights).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T ldnt(const uint8_t * rec, uint32_t off) { return __builtin_nontemporal_load((const T *) (rec + off)); }
+template <> __device__ __forceinline__ uint4 ldnt<uint4>(const uint8_t * rec, uint32_t off) {
+    const u32x4_t v = __builtin_nontemporal_load((const u32x4_t *) (rec + off)); return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ uint2 ldnt<uint2>(const uint8_t * rec, uint32_t off) {
+    const u32x2_t v = __builtin_nontemporal_load((const u32x2_t *) (rec + off)); return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void load_rec(RecQ4K & R, const uint8_t * rec, int lane) {
+    const uint32_t l = (uint32_t) lane;
+    R.qs = ldnt<uint4>(rec, l * 16u);
+    R.hd = ldnt<uint4>(rec, 1024u + (l >> 3) * 16u);
+}
+__device__ __forceinline__ void load_rec(RecQ5K & R, const uint8_t * rec, int lane) {
+    const uint32_t l = (uint32_t) lane;
+    R.qs = ldnt<uint4>(rec, l * 16u);
+    R.qh = ldnt<uint32_t>(rec, 1024u + l * 4u);
+    R.hd = ldnt<uint4>(rec, 1280u + (l >> 3) * 16u);
+}
+__device__ __forceinline__ void load_rec(RecQ6K & R, const uint8_t * rec, int lane) {
+    const uint32_t l = (uint32_t) lane;
+    R.ql = ldnt<uint4>(rec, l * 16u);
+    R.qh = ldnt<uint2>(rec, 1024u + l * 8u);
+    R.sc = ldnt<uint2>(rec, 1536u + (l >> 3) * 16u + ((l >> 2) & 1u) * 8u);
+    R.d  = ldnt<unsigned short>(rec, 1664u + (l >> 3) * 2u);
+}
+
+// 6-bit scale/min unpack, ggml-quants.c:6928-6933
+__device__ __forceinline__ void unpack_k4(const uint4 & hd, uint32_t & sc03, uint32_t & sc47, uint32_t & mn03, uint32_t & mn47) {
+    const uint32_t u0 = hd.y, u1 = hd.z, u2 = hd.w;
+    sc03 = u0 & 0x3f3f3f3fu; mn03 = u1 & 0x3f3f3f3fu;
+    sc47 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+    mn47 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+}
+#define BYTE(w, k) (int) (((w) >> (8 * (k))) & 0xffu)
+
+// The terms one super-block contributes to the f32 chains of lane (r, e):
+//   d, fs   : acc  = fma(d, fs, acc)                      (all types; fs = (float) of the exact int32 lane sum)
+//   dmin, pm: Q4_K: accm = fma(dmin, pm, accm) for l = e&3 ; Q5_K: accm = accm + dmin*pm (pm = all-8 integer sum)
+struct Terms { float d, fs, dmin, pm; };
+
+__device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
+    const int e = lane & 7, l = e & 3;
+    const float ydv = yd[ci];
+    Terms T;
+    T.d = ydv * h2f(R.hd.x & 0xffffu);
+    T.dmin = (-ydv) * h2f(R.hd.x >> 16);
+    uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+    const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+    const uint32_t wq[8] = { R.qs.x & 0x0f0f0f0fu, (R.qs.x >> 4) & 0x0f0f0f0fu, R.qs.y & 0x0f0f0f0fu, (R.qs.y >> 4) & 0x0f0f0f0fu,
+                             R.qs.z & 0x0f0f0f0fu, (R.qs.z >> 4) & 0x0f0f0f0fu, R.qs.w & 0x0f0f0f0fu, (R.qs.w >> 4) & 0x0f0f0f0fu };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    const int sumi = dotscale8<false>(wq, aq, sc03, sc47);
+    T.fs = (float) sumi;
+    const uint32_t mw = (l < 2) ? mn03 : mn47;
+    const int sh = (l & 1) * 16;
+    const int ma = (int) ((mw >> sh) & 0xffu), mb = (int) ((mw >> (sh + 8)) & 0xffu);
+    const int2 sp = *(const int2 *) (S + ci * 8 + 2 * l);
+    T.pm = (float) (mul24(ma, sp.x) + mul24(mb, sp.y));  // 6-bit min x sum of 32 int8
+    return T;
+}
+
+__device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
+    const int e = lane & 7;
+    const float ydv = yd[ci];
+    Terms T;
+    T.d = ydv * h2f(R.hd.x & 0xffffu);
+    T.dmin = (-ydv) * h2f(R.hd.x >> 16);
+    uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+    const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+    const uint32_t qh = R.qh;
+#define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))
+    const uint32_t wq[8] = { Q5(R.qs.x, 0, 0), Q5(R.qs.x, 4, 1), Q5(R.qs.y, 0, 2), Q5(R.qs.y, 4, 3), Q5(R.qs.z, 0, 4), Q5(R.qs.z, 4, 5), Q5(R.qs.w, 0, 6), Q5(R.qs.w, 4, 7) };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    const int sumi = dotscale8<false>(wq, aq, sc03, sc47);
+#undef Q5
+    T.fs = (float) sumi;
+    // hsum(mins . q8sums) over all 8 sub-blocks (:7515-7518): exact integer, any order
+    const uint32_t mw = (e < 4) ? mn03 : mn47;
+    const int hs = group8_sum(mul24((int) ((mw >> (8 * (e & 3))) & 0xffu), S[ci * 8 + e]));
+    T.pm = (float) hs;
+    return T;
+}
+
+__device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane, const uint32_t * q8, const int * S, const float * yd) {
+    (void) S;
+    const int e = lane & 7;
+    Terms T;
+    T.d = yd[ci] * h2f(R.d);
+    T.dmin = 0.f; T.pm = 0.f;
+    const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+    // (q6 - 32) as int8: q6 in [0,63] -> (q6 + 0x60) ^ 0x80 per byte, no inter-byte carry
+#define Q6(lo, hb) ((((lo) | ((hb) << 4)) + 0x60606060u) ^ 0x80808080u)
+#define SB(w, k) ((int) (int8_t) ((w) >> (8 * (k))))
+    const uint32_t A0 = R.ql.x, B0 = R.ql.y, h0 = R.qh.x, A1 = R.ql.z, B1 = R.ql.w, h1 = R.qh.y;
+    const uint32_t wq[8] = { Q6(A0 & 0x0f0f0f0fu, h0 & 0x03030303u), Q6(B0 & 0x0f0f0f0fu, (h0 >> 2) & 0x03030303u),
+                             Q6((A0 >> 4) & 0x0f0f0f0fu, (h0 >> 4) & 0x03030303u), Q6((B0 >> 4) & 0x0f0f0f0fu, (h0 >> 6) & 0x03030303u),
+                             Q6(A1 & 0x0f0f0f0fu, h1 & 0x03030303u), Q6(B1 & 0x0f0f0f0fu, (h1 >> 2) & 0x03030303u),
+                             Q6((A1 >> 4) & 0x0f0f0f0fu, (h1 >> 4) & 0x03030303u), Q6((B1 >> 4) & 0x0f0f0f0fu, (h1 >> 6) & 0x03030303u) };
+    const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    const int sumi = dotscale8<true>(wq, aq, R.sc.x, R.sc.y);
+#undef Q6
+#undef SB
+    T.fs = (float) sumi;
+    return T;
+}
+
+// one step of the reference's per-lane f32 chains (the ONLY place their order is defined)
+template <int TYPE>
+__device__ __forceinline__ void chain_step(RowAcc & A, float d, float fs, float dmin, float pm) {
+    A.acc = fmaf(d, fs, A.acc);
+    if (TYPE == BAMD_Q4_K) A.accm = fmaf(dmin, pm, A.accm);                    // _mm_fmadd_ps(dmin, prod, acc_m)
+    if (TYPE == BAMD_Q5_K) { const float t = dmin * pm; A.accm = A.accm + t; } // summs += dmin * hsum  (mul, then add)
+}
+
+// horizontal reductions at the end of a row (hsum_float_8, ggml-quants.c:47-53, and the acc_m folds), valid in lane e == 0 of
+// each 8-lane group: (a_e + a_{e+4}) -> (+ lane e+2) -> (+ lane e+1), the reference's tree, by DPP row_shl:4 / quad_perm.
+__device__ __forceinline__ float dpp_f_shl4(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_f_xor2(float v) { return __int_as_float(dpp_i<DPP_XOR2>(__float_as_int(v))); }
+__device__ __forceinline__ float dpp_f_xor1(float v) { return __int_as_float(dpp_i<DPP_XOR1>(__float_as_int(v))); }
+template <int TYPE>
+__device__ __forceinline__ float finish_row(const RowAcc & A) {
+    float v = A.acc;
+    v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v);
+    if (TYPE == BAMD_Q4_K) {
+        float m = A.accm;
+        m = m + dpp_f_xor2(m); m = m + dpp_f_xor1(m);
+        return v + m;
+    }
+    if (TYPE == BAMD_Q5_K) return v + A.accm;
+    return v;
+}
+
+// ggml_v_expf (AVX2), one lane — ggml.c:2490-2522
+__device__ __forceinline__ float v_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + __float_as_uint(1.0f));
+    const bool c = fabsf(n) > 126.0f;
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u, 0x1.ffffecp-1f * b);
+    if (!c) return fmaf(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = __uint_as_float(g + 0x7f000000u), s2 = __uint_as_float(e - g);
+    if (fabsf(n) > 192.0f) return s1 * s1;
+    return fmaf(s2, j, s2) * s1;
+}
+__device__ __forceinline__ float v_silu(float x) {
+    const float neg_x = 0.0f - x;
+    const float one_plus = 1.0f + v_expf(neg_x);
+    return x / one_plus;
+}
+
+__device__ __forceinline__ unsigned long long argmax_key(float v, int row) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long) u << 32) | (unsigned long long) (0xffffffffu - (uint32_t) row);
+}
+
+struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S; float * yd; double * red; };
+#define BAMD_PRO_ISSUE(ap, pa) (ap).issue((pa).x, (pa).nw, (pa).K, wave_id())
+#define BAMD_PRO_FINISH(ap, pa) (ap).finish((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
+
+__device__ __forceinline__ void get_scale_min_k4(int j, const uint8_t * q, int & d, int & m) {
+    if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; }
+    else { d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4); }
+}
+
+// get_rows of one token (ggml.c:13186-13228 -> dequantize_row_*): row `tok` of the embedding matrix (GGUF layout) -> x[E]
+__device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, int E, int tok, float * x) {
+    // get_rows: ggml.c:13186-13228 -> dequantize_row_*
+    if (embd_type == BAMD_F32) {
+        const float * src = (const float *) embd + (size_t) tok * E;
+        for (int i = threadIdx.x; i < E; i += blockDim.x) x[i] = src[i];
+    } else if (embd_type == BAMD_F16) {
+        const unsigned short * src = (const unsigned short *) embd + (size_t) tok * E;
+        for (int i = threadIdx.x; i < E; i += blockDim.x) x[i] = h2f(src[i]);
+    } else {
+        const int nb = E >> 8;
+        const int bb = bamd_block_bytes(embd_type);
+        const uint8_t * row = embd + (size_t) tok * nb * bb;
+        for (int i = threadIdx.x; i < E; i += blockDim.x) {
+            const uint8_t * b = row + (size_t) (i >> 8) * bb;
+            const int n = i & 255;
+            float y;
+            if (embd_type == BAMD_Q4_K || embd_type == BAMD_Q5_K) {
+                const float d = h2f(*(const unsigned short *) b), mn = h2f(*(const unsigned short *) (b + 2));
+                const int c = n >> 5, l = n & 31;           // chunk c: sub-block scale index c
+                int sc, m; get_scale_min_k4(c, b + 4, sc, m);
+                const float d1 = d * (float) sc, m1 = mn * (float) m;
+                int q;
+                if (embd_type == BAMD_Q4_K) {
+                    const uint8_t v = b[16 + 32 * (c >> 1) + l];
+                    q = (c & 1) ? (v >> 4) : (v & 0xF);
+                } else {
+                    const uint8_t v = b[48 + 32 * (c >> 1) + l];
+                    q = ((c & 1) ? (v >> 4) : (v & 0xF)) + (((b[16 + l] >> c) & 1) ? 16 : 0);
+                }
+                const float t = d1 * (float) q;
+                y = t - m1;
+            } else {
+                const float d = h2f(*(const unsigned short *) (b + 208));
+                const int half = n >> 7, nn = n & 127, cc = nn >> 5, l = nn & 31;
+                const uint8_t * ql = b + 64 * half, * qh = b + 128 + 32 * half;
+                const int8_t * sc = (const int8_t *) (b + 192 + 8 * half);
+                const int lo = (cc & 1) ? ql[l + 32] : ql[l];
+                const int nib = (cc & 2) ? (lo >> 4) : (lo & 0xF);
+                const int q = (int) (int8_t) (nib | (((qh[l] >> (2 * cc)) & 3) << 4)) - 32;
+                const int is = l / 16;
+                const float t = d * (float) sc[is + 2 * cc];
+                y = t * (float) q;
+            }
+            x[i] = y;
+        }
+    }
+}
+
+// ===========================================================================================================
+// Attention (single token): RoPE + KV store + scores + softmax + P.V         (reference: llm_build_kv, llama.cpp:8318)
+// ===========================================================================================================
+// KV cache, "chain-major" physical order (logically the reference's K [n_ctx][Hkv*hd] f16 and V^T [Hkv*hd][n_ctx] f16,
+// llama.cpp:7845-7875; bamd_op_attention converts at the boundary):
+//   K : inside each head row, element n = 8l + e is stored at index e*(hd/8) + l
+//   V^T: inside each row, position p = 64B + 8l + e is stored at index 64B + 8e + l
+// The reference's attention mat-muls (tinyBLAS, sgemm.cpp:405-431) keep 8 SIMD lanes e, each a sequential f32 chain over
+// the steps l.  With this order the wave lane that stands for SIMD lane e finds the operands of consecutive steps
+// CONTIGUOUS: 16-byte loads straight from HBM/L2, no LDS staging, no gather.
+__device__ __forceinline__ int kperm(int n, int L) { return (n & 7) * L + (n >> 3); }
+__device__ __forceinline__ int vperm(int p) { return (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3); }
+
+// dot of up to 32 steps for lane e: k8 = this lane's L halves of the K row (L <= 32), q = this lane's L floats / halves
+template <bool PREFILL>
+__device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const float * qf, const unsigned short * qh) {
+    if (!PREFILL) {
+        float acc = 0.f;                                           // tinyBLAS F16 x F32, KN = 8 (sgemm.cpp:405-431)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 8 < L) {
+                const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
+                const float4 qa = *(const float4 *) (qf + g * 8), qb = *(const float4 *) (qf + g * 8 + 4);
+                const float qv[8] = { qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w };
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), qv[u], acc);
+            }
+        }
+        return acc;
+    } else {
+        float a4[4] = { 0.f, 0.f, 0.f, 0.f };                      // ggml_vec_dot_f16: 4 accumulators x 8 lanes (ggml.c:2038)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 8 < L) {
+                const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
+                const uint4 qq = *(const uint4 *) (qh + g * 8);
+                const uint32_t qw[4] = { qq.x, qq.y, qq.z, qq.w };
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    a4[u & 3] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), h2f((qw[u >> 1] >> (16 * (u & 1))) & 0xffffu), a4[u & 3]);
+            }
+        }
+        const float s02 = a4[0] + a4[2], s13 = a4[1] + a4[3];
+        return s02 + s13;
+    }
+}
+__device__ __forceinline__ float hsum8_tinyblas(float v) { v = v + dpp_f_shl4(v); v = v + dpp_f_xor2(v); v = v + dpp_f_xor1(v); return v; }
+__device__ __forceinline__ float hsum8_vecdot(float v) { v = v + dpp_f_shl4(v); v = v + dpp_f_xor1(v); v = v + dpp_f_xor2(v); return v; }   // lo+hi, then two hadd_ps
+
+// RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143) of `nheads` consecutive heads of src into chain-major LDS copies
+__device__ __forceinline__ void rope_heads(const float * src, const float * rope, int hd, int nheads, float * qt, unsigned short * q16t,
+                                           unsigned short * k16t) {
+    const int L = hd >> 3;
+    for (int i = threadIdx.x; i < nheads * (hd / 2); i += blockDim.x) {
+        const int hh = i / (hd / 2), p = i - hh * (hd / 2);
+        const float c = rope[2 * p], s = rope[2 * p + 1];
+        const float x0 = src[hh * hd + 2 * p], x1 = src[hh * hd + 2 * p + 1];
+        const float t0 = x0 * c, t1 = x1 * s, t2 = x0 * s, t3 = x1 * c;
+        const float r0 = t0 - t1, r1 = t2 + t3;
+        const int i0 = hh * hd + kperm(2 * p, L), i1 = hh * hd + kperm(2 * p + 1, L);
+        if (qt) { qt[i0] = r0; qt[i1] = r1; q16t[i0] = f2h(r0); q16t[i1] = f2h(r1); }
+        else { k16t[i0] = f2h(r0); k16t[i1] = f2h(r1); }
+    }
+}
+
+
+// dynamic LDS of a mat-vec workgroup: quantised activations + reduction scratch (host side of carve_lds)
+static inline size_t act_lds_bytes(int K) {
+    const int nb = K >> 8;
+    size_t b = (size_t) nb * (256 + 32 + 4);
+    b = (b + 15) & ~(size_t) 15;
+    return b + 16 * sizeof(double) + 16 * sizeof(unsigned long long);
+}
+
+
+// one token's Q8_K activations in global memory: LDS layout (matmul_batch_kernel) and f16 MFMA layout (matmul_mfma_*), bamd_prefill.hip
+#define BAMD_TT 8                       /* tokens per workgroup tile of matmul_batch_kernel */
+#define BAMD_BLOB_BYTES(nb) (BAMD_ACT_RED_OFF(nb))
+#define BAMD_B16_REC 528
+#define BAMD_BLOB16_BYTES(nb) ((size_t) (nb) * (BAMD_B16_REC + 4))

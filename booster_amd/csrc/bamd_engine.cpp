@@ -814,7 +814,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_rope_row(int pos, 
     rope_row(row, pos, n_dims, freq_base, freq_scale, freq_factors, 0.0f, 1.0f, 8192, 32.0f, 1.0f);
     return 0;
 }
-// reference layout <-> chain-major device layout of the KV cache (bamd_kernels.hip, "Attention")
+// reference layout <-> chain-major device layout of the KV cache (bamd_device.h, "Attention")
 static void kv_to_device_order(const uint16_t * k_ref, const uint16_t * v_ref, int n_ctx, int n_ctx_pad, int Hkv, int hd, std::vector<uint16_t> & kd, std::vector<uint16_t> & vd) {
     const int Ekv = Hkv * hd, L = hd / 8;
     kd.assign((size_t) n_ctx_pad * Ekv, 0); vd.assign((size_t) Ekv * n_ctx_pad, 0);

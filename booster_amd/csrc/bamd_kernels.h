@@ -1,4 +1,4 @@
-// bamd_kernels.h — host-visible launch interface of bamd_kernels.hip
+// bamd_kernels.h — host-visible launch interface of the kernel files (bamd_matvec.hip, bamd_attention.hip, bamd_prefill.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +31,7 @@ struct bamd_mv_args {
 struct bamd_attn_args {
     const bamd_step_state * st;
     const float * q, * k, * v;     // f32 [H*hd], [Hkv*hd], [Hkv*hd] of this token (pre-RoPE)
-    unsigned short * kc, * vc;     // f16 caches of this layer, chain-major order (bamd_kernels.hip): K [n_ctx][Hkv*hd], V^T [Hkv*hd][n_ctx]; n_ctx % 64 == 0
+    unsigned short * kc, * vc;     // f16 caches of this layer, chain-major order (bamd_device.h): K [n_ctx][Hkv*hd], V^T [Hkv*hd][n_ctx]; n_ctx % 64 == 0
     const float * rope;            // [n_ctx][hd] (cos,sin) pairs
     float * scores;                // [H][n_ctx] scratch: scores (long-context path)
     float * probs;                 // [H][n_ctx] scratch: probabilities in V^T position order (long-context path)

@@ -1,0 +1,555 @@
+// bamd_prefill.hip — batched prefill: per-token Q8_K quantisation into global blobs, the exact MFMA mat-mul kernels (Q4_K, Q6_K),
+// the integer-dot batched mat-mul (any K-quant), batched embedding, silu*up.  Helpers: bamd_device.h.
+#include "bamd_device.h"
+
+// ===========================================================================================================
+// Batched prefill (T > 1 tokens per call; reference: llama_decode with a micro-batch, ggml_compute_forward_mul_mat with
+// ne11 = T, ggml.c:12277-12492).  Per (row, token) the arithmetic is EXACTLY the single-token chain above — the reference
+// quantises each activation row to Q8_K and runs the same vec_dot per (row, column) — so the batched kernels reuse
+// block_terms / chain_step / finish_row unchanged and differ only in data movement: the weights of a record are unpacked once
+// and used for BAMD_TT tokens whose Q8_K activations sit in LDS.  (An MFMA formulation that keeps the per-lane chains exact —
+// f16 A = scale x quant, one 32-deep MFMA per SIMD lane e — is the next step; see DESIGN.md.)
+// ===========================================================================================================
+
+// one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
+// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block 528 B: 8 (e) x 4 (g) groups of 8 halves — group (e, g) = the
+// int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane — followed by
+// the four i16 pairs (S_2l, S_2l+1) of the block sums; after the nb super-blocks, yd[nb] f32.  (528 B = 132 dwords: the MFMA
+// kernel stages these records in LDS, and 132 = 4 mod 64 makes its 16-byte reads bank-conflict free.)
+template <bool NORM>
+__global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
+                                                             uint8_t * __restrict__ blob, uint8_t * __restrict__ blob16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = K >> 8, t = blockIdx.x;
+    uint32_t * q8 = (uint32_t *) smem; int * S = (int *) (q8 + nb * 64); float * yd = (float *) (S + nb * 8);
+    double * red = (double *) (smem + BAMD_ACT_RED_OFF(nb));
+    const float * xt = x + (size_t) t * K;
+    ActPro<NORM> ap; ap.issue(xt, nw, K, wave_id()); ap.finish(xt, nw, eps, K, q8, S, yd, red);
+    const size_t bb = BAMD_BLOB_BYTES(nb);
+    if (blob) {
+        const uint4 * src = (const uint4 *) smem; uint4 * dst = (uint4 *) (blob + (size_t) t * bb);
+        for (int i = threadIdx.x; i < (int) (bb / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    if (blob16) {
+        uint8_t * o = blob16 + (size_t) t * BAMD_BLOB16_BYTES(nb);
+        for (int i = threadIdx.x; i < nb * 64; i += blockDim.x) {          // q8[ci*64 + e*8 + c] = sub-block c, chunk e, 4 int8
+            const int ci = i >> 6, e = (i >> 3) & 7, c = i & 7;
+            const uint32_t w = q8[i];
+            const unsigned short h0 = f2h((float) (int8_t) (w)), h1 = f2h((float) (int8_t) (w >> 8)), h2 = f2h((float) (int8_t) (w >> 16)), h3 = f2h((float) (int8_t) (w >> 24));
+            uint2 v; v.x = (uint32_t) h0 | ((uint32_t) h1 << 16); v.y = (uint32_t) h2 | ((uint32_t) h3 << 16);
+            *(uint2 *) (o + (size_t) ci * BAMD_B16_REC + (size_t) (e * 4 + (c >> 1)) * 16 + (c & 1) * 8) = v;
+        }
+        for (int i = threadIdx.x; i < nb * 4; i += blockDim.x) {           // (S_2l, S_2l+1) as i16 pairs: |S| <= 32 * 127
+            const int ci = i >> 2, l = i & 3;
+            *(uint32_t *) (o + (size_t) ci * BAMD_B16_REC + 512 + l * 4) = ((uint32_t) S[ci * 8 + 2 * l] & 0xffffu) | ((uint32_t) S[ci * 8 + 2 * l + 1] << 16);
+        }
+        float * oyd = (float *) (o + (size_t) nb * BAMD_B16_REC);
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) oyd[i] = yd[i];
+    }
+}
+
+
+template <int TYPE, typename REC, int D, int EPI>
+__device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb, int first, int count, int stride,
+                                              float * __restrict__ out, const float * __restrict__ res, int ldo, int t0, int nt,
+                                              const unsigned char * acts, size_t bb, int nvalid) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    constexpr int NPARTS = PAIR ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const long rgb = (long) nb * RECB, rg_step = (long) stride * rgb;
+    const int chunks = nb / D;
+    REC ring[D];
+    const uint8_t * rowA = wA + (long) first * rgb;
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * RECB, lane);
+    for (int r = 0; r < count; ++r) {
+        const int rg = first + r * stride;
+        const int row = rg * 8 + (lane >> 3);
+        const long rowoff = (long) rg * rgb;
+        float gate_val[BAMD_TT];
+#pragma unroll
+        for (int part = 0; part < NPARTS; ++part) {
+            const uint8_t * pbase = (part ? wB : wA) + rowoff;
+            const bool last = !(PAIR && part == 0) && r + 1 >= count;
+            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
+            RowAcc A[BAMD_TT];
+#pragma unroll
+            for (int u = 0; u < BAMD_TT; ++u) { A[u].acc = 0.f; A[u].accm = 0.f; }
+            for (int c = 0; c < chunks; ++c) {
+                const bool inrow = c + 1 < chunks;
+                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const int step = (inrow || !last) ? RECB : 0;
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    pin_rec(ring[s]);
+#pragma unroll
+                    for (int u = 0; u < BAMD_TT; ++u) {          // tokens beyond nt read stale-but-valid LDS and are never stored
+                        const unsigned char * au = acts + (size_t) u * bb;
+                        const uint32_t * q8 = (const uint32_t *) au; const int * S = (const int *) (q8 + nb * 64); const float * yd = (const float *) (S + nb * 8);
+                        const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
+                        chain_step<TYPE>(A[u], T.d, T.fs, T.dmin, T.pm);
+                    }
+                    load_rec(ring[s], nxt + s * step, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BAMD_TT; ++u) {
+                const float val = finish_row<TYPE>(A[u]);
+                if (PAIR && part == 0) { gate_val[u] = val; continue; }
+                if ((lane & 7) == 0 && row < nvalid && u < nt) {
+                    const size_t o = (size_t) (t0 + u) * ldo + row;
+                    float y = val;
+                    if (PAIR) y = v_silu(gate_val[u]) * val;
+                    if (EPI == BAMD_EPI_ADD) y = val + res[o];
+                    out[o] = y;
+                }
+            }
+        }
+    }
+}
+
+// ---- Q4_K x Q8_K on the matrix cores, exact ---------------------------------------------------------------------------
+// The reference's per-lane integer sums  isum_e = sum_j sc_j * sum_u w[j,e,u] * x[j,e,u]  (e = SIMD lane, j = 32-element sub-block,
+// u = 0..3) are 32-term dot products per (row, token, super-block, e).  With A = sc_j * w (<= 63 * 15 = 945: exact in f16), B = x
+// (int8: exact in f16) and f32 accumulation of integers < 2^24, ONE v_mfma_f32_16x16x32_f16 per e yields the sixteen-by-sixteen
+// (row, token) tile of isum_e exactly; the f32 chains acc_e = fma(d_x * d_y, isum_e, acc_e), the min terms and the final hsum tree
+// then run on the VALU in the reference's order (ggml-quants.c:6937-6978) — bit-identical to the integer-dot kernels above.
+// MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3);
+// C/D rows 4g + i, token m (cdna_hip_programming.md, fragment layout).  One wave = 16 rows x 16 tokens over the whole K.
+typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
+typedef float bamd_f4 __attribute__((ext_vector_type(4)));
+struct bamd_mma_args {
+    const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
+    const uint8_t * blob16; int K, T, nrows, nrows_pad, ldo;
+};
+__device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2, uint32_t & sc03, uint32_t & sc47, uint32_t & mn03, uint32_t & mn47) {
+    sc03 = u0 & 0x3f3f3f3fu; mn03 = u1 & 0x3f3f3f3fu;                                    // ggml-quants.c:6928-6933
+    sc47 = (u2 & 0x0f0f0f0fu) | (((u0 >> 6) & 0x03030303u) << 4);
+    mn47 = ((u2 >> 4) & 0x0f0f0f0fu) | (((u1 >> 6) & 0x03030303u) << 4);
+}
+// Workgroup = 8 waves = 8 consecutive row tiles (128 rows) x one tile of 32 tokens (each wave: 16 rows x 2 x 16 tokens, so every A
+// fragment is built once for two MFMAs).  Per super-block:
+//   - the 32 tokens' B records (528 B each) are staged in LDS by the whole workgroup, double-buffered (one barrier per super-block);
+//   - each wave loads its two weight records in the wave-stream layout (two coalesced 16-byte-per-lane loads, prefetched one
+//     super-block ahead), transposes them into the MFMA A layout through a private, padded LDS tile, and lanes 0..15 unpack the
+//     16 row headers ONCE (d, dmin, scales, mins as i16 pairs) into LDS for the other lanes;
+//   - 8 (e) x 2 (token tiles) MFMAs; chains, min terms (v_dot2_i32_i16) and the final trees on the VALU.
+#define BAMD_MMA_NT 2
+#define BAMD_MMA_TOK (16 * BAMD_MMA_NT)
+#define BAMD_MMA_STAGE (BAMD_MMA_TOK * BAMD_B16_REC + BAMD_MMA_TOK * 4)          /* B records + yd */
+#define BAMD_MMA_WAVE_LDS (2 * 288 * 4 + 16 * 32)                                /* transposed A tile + row headers */
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    const int nb = a.K >> 8;
+    const int rt = blockIdx.y * 8 + wave;                    // row tile: rows rt*16 .. rt*16+15 = record groups 2rt, 2rt+1
+    const bool live = rt * 16 < a.nrows_pad;                 // dead waves still take part in the staging and the barriers
+    const int t0 = blockIdx.x * BAMD_MMA_TOK;
+    const size_t b16 = BAMD_BLOB16_BYTES(nb);
+    unsigned char * stage = smem;                                            // [2][BAMD_MMA_STAGE]
+    uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
+    uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
+    // staging plan: 33 uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
+    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < BAMD_MMA_TOK * 33) {
+                const int tok = idx / 33, q = idx - tok * 33;
+                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
+            }
+        }
+        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    };
+    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
+        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
+        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
+    };
+    const int rtc = live ? rt : 0;
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1152, * rec1 = rec0 + (size_t) nb * 1152;     // record groups of rows 0-7 / 8-15
+    const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + 1024 + (m & 7) * 16;                                    // header of row m (lanes g == 0)
+    bamd_f4 acc[BAMD_MMA_NT][8], accm[BAMD_MMA_NT][4];
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int l = 0; l < 4; ++l) accm[n][l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    }
+    // prologue: stage super-block 0, prefetch the weights of super-block 0
+    uint4 sr[3]; float sy = 0.f;
+    stage_issue(0, sr, sy);
+    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
+    stage_commit(0, sr, sy);
+    __syncthreads();
+    for (int ci = 0; ci < nb; ++ci) {
+        const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
+        const bool more = ci + 1 < nb;
+        if (more) stage_issue(ci + 1, sr, sy);               // global loads of the next stage in flight during the math
+        // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
+        {
+            const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
+            *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
+            *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
+            if (g == 0) {                                    // lanes 0..15: row m
+                uint32_t sc03, sc47, mn03, mn47; unpack_k4_(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+                uint4 h0, h1;
+                h0.x = hd.x; h0.y = sc03; h0.z = sc47; h0.w = 0u;
+                h1.x = __builtin_amdgcn_perm(0u, mn03, 0x0c010c00u); h1.y = __builtin_amdgcn_perm(0u, mn03, 0x0c030c02u);
+                h1.z = __builtin_amdgcn_perm(0u, mn47, 0x0c010c00u); h1.w = __builtin_amdgcn_perm(0u, mn47, 0x0c030c02u);
+                *(uint4 *) (hl + m * 8) = h0; *(uint4 *) (hl + m * 8 + 4) = h1;
+            }
+        }
+        if (more) {                                          // prefetch the next super-block's weights
+            const uint32_t ro = (uint32_t) (ci + 1) * 1152u;
+            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
+        }
+        // headers of the four C rows 4g + i; d products per token tile
+        float D[BAMD_MMA_NT][4], Dm[BAMD_MMA_NT][4]; uint4 mp[4];
+        {
+            float dw[4], dmw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t dd = hl[(4 * g + i) * 8];
+                dw[i] = h2f(dd & 0xffffu); dmw[i] = h2f(dd >> 16);
+                mp[i] = *(const uint4 *) (hl + (4 * g + i) * 8 + 4);
+            }
+#pragma unroll
+            for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                const float ydv = *(const float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + (n * 16 + m) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { D[n][i] = ydv * dw[i]; Dm[n][i] = (-ydv) * dmw[i]; }
+            }
+        }
+        // A fragment of row m per e (scales of sub-blocks 2g, 2g+1 as f16; A = (1024 + n) * s - 1024 * s = n * s exactly), used for
+        // both token tiles, then the chains
+        {
+            const uint32_t scw = hl[m * 8 + 1 + (g >> 1)] >> (16 * (g & 1));
+            const _Float16 s_lo = (_Float16) (float) (scw & 0xffu), s_hi = (_Float16) (float) ((scw >> 8) & 0xffu);
+            const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
+            const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
+            const uint32_t * wrow = wl + (m >> 3) * 288 + (m & 7) * 36 + g;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t wq = wrow[e * 4];
+                const uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+                union { uint32_t u; h2_t h; } c0, c1, c2, c3;
+                c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
+                c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
+                const h2_t a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2), a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
+                const h2_t a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2), a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+                const bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                    const bamd_h8 bv = *(const bamd_h8 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + (e * 4 + g) * 16);
+                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, z, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], si[i], acc[n][e][i]);
+                }
+            }
+        }
+        // min terms: pm_l = m_2l S_2l + m_2l+1 S_2l+1 (one v_dot2_i32_i16); accm_l = fma(dmin, pm_l, accm_l)   (:6937-6941)
+#pragma unroll
+        for (int n = 0; n < BAMD_MMA_NT; ++n) {
+            const uint4 sp = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 512);
+            const uint32_t spl[4] = { sp.x, sp.y, sp.z, sp.w };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t mpl[4] = { mp[i].x, mp[i].y, mp[i].z, mp[i].w };
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l];
+                    const float pm = (float) __builtin_amdgcn_sdot2(ma.v, sb.v, 0, false);
+                    accm[n][l][i] = fmaf(Dm[n][i], pm, accm[n][l][i]);
+                }
+            }
+        }
+        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        __syncthreads();                                     // next stage visible; this stage and the wave tiles free again
+    }
+    if (!live) return;
+    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+        const int t = t0 + n * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
+            const float mm = (accm[n][0][i] + accm[n][2][i]) + (accm[n][1][i] + accm[n][3][i]);
+            const float val = v + mm;
+            const int row = rt * 16 + 4 * g + i;
+            if (t < a.T && row < a.nrows) {
+                const size_t o = (size_t) t * a.ldo + row;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+            }
+        }
+    }
+}
+// ---- Q6_K x Q8_K on the matrix cores, exact: same skeleton as matmul_mfma_q4k_kernel -----------------------------------------
+// scale (int8) x (q6 - 32) reaches 4096 in magnitude: not every such integer is an f16.  With u = q6 in [0, 63]:
+//   q6 - 32 = 2 (u >> 1) - 32 + (u & 1) = 2 vh + vl,  vh = (u >> 1) - 16 in [-16, 15],  vl = u & 1,
+// so A_h = scale * vh (|.| <= 2048) and A_l = scale * vl (|.| <= 128) are exact f16, TWO MFMAs per e give S_h, S_l (< 2^24), and
+// isum = 2 S_h + S_l (< 2^24) is exact as fmaf(2, S_h, S_l).  Scales are per 16 elements: for SIMD lane e the sub-block c uses
+// scales[2c + (e >= 4)] (ggml-quants.c:8145-8216); no min terms.  Wave-stream Q6_K record: bamd_formats.h.
+#define BAMD_MMA6_WAVE_LDS ((2 * 288 + 2 * 144 + 16 * 8) * 4)                    /* ql tile + qh tile + row headers */
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    const int nb = a.K >> 8;
+    const int rt = blockIdx.y * 8 + wave;
+    const bool live = rt * 16 < a.nrows_pad;
+    const int t0 = blockIdx.x * BAMD_MMA_TOK;
+    const size_t b16 = BAMD_BLOB16_BYTES(nb);
+    unsigned char * stage = smem;
+    uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA6_WAVE_LDS);    // ql tile [2][288]
+    uint32_t * ql2 = wl + 2 * 288;                                                           // qh tile [2][144]
+    uint32_t * hl = ql2 + 2 * 144;                                                           // row headers [16][8]
+    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + k * 512;
+            if (idx < BAMD_MMA_TOK * 33) {
+                const int tok = idx / 33, q = idx - tok * 33;
+                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
+            }
+        }
+        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    };
+    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
+        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
+        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
+    };
+    const int rtc = live ? rt : 0;
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = rec0 + (size_t) nb * 1680;
+    const uint8_t * recm = m < 8 ? rec0 : rec1;                                             // record group of row m (lanes g == 0)
+    bamd_f4 acc[BAMD_MMA_NT][8];
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    }
+    uint4 sr[3]; float sy = 0.f;
+    stage_issue(0, sr, sy);
+    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u);
+    uint2 qa = ldnt<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldnt<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
+    uint4 hsc = *(const uint4 *) (recm + 1536 + (m & 7) * 16); uint32_t hd = *(const unsigned short *) (recm + 1664 + (m & 7) * 2);
+    stage_commit(0, sr, sy);
+    __syncthreads();
+    for (int ci = 0; ci < nb; ++ci) {
+        const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
+        const bool more = ci + 1 < nb;
+        if (more) stage_issue(ci + 1, sr, sy);
+        {
+            const int r = lane >> 3, e = lane & 7;
+            *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
+            *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
+            *(uint2 *) (ql2 + 0 * 144 + r * 18 + e * 2) = qa;
+            *(uint2 *) (ql2 + 1 * 144 + r * 18 + e * 2) = qb;
+            if (g == 0) { *(uint4 *) (hl + m * 8) = hsc; hl[m * 8 + 4] = hd; }
+        }
+        if (more) {
+            const uint32_t ro = (uint32_t) (ci + 1) * 1680u;
+            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u);
+            qa = ldnt<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldnt<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
+            hsc = *(const uint4 *) (recm + ro + 1536 + (m & 7) * 16); hd = *(const unsigned short *) (recm + ro + 1664 + (m & 7) * 2);
+        }
+        float D[BAMD_MMA_NT][4];
+        {
+            float dw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[i] = h2f(hl[(4 * g + i) * 8 + 4]);
+#pragma unroll
+            for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                const float ydv = *(const float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + (n * 16 + m) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) D[n][i] = ydv * dw[i];
+            }
+        }
+        {
+            // int8 scales of sub-blocks c = 2g, 2g+1 for the two e-halves: header byte hi*8 + c
+            h2_t sA[2], sB[2];
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const uint32_t w = hl[m * 8 + hi * 2 + (g >> 1)] >> (16 * (g & 1));
+                const _Float16 s0 = (_Float16) (float) (int) (int8_t) (w & 0xffu), s1 = (_Float16) (float) (int) (int8_t) ((w >> 8) & 0xffu);
+                sA[hi] = (h2_t) { s0, s0 }; sB[hi] = (h2_t) { s1, s1 };
+            }
+            const h2_t k1040 = { (_Float16) 1040.f, (_Float16) 1040.f };
+            const us2_t one16 = { 0x3c00, 0x3c00 };
+            const int sh = 4 * (g & 1);
+            const uint32_t * wq = wl + (m >> 3) * 288 + (m & 7) * 36 + 2 * (g >> 1);
+            const uint32_t * hq = ql2 + (m >> 3) * 144 + (m & 7) * 18 + (g >> 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint2 ab = *(const uint2 *) (wq + e * 4);
+                const uint32_t h = hq[e * 2];
+                const uint32_t uA = ((ab.x >> sh) & 0x0f0f0f0fu) | (((h >> sh) & 0x03030303u) << 4);          // q6 of sub-block 2g, chunk e
+                const uint32_t uB = ((ab.y >> sh) & 0x0f0f0f0fu) | (((h >> (sh + 2)) & 0x03030303u) << 4);    // sub-block 2g + 1
+                const uint32_t hA = (uA >> 1) & 0x1f1f1f1fu, hB = (uB >> 1) & 0x1f1f1f1fu, lA = uA & 0x01010101u, lB = uB & 0x01010101u;
+                const h2_t sa = sA[e >> 2], sb = sB[e >> 2];
+                union { uint32_t u; h2_t h; us2_t s; } c0, c1, c2, c3, d0, d1, d2, d3;
+                c0.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04030402u);
+                c2.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04030402u);
+                d0.u = __builtin_amdgcn_perm(0u, lA, 0x0c010c00u); d1.u = __builtin_amdgcn_perm(0u, lA, 0x0c030c02u);   // 0 / 1 as u16 pairs
+                d2.u = __builtin_amdgcn_perm(0u, lB, 0x0c010c00u); d3.u = __builtin_amdgcn_perm(0u, lB, 0x0c030c02u);
+                d0.s = d0.s * one16; d1.s = d1.s * one16; d2.s = d2.s * one16; d3.s = d3.s * one16;                       // -> f16 0.0 / 1.0
+                const h2_t ah0 = (c0.h - k1040) * sa, ah1 = (c1.h - k1040) * sa, ah2 = (c2.h - k1040) * sb, ah3 = (c3.h - k1040) * sb;   // exact, |.| <= 2048
+                const h2_t al0 = d0.h * sa, al1 = d1.h * sa, al2 = d2.h * sb, al3 = d3.h * sb;
+                const bamd_h8 avh = { ah0.x, ah0.y, ah1.x, ah1.y, ah2.x, ah2.y, ah3.x, ah3.y };
+                const bamd_h8 avl = { al0.x, al0.y, al1.x, al1.y, al2.x, al2.y, al3.x, al3.y };
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) {
+                    const bamd_h8 bv = *(const bamd_h8 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + (e * 4 + g) * 16);
+                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    const bamd_f4 sh_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bv, z, 0, 0, 0);
+                    const bamd_f4 sl_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bv, z, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], fmaf(2.0f, sh_[i], sl_[i]), acc[n][e][i]);
+                }
+            }
+        }
+        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        __syncthreads();
+    }
+    if (!live) return;
+#pragma unroll
+    for (int n = 0; n < BAMD_MMA_NT; ++n) {
+        const int t = t0 + n * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float val = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
+            const int row = rt * 16 + 4 * g + i;
+            if (t < a.T && row < a.nrows) {
+                const size_t o = (size_t) t * a.ldo + row;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+            }
+        }
+    }
+}
+// h[t][i] = silu(gate[t][i]) * up[t][i] — the SILU_MUL epilogue of the mat-vec kernels as its own pass (ggml_v_silu op for op)
+__global__ void __launch_bounds__(256) silu_mul_kernel(const float * __restrict__ gate, const float * __restrict__ up, float * __restrict__ h, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = v_silu(gate[i]) * up[i];
+}
+
+// grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile
+template <int EPI>
+__global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = a.K >> 8;
+    const size_t bb = BAMD_BLOB_BYTES(nb);
+    const int t0 = blockIdx.x * BAMD_TT;
+    const int nt = a.T - t0 < BAMD_TT ? a.T - t0 : BAMD_TT;
+    {   // this tile's activations -> LDS (rows past T: repeat the last token; results discarded)
+        const int n16 = (int) (bb / 16);
+        for (int i = threadIdx.x; i < n16 * BAMD_TT; i += blockDim.x) {
+            const int u = i / n16, k = i - u * n16;
+            const int tu = t0 + (u < nt ? u : nt - 1);
+            ((uint4 *) smem)[(size_t) u * n16 + k] = ((const uint4 *) (a.blob + (size_t) tu * bb))[k];
+        }
+    }
+    __syncthreads();
+    const int wave = wave_id(), nwaves = blockDim.x >> 6;
+    const int slot = blockIdx.y + gridDim.y * wave, stride = gridDim.y * nwaves;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    int off = 0;
+    const int nseg = PAIR ? 1 : a.nseg;
+    for (int s = 0; s < nseg; ++s) {
+        const int nrg = a.seg[s].nrows >> 3;
+        const int k0 = off <= slot ? 0 : (off - slot + stride - 1) / stride;
+        const int g0 = slot + k0 * stride;
+        const int count = g0 < off + nrg ? (off + nrg - 1 - g0) / stride + 1 : 0;
+        if (count > 0) {
+            const int t = a.seg[s].type;
+            const uint8_t * wA = (const uint8_t *) a.seg[s].w;
+            const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
+            const int nv = a.seg[s].nvalid > 0 ? a.seg[s].nvalid : a.seg[s].nrows;
+            // ring depth 4 when it divides the row (it does for every K % 1024 == 0), else 1
+            if ((nb & 3) == 0) {
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+            } else {
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+            }
+        }
+        off += nrg;
+    }
+}
+
+// batched prefill: one workgroup per token of the micro-batch
+__global__ void __launch_bounds__(256) embed_batch_kernel(const int32_t * __restrict__ tokens, const uint8_t * embd, int embd_type, int E, int V, float * x) {
+    int tok = tokens[blockIdx.x];
+    if (tok < 0 || tok >= V) tok = 0;
+    embed_row(embd, embd_type, E, tok, x + (size_t) blockIdx.x * E);
+}
+
+
+// ===========================================================================================================
+// launchers
+// ===========================================================================================================
+// ---- batched prefill launchers ------------------------------------------------------------------------------------------
+size_t bamd_blob_bytes(int K) { return BAMD_BLOB_BYTES(K >> 8); }
+size_t bamd_blob16_bytes(int K) { return BAMD_BLOB16_BYTES(K >> 8); }
+void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, void * blob16, hipStream_t s) {
+    if (nw) hipLaunchKernelGGL((quantize_batch_kernel<true>),  dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob, (uint8_t *) blob16);
+    else    hipLaunchKernelGGL((quantize_batch_kernel<false>), dim3(T), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, (uint8_t *) blob, (uint8_t *) blob16);
+}
+int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s) {
+    int nrg = 0;
+    if (epi == BAMD_EPI_SILU_MUL) nrg = a.seg[0].nrows >> 3; else for (int i = 0; i < a.nseg; ++i) nrg += a.seg[i].nrows >> 3;
+    const size_t lds = (size_t) BAMD_TT * BAMD_BLOB_BYTES(a.K >> 8);
+    if (lds > 160 * 1024) return 1;                           // K > 17920: would need a K-split of the activation tile
+    const int tiles = (a.T + BAMD_TT - 1) / BAMD_TT;
+    // row slots: enough workgroups to fill the chip a few times over, at least one row-group per wave
+    int gy = (4 * (n_cu > 0 ? n_cu : 256) + tiles - 1) / tiles;
+    if (gy * 8 > nrg) gy = (nrg + 7) / 8;
+    if (gy < 1) gy = 1;
+    dim3 grid(tiles, gy);
+    switch (epi) {
+        case BAMD_EPI_STORE:    hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_STORE>),    grid, dim3(512), lds, s, a); break;
+        case BAMD_EPI_ADD:      hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_ADD>),      grid, dim3(512), lds, s, a); break;
+        case BAMD_EPI_SILU_MUL: hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_SILU_MUL>), grid, dim3(512), lds, s, a); break;
+        default: return 1;
+    }
+    return 0;
+}
+int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
+                            hipStream_t s) {
+    if ((type != BAMD_Q4_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
+    bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
+    dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
+    if (type == BAMD_Q6_K) {
+        const size_t lds6 = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA6_WAVE_LDS;
+        if (res) hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds6, s, a);
+        else     hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds6, s, a);
+        return 0;
+    }
+    const size_t lds = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
+    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds, s, a);
+    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds, s, a);
+    return 0;
+}
+void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, gate, up, h, n);
+}
+void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s) {
+    hipLaunchKernelGGL(embed_batch_kernel, dim3(T), dim3(256), 0, s, tokens, (const uint8_t *) embd, embd_type, E, V, x);
+}

@@ -2,9 +2,8 @@
 #include <stdio.h>
 #include <vector>
 #include <string.h>
-#include "bamd_formats.h"
-#include "bamd_kernels.h"
-void bamd_read_stamps(unsigned long long * host);
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBAMD_TIMING [-DK_DIM=..] -Ibooster_amd/csrc tools/timing_attn.cpp
+#include "bamd_attention.hip"      // one translation unit: the kernels, their phase stamps and this driver
 int main() {
     const int H = 32, Hkv = 8, hd = 128, n_ctx = 512, pos = 250, Ekv = Hkv * hd; float *probs;
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos = pos; h.n_ctx = n_ctx; h.n_kv = 256;

@@ -2,9 +2,8 @@
 #include <stdio.h>
 #include <vector>
 #include <string.h>
-#include "bamd_formats.h"
-#include "bamd_kernels.h"
-void bamd_read_stamps(unsigned long long * host);
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBAMD_TIMING [-DK_DIM=..] -Ibooster_amd/csrc tools/timing_main.cpp
+#include "bamd_matvec.hip"      // one translation unit: the kernels, their phase stamps and this driver
 int main() {
     const int type = 12, nrows = 4096, k = K_DIM;
     size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
