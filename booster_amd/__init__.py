@@ -50,6 +50,7 @@ def lib():
         L.bamd_generate_greedy.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_float)]
         L.bamd_stage_step.argtypes = [vp, C.c_int32, vp, ci, vp, vp, ci, ci, vp]
         L.bamd_stage_token_to.argtypes = [vp, vp, vp]
+        L.bamd_stage_prefill.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
         L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
@@ -140,6 +141,16 @@ class Context:
     def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr, token_dev_ptr=None):
         _chk(lib().bamd_stage_step(self.h, int(token), token_dev_ptr, int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits),
                                    int(prefill_mode), stream_ptr))
+
+    def stage_prefill(self, tokens, n_tokens, n_past, hidden_in_ptr, hidden_out_ptr, want_logits, stream_ptr):
+        """batched prompt micro-batch through this stage (tokens: host ids on the first stage, else None);
+        returns False when the shape has no batched kernels (fall back to stage_step per token)"""
+        t = None if tokens is None else np.ascontiguousarray(tokens, np.int32)
+        rc = lib().bamd_stage_prefill(self.h, _p(t), int(n_tokens), int(n_past), hidden_in_ptr, hidden_out_ptr, 1 if want_logits else 0, stream_ptr)
+        if rc == 2:
+            return False
+        _chk(rc)
+        return True
 
     def stage_token_to(self, token_dev_ptr, stream_ptr):
         _chk(lib().bamd_stage_token_to(self.h, token_dev_ptr, stream_ptr))

@@ -217,14 +217,25 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
         if (bamd_decode(p.stages[0].ctx, tokens, n, n_past)) return 1;
         memcpy(p.logits.data(), bamd_get_logits(p.stages[0].ctx), (size_t) p.n_vocab * 4);
     } else {
+        // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
+        // and shapes without batched kernels, step token by token
+        bool batched = n > 1 && n <= 512;
+        for (size_t s = 0; s < p.stages.size() && batched; ++s) {
+            Stage & st = p.stages[s];
+            const bool last = s + 1 == p.stages.size();
+            void * hout = last ? nullptr : p.stages[s + 1].hidden_in;
+            const int rc = bamd_stage_prefill(st.ctx, s == 0 ? tokens : nullptr, n, n_past, st.hidden_in, hout, last ? 1 : 0, nullptr);
+            if (rc == 2 && s == 0) { batched = false; break; }            // no batched kernels for this model: per-token path below
+            if (rc) return 1;
+            if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }
+        }
         const int prefill = n > 1;
-        for (int t = 0; t < n; ++t) {
+        for (int t = 0; t < n && !batched; ++t) {
             for (size_t s = 0; s < p.stages.size(); ++s) {
                 Stage & st = p.stages[s];
                 const bool last = s + 1 == p.stages.size();
                 void * hout = last ? nullptr : p.stages[s + 1].hidden_in;       // lives on the NEXT device; peer write
-                void * tmp_out = hout;
-                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, tmp_out, last && t == n - 1, prefill, nullptr)) return 1;
+                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, hout, last && t == n - 1, prefill, nullptr)) return 1;
                 if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }   // hand-off: producer done before consumer starts
             }
         }
@@ -293,7 +304,7 @@ BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_si
         if (!ref.ctx) { fprintf(stderr, "initContext: error: failed to create context: %s\n", bamd_last_error()); return nullptr; }
         if (!first) {
             hipSetDevice(ref.device);
-            if (hipMalloc(&ref.hidden_in, (size_t) pod->n_embd * 4) != hipSuccess) return nullptr;
+            if (hipMalloc(&ref.hidden_in, (size_t) 512 * pod->n_embd * 4) != hipSuccess) return nullptr;     // one prompt micro-batch of hidden states
             // let the producer's device write the hand-off buffer directly over xGMI (the reference: cudaDeviceEnablePeerAccess, ggml-cuda.cu:1304)
             const int prev = pod->stages[s - 1].device;
             if (prev != ref.device) { int can = 0; hipDeviceCanAccessPeer(&can, prev, ref.device); if (can) { hipSetDevice(prev); hipDeviceEnablePeerAccess(ref.device, 0); } }

@@ -432,8 +432,13 @@ extern "C" int bamd_stage_step(bamd_context * c, int32_t token, const void * tok
 static bool prefill_batch_supported(const bamd_context * c) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
-    return g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 8192 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8) &&
-           8 * bamd_blob_bytes(std::max(m->E, m->F)) <= 160 * 1024;
+    if (!(g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 8192 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8))) return false;
+    // every mat-mul needs a kernel: the MFMA kernels take Q4_K / Q6_K with K % 1024 == 0 at any K; the integer-dot kernel takes any
+    // K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
+    auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q6_K) && K % 1024 == 0) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
+    for (const DevLayer & ly : m->layers)
+        if (!ok(ly.wq.type, m->E) || !ok(ly.wk.type, m->E) || !ok(ly.wv.type, m->E) || !ok(ly.wo.type, m->E) || !ok(ly.wg.type, m->E) || !ok(ly.wu.type, m->E) || !ok(ly.wd.type, m->F)) return false;
+    return true;
 }
 static int ensure_batch_buffers(bamd_context * c) {
     if (c->bcap) return 0;
@@ -475,15 +480,17 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     }
     return 0;
 }
-// tokens already in c->forced; leaves the hidden state of the LAST token in c->x
-static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_t s) {
+// first stage: tokens already in c->forced; later stages: hidden_in [T][E] f32 on this device.  Last stage: leaves the hidden state of
+// the LAST token in c->x (for lm_head); other stages: writes hidden_out [T][E] (possibly on the next device: peer copy).
+static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_t s, const void * hidden_in = nullptr, void * hidden_out = nullptr) {
     bamd_model * m = c->m;
     const int E = m->E, F = m->F, Ekv = m->Hkv * m->hd, ldq = E + 2 * Ekv, gq = m->H / m->Hkv;
     bamd_step_state h; memset(&h, 0, sizeof h);
     h.pos_base = n_past; h.pos = n_past; h.n_ctx = c->n_ctx; h.step = T;
     h.n_kv = std::min(c->n_ctx, (n_past + T + 31) / 32 * 32);
     HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
-    bamd_launch_embed_batch(c->forced, T, m->tok_embd.raw, m->tok_embd.type, E, m->V, c->bx, s);
+    if (m->with_embd) bamd_launch_embed_batch(c->forced, T, m->tok_embd.raw, m->tok_embd.type, E, m->V, c->bx, s);
+    else HIPC(hipMemcpyAsync(c->bx, hidden_in, (size_t) T * E * 4, hipMemcpyDeviceToDevice, s));
     for (size_t il = 0; il < m->layers.size(); ++il) {
         const DevLayer & ly = m->layers[il];
         bamd_mm_args a; memset(&a, 0, sizeof a);
@@ -518,7 +525,8 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         seg_of(a.seg[0], ly.wd, c->bx); a.nseg = 1; a.blob = c->bblob; a.K = F; a.T = T; a.ldo = E; a.res = c->bx2;
         if (batch_mm(c, a, BAMD_EPI_ADD, T, s)) return fail("batched mat-mul: unsupported shape");
     }
-    HIPC(hipMemcpyAsync(c->x, c->bx + (size_t) (T - 1) * E, (size_t) E * 4, hipMemcpyDeviceToDevice, s));
+    if (m->with_output) HIPC(hipMemcpyAsync(c->x, c->bx + (size_t) (T - 1) * E, (size_t) E * 4, hipMemcpyDeviceToDevice, s));
+    else HIPC(hipMemcpyAsync(hidden_out, c->bx, (size_t) T * E * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -550,6 +558,25 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+// a micro-batch of 2..512 prompt tokens through ONE layer-split stage (bamd_stage_step's batched counterpart): tokens (host) on the
+// stage that owns the embedding, hidden_in_dev [n_tokens][n_embd] f32 elsewhere; hidden_out_dev [n_tokens][n_embd] on every stage but
+// the last, which computes the logits of the last token when want_logits.  Returns 2 when the shape has no batched kernels (caller
+// falls back to bamd_stage_step per token).
+extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past, const void * hidden_in_dev,
+                                                                           void * hidden_out_dev, int want_logits, void * hip_stream) {
+    bamd_model * m = c->m;
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t) hip_stream;
+    if (n_tokens < 2 || n_tokens > BAMD_PREFILL_CAP || !prefill_batch_supported(c)) return 2;
+    if (n_past < 0 || n_past + n_tokens > c->n_ctx) return fail("context overflow");
+    if (m->with_embd) { if (!tokens) return fail("bamd_stage_prefill: tokens required on the first stage"); HIPC(hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s)); }
+    else if (!hidden_in_dev) return fail("bamd_stage_prefill: hidden_in required");
+    if (!m->with_output && !hidden_out_dev) return fail("bamd_stage_prefill: hidden_out required");
+    if (ensure_batch_buffers(c)) return 1;
+    if (enqueue_prefill_batch(c, n_tokens, n_past, s, hidden_in_dev, hidden_out_dev)) return 1;
+    if (m->with_output && want_logits) enqueue_lm_head(c, s, nullptr);
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; g_prefill_mfma = on == 2 ? 0 : 1; }

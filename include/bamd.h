@@ -68,6 +68,12 @@ int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * ou
  * stream) and NOT synchronised.  prefill_mode as in bamd_decode (n_tokens > 1).  Returns 0 or an error code. */
 int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev, void * hidden_out_dev,
                     int want_logits, int prefill_mode, void * hip_stream);
+/* Batched counterpart of bamd_stage_step for prompt micro-batches of 2..512 tokens: `tokens` (host) on the stage that owns the
+ * embedding, hidden_in_dev [n_tokens][n_embd] f32 on the others; writes hidden_out_dev [n_tokens][n_embd] on every stage but the
+ * last, which computes the logits of the LAST token when want_logits (bamd_stage_get_logits).  Returns 2 when this model / context
+ * shape has no batched kernels: the caller then falls back to bamd_stage_step per token.  Bit-identical to that path. */
+int bamd_stage_prefill(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past, const void * hidden_in_dev, void * hidden_out_dev,
+                       int want_logits, void * hip_stream);
 /* last stage: write the arg-max of the last bamd_stage_step(want_logits=1) into a device int32 (stream-ordered). */
 int bamd_stage_token_to(bamd_context * c, void * token_dev, void * hip_stream);
 /* host logits (n_vocab floats) of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */

@@ -170,3 +170,41 @@ def test_baseline_config_shapes_vs_oracle(bamd, po, tmp_path, cfg):
         n_past += 1
         assert np.array_equal(bits(lg_g), bits(lg_o)), "step %d: max |d| = %g" % (s, np.abs(lg_g - lg_o).max())
     oc.close(); ctx.close(); m.close()
+
+
+def test_stage_prefill_equals_single_stage(bamd, tmp_path):
+    """batched prompt micro-batches through three virtual stages (hidden states [T][E] handed over as device buffers) == the
+    single-stage batched prefill == token by token; then decode steps on top of the stage KV caches."""
+    import torch
+    p = str(tmp_path / "syn4.gguf")
+    gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=2, L=4, F=2048, V=512, seed=9)
+    full = bamd.Model(p); cf = bamd.Context(full, 128)
+    stages = [bamd.Model(p, 0, 0, 1, True, False), bamd.Model(p, 0, 1, 3, False, False), bamd.Model(p, 0, 3, 4, False, True)]
+    ctxs = [bamd.Context(s, 128) for s in stages]
+    side = torch.cuda.Stream()
+    toks = [(37 * i + 11) % 512 for i in range(45)]
+    with torch.cuda.stream(side):
+        stream = torch.cuda.current_stream().cuda_stream
+        hid = [torch.zeros(45 * 1024, dtype=torch.float32, device="cuda") for _ in range(2)]
+        for (a, b) in ((0, 30), (30, 45)):                      # two micro-batches
+            n = b - a
+            assert ctxs[0].stage_prefill(toks[a:b], n, a, None, hid[0].data_ptr(), False, stream)
+            assert ctxs[1].stage_prefill(None, n, a, hid[0].data_ptr(), hid[1].data_ptr(), False, stream)
+            assert ctxs[2].stage_prefill(None, n, a, hid[1].data_ptr(), None, True, stream)
+        tok = ctxs[2].stage_argmax(stream)
+    lg = cf.decode(toks[:30], 0); lg = cf.decode(toks[30:], 30)
+    assert tok == int(np.argmax(lg))
+    # one decode step through the stages on top of the batched KV caches
+    with torch.cuda.stream(side):
+        stream = torch.cuda.current_stream().cuda_stream
+        h1 = [torch.zeros(1024, dtype=torch.float32, device="cuda") for _ in range(2)]
+        ctxs[0].stage_step(tok, 45, None, h1[0].data_ptr(), False, False, stream)
+        ctxs[1].stage_step(tok, 45, h1[0].data_ptr(), h1[1].data_ptr(), False, False, stream)
+        ctxs[2].stage_step(tok, 45, h1[1].data_ptr(), None, True, False, stream)
+        tok2 = ctxs[2].stage_argmax(stream)
+    lg2 = cf.decode([tok], 45)
+    assert tok2 == int(np.argmax(lg2))
+    for c in ctxs + [cf]:
+        c.close()
+    for s in stages + [full]:
+        s.close()
