@@ -85,37 +85,41 @@ __global__ void __launch_bounds__(256) attn_softmax_kernel(bamd_attn_args a) {
     for (int i = threadIdx.x; i < n_kv; i += blockDim.x) a.probs[(size_t) h * n_ctx + vperm(i)] = s[i] * fs;
 }
 
-// P.V: grid (Hkv, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d) for the GQ heads
-// that share this KV head.  sgemm.cpp:405-431 with A = V^T rows (f16), B = p (f32).
-template <int GQ>
-__global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a) {
+// P.V: grid (H, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d).  sgemm.cpp:405-431 with
+// A = V^T rows (f16), B = p (f32).  The chain over positions is sequential per lane, but the loads are not: BAMD_PV_U blocks of 64
+// positions are requested together (16 KiB of V^T per wave in flight); one query head per wave so that 2 waves per CU are streaming
+// (the V^T rows of a KV head are read by its GQ query heads: L2 / MALL absorb the re-reads).
+#define BAMD_PV_U 16
+__global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a, int gq) {
     const bamd_step_state * st = a.st;
     const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
-    const int hk = blockIdx.x;
+    const int h = blockIdx.x, hk = h / gq;
     const int lane = threadIdx.x, e = lane & 7;
     const int d = blockIdx.y * 8 + (lane >> 3);
-    const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx;
-    const float * p = a.probs + (size_t) (hk * GQ) * n_ctx;
-    float acc[GQ];
+    const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx + e * 8;
+    const float * p = a.probs + (size_t) h * n_ctx + e * 8;
+    float acc = 0.f;
+    for (int b0 = 0; b0 < n_kv; b0 += 64 * BAMD_PV_U) {
+        uint4 vv[BAMD_PV_U]; float4 pa[BAMD_PV_U], pb[BAMD_PV_U];
 #pragma unroll
-    for (int g = 0; g < GQ; ++g) acc[g] = 0.f;
-    for (int b0 = 0; b0 < n_kv; b0 += 64) {                      // one 64-position block = 8 chain steps per lane
-        const uint4 vv = *(const uint4 *) (vrow + b0 + e * 8);
-        const uint32_t w[4] = { vv.x, vv.y, vv.z, vv.w };
-        const int nstep = n_kv - b0 >= 64 ? 8 : (n_kv - b0) >> 3;
+        for (int u = 0; u < BAMD_PV_U; ++u) {
+            const int b = b0 + 64 * u;
+            if (b < n_kv) { vv[u] = *(const uint4 *) (vrow + b); pa[u] = *(const float4 *) (p + b); pb[u] = *(const float4 *) (p + b + 4); }
+        }
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) {
-            const float4 pa = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8), pb = *(const float4 *) (p + (size_t) g * n_ctx + b0 + e * 8 + 4);
-            const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
+        for (int u = 0; u < BAMD_PV_U; ++u) {
+            const int b = b0 + 64 * u;
+            if (b < n_kv) {                                      // one 64-position block = 8 chain steps per lane (n_kv % 64 == 32: 4)
+                const uint32_t w[4] = { vv[u].x, vv[u].y, vv[u].z, vv[u].w };
+                const float pv[8] = { pa[u].x, pa[u].y, pa[u].z, pa[u].w, pb[u].x, pb[u].y, pb[u].z, pb[u].w };
+                const int nstep = n_kv - b >= 64 ? 8 : (n_kv - b) >> 3;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < nstep) acc[g] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc[g]);
+                for (int k = 0; k < 8; ++k) if (k < nstep) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc);
+            }
         }
     }
-#pragma unroll
-    for (int g = 0; g < GQ; ++g) {
-        const float v = hsum8_tinyblas(acc[g]);
-        if (e == 0) a.out[(size_t) (hk * GQ + g) * hd + d] = v;
-    }
+    const float v = hsum8_tinyblas(acc);
+    if (e == 0) a.out[(size_t) h * hd + d] = v;
 }
 
 // ---- ONE launch per layer, one workgroup per QUERY head (and per token of a prefill micro-batch) ---------------------------
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // softmax with the reference's 8-wide partial sums, tinyBLAS chains for P.V), but every K row and V^T chunk is loaded once for the
 // GQH heads, and the token's own K/V are already in the cache (kv_store_batch_kernel).  Dynamic LDS: GQH x 2 x n_ctx floats.
 template <int GQH>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_kernel(bamd_attn_args a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_kernel(bamd_attn_args a, int gq) {
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQH][256];
     __shared__ float redf[GQH][8];
     __shared__ double redd[GQH][8];
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int pos = st->pos + tokb;
     int n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx;
     const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
-    const int hk = blockIdx.x, h0 = hk * GQH;
+    const int h0 = blockIdx.x * GQH, hk = h0 / gq;           // GQH divides gq: the heads of a workgroup share one KV head
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
     const int r_pos = wave * 8 + (lane >> 3);
     const float * q = a.q + (size_t) tokb * a.ld_qkv + (size_t) h0 * hd;
@@ -422,13 +426,15 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_BATCH_MAX || !a.batch) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    // all query heads of a KV head in one workgroup while their score buffers fit the LDS; else one workgroup per query head
-    const size_t lds_g = (size_t) gq * a.n_ctx * 8;
-    if (lds_g <= 144 * 1024 && (gq == 2 || gq == 4 || gq == 8)) {
-        if (gq == 2)      hipLaunchKernelGGL((attn_batch_kernel<2>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
-        else if (gq == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
-        else              hipLaunchKernelGGL((attn_batch_kernel<8>), dim3(a.Hkv, T), dim3(512), lds_g, s, a);
-    } else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+    // as many query heads of a KV head per workgroup as have their score buffers fit the LDS (2 x n_ctx floats each); else one
+    int gqh = gq;
+    while (gqh > 1 && (size_t) gqh * a.n_ctx * 8 > 144 * 1024) gqh >>= 1;
+    const size_t lds_g = (size_t) gqh * a.n_ctx * 8;
+    const dim3 grid(a.Hkv * gq / (gqh > 1 ? gqh : 1), T);
+    if (gqh == 8)      hipLaunchKernelGGL((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
+    else if (gqh == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
+    else if (gqh == 2) hipLaunchKernelGGL((attn_batch_kernel<2>), grid, dim3(512), lds_g, s, a, gq);
+    else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
     return 0;
 }
 
@@ -442,12 +448,12 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;
     if (ty < 1) ty = 1;
-    dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
+    dim3 g1(a.Hkv, ty), g3(a.Hkv * gq, a.hd / 8);
     switch (gq) {
 #define CASE(G) case G: \
         hipLaunchKernelGGL((attn_qk_kernel<G>), g1, dim3(512), 0, s, a); \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(256), 0, s, a); \
-        hipLaunchKernelGGL((attn_pv_kernel<G>), g3, dim3(64), 0, s, a); break;
+        hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64), 0, s, a, gq); break;
         CASE(1) CASE(2) CASE(4) CASE(8)
 #undef CASE
         default: return 1;
