@@ -54,47 +54,67 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 
 // softmax over n_kv scores of one head: grid (H), block 256.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
 // Probabilities are written back in the V^T position order (vperm) so the P.V lanes read them contiguously.
-__global__ void __launch_bounds__(256) attn_softmax_kernel(bamd_attn_args a) {
-    __shared__ float redf[4];
-    __shared__ double redd[4];
+#define BAMD_SM_R 8                      /* values per thread kept in registers: one pass over global memory up to n_kv = 8192 */
+__global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
+    __shared__ float redf[16];
+    __shared__ double redd[16];
     const bamd_step_state * st = a.st;
     const int n_kv = st->n_kv, n_ctx = a.n_ctx;
     const int h = blockIdx.x;
     float * s = a.scores + (size_t) h * n_ctx;
+    float * pr = a.probs + (size_t) h * n_ctx;
     const float scale = a.kq_scale;
-    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), nw = blockDim.x >> 6;
+    const bool cached = n_kv <= BAMD_SM_R * (int) blockDim.x;
+    float v[BAMD_SM_R];
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) { const float w = s[i] * scale; mx = w > mx ? w : mx; }
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; v[k] = i < n_kv ? s[i] * scale : -INFINITY; mx = v[k] > mx ? v[k] : mx; }
+    } else for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s[i] * scale; mx = w > mx ? w : mx; }
     for (int o = 32; o; o >>= 1) { const float om = __shfl_xor(mx, o); mx = om > mx ? om : mx; }
     if (lane == 0) redf[wave] = mx;
     __syncthreads();
-    mx = redf[0]; for (int w = 1; w < 4; ++w) mx = redf[w] > mx ? redf[w] : mx;
+    mx = redf[0]; for (int w = 1; w < nw; ++w) mx = redf[w] > mx ? redf[w] : mx;
     double sum = 0.0;
-    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) {
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < BAMD_SM_R; ++k) {
+            const int i = tid + k * blockDim.x;
+            if (i < n_kv) {                                      // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+                const float val = v_expf(v[k] - mx);
+                v[k] = val;
+                const float c = hsum8_tinyblas(val);             // the reference's 8-wide partial sum (same tree shape)
+                if ((lane & 7) == 0) sum += (double) c;
+            }
+        }
+    } else for (int i = tid; i < n_kv; i += blockDim.x) {
         const float w = s[i] * scale;
         const float val = v_expf(w - mx);
         s[i] = val;                                              // same index this thread just read: no hazard
-        const float c = hsum8_tinyblas(val);                     // the reference's 8-wide partial sum (same tree shape)
+        const float c = hsum8_tinyblas(val);
         if ((lane & 7) == 0) sum += (double) c;
     }
     sum = wave_sum_f64(sum);
     if (lane == 0) redd[wave] = sum;
     __syncthreads();
-    double tot = 0.0; for (int w = 0; w < 4; ++w) tot += redd[w];
+    double tot = 0.0; for (int w = 0; w < nw; ++w) tot += redd[w];
     const float fs = (float) (1.0 / tot);
-    for (int i = threadIdx.x; i < n_kv; i += blockDim.x) a.probs[(size_t) h * n_ctx + vperm(i)] = s[i] * fs;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) pr[vperm(i)] = v[k] * fs; }
+    } else for (int i = tid; i < n_kv; i += blockDim.x) pr[vperm(i)] = s[i] * fs;
 }
-
 // P.V: grid (H, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d).  sgemm.cpp:405-431 with
 // A = V^T rows (f16), B = p (f32).  The chain over positions is sequential per lane, but the loads are not: BAMD_PV_U blocks of 64
-// positions are requested together (16 KiB of V^T per wave in flight); one query head per wave so that 2 waves per CU are streaming
-// (the V^T rows of a KV head are read by its GQ query heads: L2 / MALL absorb the re-reads).
+// positions are requested together (16 KiB of V^T per wave in flight).  Workgroup = the gq query heads of one KV head, one wave
+// each: they stream the same V^T rows in step, so three of the four reads hit the CU's vector L1.
 #define BAMD_PV_U 16
-__global__ void __launch_bounds__(64) attn_pv_kernel(bamd_attn_args a, int gq) {
+__global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) {
     const bamd_step_state * st = a.st;
     const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
-    const int h = blockIdx.x, hk = h / gq;
-    const int lane = threadIdx.x, e = lane & 7;
+    const int hk = blockIdx.x, h = hk * gq + wave_id();
+    const int lane = threadIdx.x & 63, e = lane & 7;
     const int d = blockIdx.y * 8 + (lane >> 3);
     const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx + e * 8;
     const float * p = a.probs + (size_t) h * n_ctx + e * 8;
@@ -448,12 +468,12 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;
     if (ty < 1) ty = 1;
-    dim3 g1(a.Hkv, ty), g3(a.Hkv * gq, a.hd / 8);
+    dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
     switch (gq) {
 #define CASE(G) case G: \
         hipLaunchKernelGGL((attn_qk_kernel<G>), g1, dim3(512), 0, s, a); \
-        hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(256), 0, s, a); \
-        hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64), 0, s, a, gq); break;
+        hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
+        hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); break;
         CASE(1) CASE(2) CASE(4) CASE(8)
 #undef CASE
         default: return 1;
