@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
 // A = V^T rows (f16), B = p (f32).  The chain over positions is sequential per lane, but the loads are not: BAMD_PV_U blocks of 64
 // positions are requested together (16 KiB of V^T per wave in flight).  Workgroup = the gq query heads of one KV head, one wave
 // each: they stream the same V^T rows in step, so three of the four reads hit the CU's vector L1.
-#define BAMD_PV_U 16
+#define BAMD_PV_U 8
 __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) {
     const bamd_step_state * st = a.st;
     const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
@@ -119,25 +119,33 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
     const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx + e * 8;
     const float * p = a.probs + (size_t) h * n_ctx + e * 8;
     float acc = 0.f;
-    for (int b0 = 0; b0 < n_kv; b0 += 64 * BAMD_PV_U) {
-        uint4 vv[BAMD_PV_U]; float4 pa[BAMD_PV_U], pb[BAMD_PV_U];
-#pragma unroll
-        for (int u = 0; u < BAMD_PV_U; ++u) {
-            const int b = b0 + 64 * u;
-            if (b < n_kv) { vv[u] = *(const uint4 *) (vrow + b); pa[u] = *(const float4 *) (p + b); pb[u] = *(const float4 *) (p + b + 4); }
-        }
-#pragma unroll
-        for (int u = 0; u < BAMD_PV_U; ++u) {
-            const int b = b0 + 64 * u;
-            if (b < n_kv) {                                      // one 64-position block = 8 chain steps per lane (n_kv % 64 == 32: 4)
-                const uint32_t w[4] = { vv[u].x, vv[u].y, vv[u].z, vv[u].w };
-                const float pv[8] = { pa[u].x, pa[u].y, pa[u].z, pa[u].w, pb[u].x, pb[u].y, pb[u].z, pb[u].w };
-                const int nstep = n_kv - b >= 64 ? 8 : (n_kv - b) >> 3;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < nstep) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc);
-            }
-        }
+    // two register sets of BAMD_PV_U blocks: the requests of the next set are in flight while the chain walks the current one
+    uint4 vA[BAMD_PV_U], vB[BAMD_PV_U]; float4 paA[BAMD_PV_U], pbA[BAMD_PV_U], paB[BAMD_PV_U], pbB[BAMD_PV_U];
+#define BAMD_PV_LOAD(V_, PA_, PB_, base_) do { \
+        _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) { \
+            const int b = (base_) + 64 * u < n_kv ? (base_) + 64 * u : 0;      /* unconditional requests (block 0 again past the end): counted waits */ \
+            V_[u] = *(const uint4 *) (vrow + b); PA_[u] = *(const float4 *) (p + b); PB_[u] = *(const float4 *) (p + b + 4); \
+        } } while (0)
+#define BAMD_PV_CHAIN(V_, PA_, PB_, base_) do { \
+        _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) { \
+            const int b = (base_) + 64 * u; \
+            if (b < n_kv) {                                      /* one 64-position block = 8 chain steps per lane (n_kv % 64 == 32: 4) */ \
+                const uint32_t w[4] = { V_[u].x, V_[u].y, V_[u].z, V_[u].w }; \
+                const float pv[8] = { PA_[u].x, PA_[u].y, PA_[u].z, PA_[u].w, PB_[u].x, PB_[u].y, PB_[u].z, PB_[u].w }; \
+                const int nstep = n_kv - b >= 64 ? 8 : (n_kv - b) >> 3; \
+                _Pragma("unroll") for (int k = 0; k < 8; ++k) if (k < nstep) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); \
+            } \
+        } } while (0)
+    constexpr int STEP = 64 * BAMD_PV_U;
+    BAMD_PV_LOAD(vA, paA, pbA, 0);
+    for (int b0 = 0; b0 < n_kv; b0 += 2 * STEP) {
+        BAMD_PV_LOAD(vB, paB, pbB, b0 + STEP);
+        BAMD_PV_CHAIN(vA, paA, pbA, b0);
+        BAMD_PV_LOAD(vA, paA, pbA, b0 + 2 * STEP);
+        BAMD_PV_CHAIN(vB, paB, pbB, b0 + STEP);
     }
+#undef BAMD_PV_LOAD
+#undef BAMD_PV_CHAIN
     const float v = hsum8_tinyblas(acc);
     if (e == 0) a.out[(size_t) h * hd + d] = v;
 }
