@@ -469,8 +469,9 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
-    if (a.n_ctx <= BAMD_ATTN_FUSED_MAX && max_tiles >= 0) {
-        // context fits the LDS score buffer: one fused launch per layer, one workgroup per query head
+    if (a.n_ctx <= BAMD_ATTN_BATCH_MAX && max_tiles >= 0) {
+        // the caller knows n_kv <= BAMD_ATTN_FUSED_MAX for this launch and the score buffers fit the LDS: one fused launch per
+        // layer, one workgroup per query head
         hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
         return 0;
     }

@@ -114,9 +114,9 @@ struct bamd_context {
     int32_t * forced = nullptr; int forced_cap = 0;
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph = nullptr; int graph_fused = -1;
     // stage-step graphs (bamd_stage_step): one per (want_logits, prefill_mode), valid for the pointers it was captured with
-    struct StageGraph { hipGraphExec_t exec = nullptr; const void * token_src = nullptr, * hin = nullptr; void * hout = nullptr; };
+    struct StageGraph { hipGraphExec_t exec = nullptr; const void * token_src = nullptr, * hin = nullptr; void * hout = nullptr; int fused = -1; };
     StageGraph sgraph[2][2];
     // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
     int bcap = 0;
@@ -355,7 +355,11 @@ struct StepTimer {                 // optional per-launch HIP-event timing (bamd
 static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.stream; sg.out = out; sg.type = d.type; sg.nrows = d.nrows_pad; sg.nvalid = d.nrows; }
 
 // enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
-static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm) {
+// pos_hi: the highest position this enqueue (or every replay of the graph being captured) will see.  The single-launch attention
+// kernel serves n_kv <= 2048 (one workgroup per head has the bandwidth for that) at any n_ctx <= 8192 (its LDS score buffers);
+// longer sequences take the three-kernel path.
+static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && c->n_ctx_pad <= 8192 && pos_hi < 2048; }
+static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
     bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
     const int tiles = std::min(std::max(c->n_ctx / 64, 1), 32);
@@ -379,7 +383,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         if (tm) tm->begin(s, 1, 0.0);
         // three-kernel path (scores | softmax | P.V) everywhere for now: the fused single-launch kernel is correct (tests)
         // but not yet faster at n_kv ~ 256 (14.9 vs 12.8 us on MI355X) — BAMD_ATTN_FUSED=1 selects it
-        if (bamd_launch_attention(t, gq, g_attn_fused ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
+        if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
         if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
         memset(&a, 0, sizeof a);
@@ -551,7 +555,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
         const int prefill_mode = n_tokens > 1;
         for (int t = 0; t < n_tokens; ++t) {
             enqueue_begin(c, n_tokens, 1, s);
-            if (enqueue_layers(c, prefill_mode, s, nullptr)) return 1;
+            if (enqueue_layers(c, prefill_mode, s, nullptr, n_past + n_tokens)) return 1;
             if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);
         }
     }
@@ -582,12 +586,12 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_co
 extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; g_prefill_mfma = on == 2 ? 0 : 1; }
 extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) { return c->logits_host; }
 
-static int build_graph(bamd_context * c) {
+static int build_graph(bamd_context * c, int pos_hi) {
     hipStream_t s = c->stream;
     hipGraph_t g = nullptr;
     HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     enqueue_begin(c, 0, 1, s);
-    int rc = enqueue_layers(c, 0, s, nullptr);
+    int rc = enqueue_layers(c, 0, s, nullptr, pos_hi);
     enqueue_lm_head(c, s, nullptr);
     hipError_t e = hipStreamEndCapture(s, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
@@ -604,7 +608,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     if (n_steps < 1 || n_past < 1 || n_past + n_steps > c->n_ctx || n_steps + 1 > c->out_cap) return fail("bad n_past / n_steps");
     HIPC(hipSetDevice(m->device));
     hipStream_t s = c->stream;
-    if (!c->graph && build_graph(c)) return 1;
+    const int fused = attn_fused_for(c, n_past + n_steps) ? 1 : 0;
+    if (c->graph && c->graph_fused != fused) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    if (!c->graph && build_graph(c, n_past + n_steps)) return 1;
+    c->graph_fused = fused;
     if (set_state(c, n_past, s, true)) return 1;
     hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, s));
@@ -641,14 +648,15 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
             bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, q);
             HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         }
-        if (enqueue_layers(c, prefill_mode, q, nullptr)) return 1;
+        if (enqueue_layers(c, prefill_mode, q, nullptr, pos)) return 1;
         if (m->with_output) { if (want_logits) enqueue_lm_head(c, q, nullptr); }
         else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         return 0;
     };
     if (!g_stage_graph || s == nullptr) return enqueue(s);           // the legacy default stream cannot be captured
     bamd_context::StageGraph & sg = c->sgraph[want_logits ? 1 : 0][prefill_mode ? 1 : 0];
-    if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+    const int fused = attn_fused_for(c, pos) ? 1 : 0;
+    if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev || sg.fused != fused)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
     if (!sg.exec) {
         hipGraph_t g = nullptr;
         HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -659,7 +667,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
         const hipError_t e2 = hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e2 != hipSuccess) { sg.exec = nullptr; return fail(std::string("stage graph instantiate: ") + hipGetErrorString(e2)); }
-        sg.token_src = forced; sg.hin = hidden_in_dev; sg.hout = hidden_out_dev;
+        sg.token_src = forced; sg.hin = hidden_in_dev; sg.hout = hidden_out_dev; sg.fused = fused;
     }
     HIPC(hipGraphLaunch(sg.exec, s));
     return 0;
@@ -707,7 +715,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
     if (set_state(c, pos, s, false)) return 1;
     StepTimer tm; tm.on = true;
     tm.begin(s, 2, 0.0); enqueue_begin(c, 1, 1, s); tm.end(s);
-    if (enqueue_layers(c, 0, s, &tm)) return 1;
+    if (enqueue_layers(c, 0, s, &tm, pos)) return 1;
     enqueue_lm_head(c, s, &tm);
     HIPC(hipStreamSynchronize(s));
     for (int i = 0; i < 4; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
