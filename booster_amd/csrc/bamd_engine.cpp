@@ -356,9 +356,10 @@ static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.s
 
 // enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
 // pos_hi: the highest position this enqueue (or every replay of the graph being captured) will see.  The single-launch attention
-// kernel serves n_kv <= 2048 (one workgroup per head has the bandwidth for that) at any n_ctx <= 8192 (its LDS score buffers);
-// longer sequences take the three-kernel path.
-static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && c->n_ctx_pad <= 8192 && pos_hi < 2048; }
+// kernel (one workgroup per query head, serial over the sequence) wins below ~450 positions (measured crossover, 8B shape: 1.73 vs
+// 1.85 ms/token at 240, equal at 440, 2.06 vs 1.88 at 740) at any n_ctx <= 8192 (its LDS score buffers); longer sequences take the
+// three-kernel path, whose cost is nearly flat up to a few thousand positions.
+static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && c->n_ctx_pad <= 8192 && pos_hi < 448; }
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
     bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
