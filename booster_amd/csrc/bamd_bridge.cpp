@@ -119,6 +119,36 @@ void init_janus(Pod & p) {                        // cpp/janus.cpp:410-490
         if (type == LANG_EN && lower) { p.scales[(size_t) id] = (float) (1.0 - (1.0 - scale) * probes[std::min<size_t>(len, 19)]); continue; }
         p.scales[(size_t) id] = scale;
     }
+    // second half of initJanus (cpp/janus.cpp:528-700): fixed overrides.  The reference writes them without bounds (an id past the
+    // vocabulary, or eot = -1, is a wild heap write there); here such ids are skipped.
+    const int V = p.n_vocab;
+    auto put = [&](int id, float v) { if (id >= 0 && id < V) p.scales[(size_t) id] = v; };
+    auto part = [&](double k) { return (float) (1.0 - (1.0 - scale) * k); };
+    put(0, 1.0f); put(p.vocab.eos, scale); put(p.vocab.eot, scale);
+    // (the reference tests llama_model_desc for "llama" / "mistral": always true for the one architecture this engine loads)
+    if (V > 128000) {                              // Llama-3 vocabulary: by piece, then by id range and class
+        for (int id = 0; id < V; id++) {
+            const std::string & t = p.vocab.token_to_piece(id);
+            if (t == "\n" || t == "\n\n" || t == " " || t == "," || t == ".") { put(id, part(0.10)); continue; }
+            if (t == "  " || t == "    ") { put(id, part(0.20)); continue; }
+            if (t == " \xe2\x80\x94" || t == "-" || t == ":" || t == ";" || t == " (" || t == ")." || t == " )" || t == ")" || t == "(") { put(id, part(0.30)); continue; }
+            const int type = (int) p.types[(size_t) id];
+            if (type == SPACE_RU && id < 50000) { put(id, part(id < 20000 ? 0.30 : id < 35000 ? 0.40 : 0.50)); continue; }
+            if (type == SPACE_EN && id < 1100) { put(id, part(id < 500 ? 0.30 : id < 800 ? 0.40 : 0.50)); continue; }
+        }
+    } else {                                       // Llama-2 / Mistral vocabulary: a table of token ids
+        static const struct { double k; int ids[20]; } table[] = {
+            { 0.10, { 13, 29871, 29892, -1 } },
+            { 0.20, { 259, 268, 29889, -1 } },
+            { 0.30, { 813, 29899, 29901, 29936, 313, 467, 1723, 29897, 29898, 490, 531, 606, 614, 263, 278, 297, 304, 310, 322, -1 } },
+            { 0.35, { 665, 733, 863, 363, 372, 373, 385, 393, 408, 411, -1 } },
+            { 0.40, { 1077, 1097, 1186, 470, 472, 526, -1 } },
+            { 0.45, { 1447, 1538, 1604, 1685, -1 } },
+            { 0.50, { 4281, 857, 939, 1651, 319, -1 } },
+        };
+        put(EOS_HARDCODED, scale);
+        for (const auto & row : table) for (int i = 0; i < 20 && row.ids[i] >= 0; i++) put(row.ids[i], part(row.k));
+    }
     p.janus_ready = true;
 }
 
@@ -417,6 +447,26 @@ BAMD_API bamd_vocab * bamd_vocab_load(const char * gguf_path) {
     return h.release();
 }
 BAMD_API void bamd_vocab_free(bamd_vocab * h) { delete h; }
+// test hooks: the host Janus sampler (init_janus + sample_janus) on a vocabulary-only GGUF and scripted logits — no GPU involved
+BAMD_API void * bamd_janus_test_new(const bamd_vocab * h, float scale, float hi, float lo, int depth) {
+    Pod * p = new Pod();
+    p->vocab = h->v; p->n_vocab = h->v.n_vocab();
+    p->jp.scale = scale; p->jp.hi = hi; p->jp.lo = lo; p->jp.depth = depth;
+    init_janus(*p);
+    return p;
+}
+BAMD_API void bamd_janus_test_tables(void * pod, float * types, float * scales) {
+    Pod & p = *(Pod *) pod;
+    memcpy(types, p.types.data(), p.types.size() * 4); memcpy(scales, p.scales.data(), p.scales.size() * 4);
+}
+// logits: n_vocab floats, modified in place as the sampler does; last: the n_last most recent tokens (newest last)
+BAMD_API int bamd_janus_test_sample(void * pod, float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed) {
+    Pod & p = *(Pod *) pod;
+    p.rng.seed(seed);
+    const std::vector<int> last_tokens(last, last + n_last);
+    return sample_janus(p, logits, last_tokens, (size_t) prompt_len, (size_t) pos, (size_t) max);
+}
+BAMD_API void bamd_janus_test_free(void * pod) { delete (Pod *) pod; }
 BAMD_API int bamd_vocab_tokenize(const bamd_vocab * h, const char * text, int text_len, int add_special, int parse_special, int32_t * out, int cap) {
     const std::vector<int> t = h->v.tokenize(std::string(text, (size_t) text_len), add_special != 0, parse_special != 0);
     for (int i = 0; i < (int) t.size() && i < cap; ++i) out[i] = t[(size_t) i];

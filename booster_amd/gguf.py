@@ -289,6 +289,52 @@ def synthetic_spm_vocab(n_extra=200, seed=1):
                 add_bos_token=True, add_space_prefix=True)
 
 
+def synthetic_janus_vocab(n_total=640, seed=5):
+    """SPM vocab of n_total tokens for the Janus sampler tests: the synthetic_spm_vocab pieces, the punctuation / whitespace /
+    'pedantic' pieces cpp/janus.cpp names (:381-392, :536-560), then random Latin, Cyrillic and other-script pieces with and without
+    the leading space, interleaved over the whole id range — so that every token class (LANG_/SPACE_ EN, RU, OTHER, ZERO), every
+    scale formula, the id-range rules of the Llama-3 branch (n_total > 128000) and the id table of the Llama-2 branch occur.
+    Pieces stay below 20 bytes (Latin) / 40 bytes (Cyrillic): the reference indexes a 20-entry table by piece length without a
+    bound.  "<|im_end|>" gives the vocabulary an EOT id (the reference writes scales[eot] unchecked)."""
+    import random
+    rnd = random.Random(seed)
+    v = synthetic_spm_vocab(n_extra=60, seed=seed)
+    toks, scores, types = v["tokens"][:-1], v["scores"][:-1], v["types"][:-1]
+    ru = "абвгдежзиклмнопрстуфхцчшщыэюяё"
+    ru_up = "АБВГДЕЖЗИКЛМНОПРСТУФ"
+    en = "abcdefghijklmnopqrstuvwxyz"
+    other = "\u00e9\u00fc\u00f1\u4e2d\u6587\u3042\u0391\u05d0"
+    seen = set(toks)
+    sp = "\u2581"
+    extra = [sp + "*", sp + "=", sp + "-", sp + "+", "{", "}", "[", "]", sp + "{", sp + "}", sp + "[", sp + "]", "```", "<|end_of_text|>",
+             "12", "345", sp, sp + sp, sp + sp + sp + sp, sp + "\u2014", ":", ";", sp + "(", ").", sp + ")", ")", "(", "\n\n",
+             "\u00e9t\u00e9", sp + "\u00e9", "\u4e2d\u6587", sp + "\u4e2d", "\u041f\u0440\u0438", sp + "\u041c\u0438\u0440", "\u0401\u0436", "ab\u0436"]
+    for piece in extra:
+        if piece not in seen:
+            seen.add(piece); toks.append(piece); scores.append(-rnd.random() * 8.0); types.append(1)
+    while len(toks) < n_total - 2:
+        script = rnd.choice(["ru", "ru", "ru", "en", "en", "other", "RU", "EN"])
+        n = rnd.choice([1, 2, 2, 3, 4, 6, 9])
+        if script == "ru":
+            body = "".join(rnd.choice(ru) for _ in range(n))
+        elif script == "RU":
+            body = rnd.choice(ru_up) + "".join(rnd.choice(ru) for _ in range(n - 1))
+        elif script == "en":
+            body = "".join(rnd.choice(en) for _ in range(n))
+        elif script == "EN":
+            body = rnd.choice(en).upper() + "".join(rnd.choice(en) for _ in range(n - 1))
+        else:
+            body = "".join(rnd.choice(other) for _ in range(min(n, 4)))
+        piece = (sp if rnd.random() < 0.4 else "") + body
+        if piece in seen:
+            continue
+        seen.add(piece); toks.append(piece); scores.append(-rnd.random() * 8.0 - n * 0.01); types.append(1)
+    toks.append("<|im_end|>"); scores.append(0.0); types.append(3)
+    toks.append("<|user|>"); scores.append(0.0); types.append(4)
+    v.update(tokens=toks, scores=scores, types=types)
+    return v
+
+
 def _bytes_to_unicode():
     bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
     cs = bs[:]

@@ -99,6 +99,13 @@ int bamd_vocab_eot(const bamd_vocab * v);
  * candidate with logit / top < cutoff) through the linear-time path (fast = 1; falls back by itself when ties or a non-positive top
  * make the order depend on the full sort) or the full-sort path (fast = 0).  Writes up to `cap` ids in order, returns the count. */
 int bamd_janus_shortlist_test(const float * logits, int n_vocab, float cutoff, int fast, int32_t * ids, int cap);
+/* Test hooks, CPU only: the host Janus sampler on a vocabulary (initJanus, janus.cpp:410-700; sample_janus_token, janus.cpp:191-331;
+ * llama_sample_token, llama-sampling.cpp:610-631).  _new builds the per-token type / scale tables; _sample applies the penalties to
+ * `logits` (n_vocab floats) in place and draws with std::mt19937(seed); last = the most recent tokens, newest last. */
+void * bamd_janus_test_new(const bamd_vocab * v, float scale, float hi, float lo, int depth);
+void bamd_janus_test_tables(void * janus, float * types, float * scales);
+int bamd_janus_test_sample(void * janus, float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed);
+void bamd_janus_test_free(void * janus);
 
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
