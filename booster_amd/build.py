@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libbooster_amd.so")
-SOURCES = ["bamd_matvec.hip", "bamd_attention.hip", "bamd_prefill.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
+SOURCES = ["bamd_matvec.hip", "bamd_attention.hip", "bamd_prefill.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
 HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_device.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
 # -ffp-contract=off: the numerics contract (bit-parity with the reference CPU path) forbids implicit FMA fusion.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]

@@ -43,6 +43,8 @@ struct Pod {
     std::mt19937 rng;
     std::atomic<bool> stop{ false };
     std::vector<float> logits;                   // host copy the sampler may modify in place
+    bool gpu_sampler = false;                    // Janus penalties + shortlist on the device (bamd_logits_shortlist); env BAMD_JANUS_GPU=0 disables
+    int64_t n_sample_dev = 0, n_sample_host = 0; // tokens sampled from the device shortlist / through the host path
     // llama_timings equivalents (llama.cpp:18527-18551)
     double t_p_eval_ms = 0, t_eval_ms = 0; int64_t n_p_eval = 0, n_eval = 0;
 };
@@ -153,6 +155,23 @@ void init_janus(Pod & p) {                        // cpp/janus.cpp:410-490
 }
 
 struct Cand { int id; float logit, p; };
+float janus_cutoff(const Pod & p, int topToken);
+// the per-vocabulary tables of the device sampler, on the stage that owns the output layer; false = stay on the host sampler
+bool upload_sampler_tables(Pod & p) {
+    const char * e = getenv("BAMD_JANUS_GPU");
+    p.gpu_sampler = false;
+    if ((e && atoi(e) == 0) || p.stages.empty()) return false;
+    std::vector<uint8_t> cls((size_t) p.n_vocab); std::vector<float> cut((size_t) p.n_vocab);
+    for (int id = 0; id < p.n_vocab; id++) {
+        const float t = p.types[(size_t) id];
+        cls[(size_t) id] = (t == LANG_EN || t == LANG_OTHER) ? 1 : 0;
+        cut[(size_t) id] = janus_cutoff(p, id);
+    }
+    if (bamd_sampler_tables(p.stages.back().ctx, cls.data(), cut.data(), p.n_vocab)) return false;
+    if (p.stages.size() == 1) bamd_set_logits_readback(p.stages[0].ctx, 0);
+    p.gpu_sampler = true;
+    return true;
+}
 
 // cpp/janus.cpp:191-331 + llama_sample_token (llama-sampling.cpp:32-58, :610-631)
 // The shortlist of sample_janus_token (janus.cpp:262-300): ALL candidates sorted by logit (std::sort, descending), the cut-off
@@ -190,6 +209,21 @@ static void janus_shortlist(const float * logits, size_t V, CutoffFn cutoff_of, 
     for (size_t i = 1; i < cand.size(); i++) if (cand[i].logit / topLogit < cutoff) { cand.resize(i); break; }
 }
 
+// the cut-off of the shortlist, chosen by the top token (janus.cpp:303-306)
+float janus_cutoff(const Pod & p, int topToken) {
+    const float topType = p.types[(size_t) topToken];
+    return (is_pedantic(p.vocab.token_to_piece(topToken)) || topType == LANG_RU || topType == LANG_EN) ? p.jp.hi : p.jp.lo;
+}
+// llama_sample_token (llama-sampling.cpp:610-631): softmax over the sorted shortlist, one draw from std::discrete_distribution on the pod's mt19937
+static int janus_draw(Pod & p, std::vector<Cand> & cand) {
+    const float max_l = cand[0].logit; float cum = 0.0f;
+    for (auto & c : cand) { c.p = expf(c.logit - max_l); cum += c.p; }
+    std::vector<float> probs; probs.reserve(cand.size());
+    for (auto & c : cand) { c.p /= cum; probs.push_back(c.p); }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return cand[(size_t) dist(p.rng)].id;
+}
+
 int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, size_t promptLen, size_t pos, size_t max) {
     const size_t V = (size_t) p.n_vocab, ctxSize = last_tokens.size();
     const int lastToken = last_tokens[ctxSize - 1];
@@ -207,17 +241,63 @@ int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, 
         if ((lastType == SPACE_RU || lastType == LANG_RU) && (curType == LANG_EN || curType == LANG_OTHER)) logits[id] *= 0.5;
     }
     std::vector<Cand> cand;
-    janus_shortlist(logits, V, [&](int topToken) {
-        const float topType = p.types[(size_t) topToken];
-        return (is_pedantic(p.vocab.token_to_piece(topToken)) || topType == LANG_RU || topType == LANG_EN) ? p.jp.hi : p.jp.lo;
-    }, true, cand);
-    // softmax over the (sorted) shortlist, then one draw from std::discrete_distribution on the pod's mt19937
-    const float max_l = cand[0].logit; float cum = 0.0f;
-    for (auto & c : cand) { c.p = expf(c.logit - max_l); cum += c.p; }
-    std::vector<float> probs; probs.reserve(cand.size());
-    for (auto & c : cand) { c.p /= cum; probs.push_back(c.p); }
-    std::discrete_distribution<> dist(probs.begin(), probs.end());
-    return cand[(size_t) dist(p.rng)].id;
+    janus_shortlist(logits, V, [&](int topToken) { return janus_cutoff(p, topToken); }, true, cand);
+    return janus_draw(p, cand);
+}
+
+// The same sampler with the O(n_vocab) passes on the device: the penalties become a short list of per-token factors
+// (a token that occurs k times in the window is multiplied k times, in sequence, as the reference's loop does), the x0.5 pass and
+// the ratio test run where the logits are, and only the shortlist comes back.  Whenever the order of the result could depend on the
+// reference's full sort the (already penalised) logits are read back and the host shortlist runs on them: same result either way.
+int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t promptLen, size_t pos, size_t max) {
+    const size_t V = (size_t) p.n_vocab, ctxSize = last_tokens.size();
+    Stage & st = p.stages.back();
+    const float lastType = p.types[(size_t) last_tokens[ctxSize - 1]];
+    const bool ru_context = lastType == SPACE_RU || lastType == LANG_RU;
+    std::vector<bamd_logit_penalty> pen;
+    std::unordered_map<int, size_t> slot;
+    auto entry = [&](int id) -> bamd_logit_penalty & {
+        auto it = slot.find(id);
+        if (it == slot.end()) { it = slot.emplace(id, pen.size()).first; pen.push_back(bamd_logit_penalty{ id, 0, 0, 1.0f, 1.0, 0.0 }); }
+        return pen[it->second];
+    };
+    if (V > (size_t) EOS_HARDCODED) entry(EOS_HARDCODED).pre = 1.0 + log(1.0 + float(pos - promptLen) / float(max)) * 0.05;
+    const size_t depth = std::min((size_t) p.jp.depth, pos - promptLen);
+    for (size_t i = 0; i < depth; i++) {
+        const int id = last_tokens[ctxSize - 1 - i];
+        bamd_logit_penalty & e = entry(id);
+        if (ru_context && p.types[(size_t) id] == LANG_RU) { e.kind = 1; e.d = 1.0 - (1.0 - p.scales[(size_t) id]) * 0.20; }
+        else { e.kind = 0; e.f = p.scales[(size_t) id]; }
+        e.count++;
+    }
+    std::vector<Cand> cand;
+    bool host_path = pen.size() > (size_t) BAMD_PENALTY_CAP;
+    if (!host_path) {
+        bamd_shortlist_head head;
+        std::vector<int32_t> ids((size_t) BAMD_SHORTLIST_CAP); std::vector<float> vals((size_t) BAMD_SHORTLIST_CAP);
+        void * stream = p.stages.size() == 1 ? bamd_context_stream(st.ctx) : nullptr;
+        if (bamd_logits_shortlist(st.ctx, pen.data(), (int) pen.size(), ru_context ? 1 : 0, &head, ids.data(), vals.data(), stream)) return -1;
+        host_path = head.nan || !(head.top_logit > 0.0f) || head.ntop != 1 || head.count < 1 || head.count > BAMD_SHORTLIST_CAP;
+        if (!host_path) {
+            for (int i = 0; i < head.count; i++) cand.push_back(Cand{ ids[(size_t) i], vals[(size_t) i], 0.0f });
+            std::sort(cand.data(), cand.data() + cand.size(), [](const Cand & a, const Cand & b) { return a.logit > b.logit; });
+            host_path = cand[0].id != head.top_id;
+            for (size_t i = 1; i < cand.size() && !host_path; i++) host_path = !(cand[i].logit < cand[i - 1].logit);
+        }
+        if (host_path) {                          // the device logits already carry the penalties: shortlist them on the host
+            const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, nullptr);
+            if (!lg) return -1;
+            janus_shortlist(lg, V, [&](int topToken) { return janus_cutoff(p, topToken); }, true, cand);
+        }
+    } else {                                      // more distinct penalised tokens than the device list holds: the host sampler
+        const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, nullptr);
+        if (!lg) return -1;
+        memcpy(p.logits.data(), lg, V * 4);
+        p.n_sample_host++;
+        return sample_janus(p, p.logits.data(), last_tokens, promptLen, pos, max);
+    }
+    if (host_path) p.n_sample_host++; else p.n_sample_dev++;
+    return janus_draw(p, cand);
 }
 
 // ---- model placement: Booster's gpus: split (cpp/bridge.cpp:745-750, llama.cpp:5932-5969) ----------------------------------
@@ -245,7 +325,7 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
     const auto t0 = std::chrono::steady_clock::now();
     if (p.stages.size() == 1) {
         if (bamd_decode(p.stages[0].ctx, tokens, n, n_past)) return 1;
-        memcpy(p.logits.data(), bamd_get_logits(p.stages[0].ctx), (size_t) p.n_vocab * 4);
+        if (!p.gpu_sampler) memcpy(p.logits.data(), bamd_get_logits(p.stages[0].ctx), (size_t) p.n_vocab * 4);     // else the logits stay on the device
     } else {
         // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
         // and shapes without batched kernels, step token by token
@@ -269,9 +349,14 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
                 if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }   // hand-off: producer done before consumer starts
             }
         }
-        const float * lg = bamd_stage_get_logits(p.stages.back().ctx, nullptr);
-        if (!lg) return 1;
-        memcpy(p.logits.data(), lg, (size_t) p.n_vocab * 4);
+        if (!p.gpu_sampler) {
+            const float * lg = bamd_stage_get_logits(p.stages.back().ctx, nullptr);
+            if (!lg) return 1;
+            memcpy(p.logits.data(), lg, (size_t) p.n_vocab * 4);
+        } else {                                  // the logits stay on the last device; llama_decode's synchronisation still applies
+            hipSetDevice(p.stages.back().device);
+            if (hipStreamSynchronize(nullptr) != hipSuccess) return 1;
+        }
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (n == 1) { p.t_eval_ms += ms; p.n_eval += 1; } else { p.t_p_eval_ms += ms; p.n_p_eval += n; }    // llama_synchronize, llama.cpp:18527-18551
@@ -355,7 +440,7 @@ BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID
     const std::string job = jobID, text = prompt;
     p.t_p_eval_ms = p.t_eval_ms = 0; p.n_p_eval = p.n_eval = 0;             // llama_reset_timings
     p.stop.store(false);
-    if (!p.janus_ready) init_janus(p);                                       // the reference rebuilds (and leaks) the tables per request
+    if (!p.janus_ready) { init_janus(p); upload_sampler_tables(p); }                                       // the reference rebuilds (and leaks) the tables per request
     const uint32_t seed = (uint32_t) time(nullptr);
     p.rng.seed(seed);                                                        // llama_set_rng_seed
     { std::lock_guard<std::mutex> lk(g_mu); g_jobs[job].seed = seed; }
@@ -385,7 +470,9 @@ BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID
         }
         embd.clear();
         if ((int) embd_inp.size() <= n_consumed) {
-            const int id = sample_janus(p, p.logits.data(), last_tokens, embd_inp.size(), (size_t) n_past, (size_t) p.n_predict);
+            const int id = p.gpu_sampler ? sample_janus_device(p, last_tokens, embd_inp.size(), (size_t) n_past, (size_t) p.n_predict)
+                                         : sample_janus(p, p.logits.data(), last_tokens, embd_inp.size(), (size_t) n_past, (size_t) p.n_predict);
+            if (id < 0) return 1;
             last_tokens.erase(last_tokens.begin()); last_tokens.push_back(id);
             embd.push_back(id);
             --n_remain;
@@ -426,6 +513,33 @@ BAMD_API int bamd_janus_shortlist_test(const float * logits, int V, float cutoff
     janus_shortlist(logits, (size_t) V, [&](int) { return cutoff; }, fast != 0, cand);
     for (size_t i = 0; i < cand.size() && (int) i < cap; ++i) ids[i] = cand[i].id;
     return (int) cand.size();
+}
+
+// test hook: one draw of the pod's sampler on scripted logits (n_vocab floats, uploaded to the device of the output layer);
+// device = 1: penalties + shortlist on the device (sample_janus_device), 0: the host sampler.  logits_after (may be null) receives
+// the logits after the penalties.  counts[2] (may be null): draws served by the device shortlist / by the host path so far.
+BAMD_API int bamd_bridge_sample_test(void * ctx, const float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed,
+                                     int device, float * logits_after, int64_t * counts) {
+    Pod & p = *(Pod *) ctx;
+    if (!p.janus_ready) { init_janus(p); upload_sampler_tables(p); }
+    p.rng.seed(seed);
+    const std::vector<int> last_tokens(last, last + n_last);
+    int id;
+    if (device) {
+        if (!p.gpu_sampler || bamd_set_logits_test(p.stages.back().ctx, logits)) return -1;
+        id = sample_janus_device(p, last_tokens, (size_t) prompt_len, (size_t) pos, (size_t) max);
+        if (logits_after) {
+            const float * lg = p.stages.size() == 1 ? bamd_get_logits(p.stages.back().ctx) : bamd_stage_get_logits(p.stages.back().ctx, nullptr);
+            if (!lg) return -1;
+            memcpy(logits_after, lg, (size_t) p.n_vocab * 4);
+        }
+    } else {
+        memcpy(p.logits.data(), logits, (size_t) p.n_vocab * 4);
+        id = sample_janus(p, p.logits.data(), last_tokens, (size_t) prompt_len, (size_t) pos, (size_t) max);
+        if (logits_after) memcpy(logits_after, p.logits.data(), (size_t) p.n_vocab * 4);
+    }
+    if (counts) { counts[0] = p.n_sample_dev; counts[1] = p.n_sample_host; }
+    return id;
 }
 
 BAMD_API int bamd_bridge_tokenize(void * ctx, const char * text, int add_special, int parse_special, int32_t * out, int cap) {

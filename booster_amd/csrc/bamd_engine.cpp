@@ -110,6 +110,11 @@ struct bamd_context {
     int n_ctx_pad = 0;              // KV row stride: n_ctx rounded up to 64 (V^T rows are stored in 64-position blocks)
     float * logits = nullptr;        // device
     float * logits_host = nullptr;   // pinned
+    bool logits_readback = true, logits_host_valid = false;
+    // sampler prefilter (bamd_logits_shortlist): per-vocabulary tables, penalty list and result (device + pinned mirrors)
+    uint8_t * samp_cls = nullptr; float * samp_cut = nullptr;
+    bamd_logit_penalty * samp_pen = nullptr, * samp_pen_host = nullptr;
+    unsigned char * samp_out = nullptr, * samp_out_host = nullptr;
     bamd_step_state * st = nullptr;
     int32_t * forced = nullptr; int forced_cap = 0;
     int32_t * out_tokens = nullptr; int out_cap = 0;
@@ -336,6 +341,8 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
     if (c->logits_host) hipHostFree(c->logits_host);
+    if (c->samp_pen_host) hipHostFree(c->samp_pen_host);
+    if (c->samp_out_host) hipHostFree(c->samp_out_host);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -560,7 +567,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
             if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);
         }
     }
-    if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
+    c->logits_host_valid = c->logits_readback;
+    if (c->logits_readback && hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
     return 0;
@@ -585,7 +593,66 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_co
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; g_prefill_mfma = on == 2 ? 0 : 1; }
-extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) { return c->logits_host; }
+extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(bamd_context * c) {
+    if (!c->logits_host_valid) {                                          // bamd_set_logits_readback(c, 0): copy on demand
+        if (hipSetDevice(c->m->device) != hipSuccess) return nullptr;
+        if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) c->m->V * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return nullptr;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
+        c->logits_host_valid = true;
+    }
+    return c->logits_host;
+}
+extern "C" __attribute__((visibility("default"))) void bamd_set_logits_readback(bamd_context * c, int on) { c->logits_readback = on != 0; }
+extern "C" __attribute__((visibility("default"))) void * bamd_context_stream(bamd_context * c) { return (void *) c->stream; }
+extern "C" __attribute__((visibility("default"))) int bamd_set_logits_test(bamd_context * c, const float * logits) {
+    if (hipSetDevice(c->m->device) != hipSuccess) return 1;
+    HIPC(hipMemcpy(c->logits, logits, (size_t) c->m->V * 4, hipMemcpyHostToDevice));
+    c->logits_host_valid = false;
+    return 0;
+}
+
+// ---- sampler prefilter (kernels in bamd_sampler.hip) --------------------------------------------------------
+extern "C" __attribute__((visibility("default"))) int bamd_sampler_tables(bamd_context * c, const uint8_t * halve_class, const float * cutoff_of, int n_vocab) {
+    bamd_model * m = c->m;
+    if (n_vocab != m->V || !m->with_output) { fail("bamd_sampler_tables: needs the stage that owns the output layer, n_vocab of the model"); return 1; }
+    if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
+    if (!c->samp_cls) {
+        const size_t out_bytes = sizeof(bamd_shortlist_head) + (size_t) BAMD_SHORTLIST_CAP * 8;
+        if (dev_alloc(c->allocs, (void **) &c->samp_cls, (size_t) m->V) || dev_alloc(c->allocs, (void **) &c->samp_cut, (size_t) m->V * 4) ||
+            dev_alloc(c->allocs, (void **) &c->samp_pen, sizeof(bamd_logit_penalty) * BAMD_PENALTY_CAP) || dev_alloc(c->allocs, (void **) &c->samp_out, out_bytes)) return 1;
+        HIPC(hipHostMalloc((void **) &c->samp_pen_host, sizeof(bamd_logit_penalty) * BAMD_PENALTY_CAP));
+        HIPC(hipHostMalloc((void **) &c->samp_out_host, out_bytes));
+    }
+    HIPC(hipMemcpy(c->samp_cls, halve_class, (size_t) m->V, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(c->samp_cut, cutoff_of, (size_t) m->V * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_logits_shortlist(bamd_context * c, const bamd_logit_penalty * pen, int n_pen, int halve,
+                                                                            bamd_shortlist_head * head, int32_t * ids, float * vals, void * hip_stream) {
+    bamd_model * m = c->m;
+    if (!c->samp_cls) { fail("bamd_logits_shortlist before bamd_sampler_tables"); return 1; }
+    if (n_pen < 0 || n_pen > BAMD_PENALTY_CAP) { fail("bamd_logits_shortlist: too many penalty entries"); return 1; }
+    if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
+    hipStream_t s = (hipStream_t) hip_stream;
+    const size_t out_bytes = sizeof(bamd_shortlist_head) + (size_t) BAMD_SHORTLIST_CAP * 8;
+    if (n_pen) {
+        memcpy(c->samp_pen_host, pen, sizeof(bamd_logit_penalty) * (size_t) n_pen);
+        HIPC(hipMemcpyAsync(c->samp_pen, c->samp_pen_host, sizeof(bamd_logit_penalty) * (size_t) n_pen, hipMemcpyHostToDevice, s));
+    }
+    bamd_shortlist_head * dh = (bamd_shortlist_head *) c->samp_out;
+    int32_t * dids = (int32_t *) (c->samp_out + sizeof(bamd_shortlist_head));
+    float * dvals = (float *) (c->samp_out + sizeof(bamd_shortlist_head) + (size_t) BAMD_SHORTLIST_CAP * 4);
+    bamd_launch_sampler_shortlist(c->logits, c->samp_pen, n_pen, c->samp_cls, halve, c->samp_cut, m->V, dh, dids, dvals, BAMD_SHORTLIST_CAP, s);
+    c->logits_host_valid = false;
+    HIPC(hipMemcpyAsync(c->samp_out_host, c->samp_out, out_bytes, hipMemcpyDeviceToHost, s));
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { fail(std::string("sampler prefilter failed: ") + hipGetErrorString(e)); return 1; }
+    memcpy(head, c->samp_out_host, sizeof *head);
+    const int n = std::min(std::max(head->count, 0), BAMD_SHORTLIST_CAP);
+    memcpy(ids, c->samp_out_host + sizeof(bamd_shortlist_head), (size_t) n * 4);
+    memcpy(vals, c->samp_out_host + sizeof(bamd_shortlist_head) + (size_t) BAMD_SHORTLIST_CAP * 4, (size_t) n * 4);
+    return 0;
+}
 
 static int build_graph(bamd_context * c, int pos_hi) {
     hipStream_t s = c->stream;
@@ -622,6 +689,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     HIPC(hipMemcpyAsync(out_tokens, c->out_tokens, (size_t) (n_steps + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPC(hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    c->logits_host_valid = true;
     if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/bamd.h"   // bamd_logit_penalty, bamd_shortlist_head
 
 enum { BAMD_PRO_PLAIN = 0, BAMD_PRO_NORM = 1 };
 enum { BAMD_EPI_STORE = 0, BAMD_EPI_ADD = 1, BAMD_EPI_SILU_MUL = 2, BAMD_EPI_ARGMAX = 3 };
@@ -67,3 +68,5 @@ void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_
 int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported
+void bamd_launch_sampler_shortlist(float * logits, const bamd_logit_penalty * pen, int n_pen, const uint8_t * halve_class, int halve,
+                                   const float * cutoff_of, int V, bamd_shortlist_head * head, int32_t * ids, float * vals, int cap, hipStream_t s);

@@ -82,6 +82,28 @@ int bamd_model_device(const bamd_model * m);
 /* arg-max token of the last bamd_stage_step(want_logits=1) on the last stage; synchronises `hip_stream`. */
 int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token);
 
+/* ---- sampler prefilter on the device: the Janus penalties and shortlist where the lm_head left the logits ---- */
+/* one distinct penalised token: logit = (float)(logit * pre) when pre != 0 (the EOS boost, janus.cpp:236), then `count` times
+ * logit *= f (kind 0: float x float, janus.cpp:263) or logit = (float)(logit * d) (kind 1: float x double, janus.cpp:255) */
+typedef struct { int32_t id, count, kind; float f; double d, pre; } bamd_logit_penalty;
+typedef struct { unsigned long long top_key; int32_t count, ntop, nan, top_id; float top_logit, cutoff; } bamd_shortlist_head;
+#define BAMD_SHORTLIST_CAP 1024
+#define BAMD_PENALTY_CAP 512
+/* per-vocabulary tables, uploaded once: halve_class[id] != 0 = token of a class the x0.5 pass hits (janus.cpp:269-283);
+ * cutoff_of[id] = the shortlist cut-off when `id` is the top token (janus.cpp:303-306) */
+int bamd_sampler_tables(bamd_context * c, const uint8_t * halve_class, const float * cutoff_of, int n_vocab);
+/* Applies the penalties to the logits of the last decode / stage step IN PLACE on the device, then collects the candidates with
+ * !(logit / top < cutoff_of[top]) (unordered) into ids / vals (up to BAMD_SHORTLIST_CAP) and fills *head: count (may exceed the cap),
+ * ntop (logits equal to the top), nan, top_id, top_logit, cutoff.  Nothing is collected when top <= 0.  Runs on `hip_stream` —
+ * pass bamd_context_stream(c) after bamd_decode, the stage's stream after bamd_stage_step — and synchronises it.  Returns 0 or 1. */
+int bamd_logits_shortlist(bamd_context * c, const bamd_logit_penalty * pen, int n_pen, int halve, bamd_shortlist_head * head,
+                          int32_t * ids, float * vals, void * hip_stream);
+void * bamd_context_stream(bamd_context * c);
+/* 0: bamd_decode leaves the logits on the device; bamd_get_logits then copies them on demand (default 1: copied by every decode) */
+void bamd_set_logits_readback(bamd_context * c, int on);
+/* test hook: overwrite the device logits (n_vocab floats) */
+int bamd_set_logits_test(bamd_context * c, const float * logits);
+
 /* ---- tokenizer of a GGUF, CPU only: llama_tokenize / llama_token_to_piece / llama_token_is_eog ---- */
 typedef struct bamd_vocab bamd_vocab;
 bamd_vocab * bamd_vocab_load(const char * gguf_path);                   /* llm_load_vocab, llama.cpp:5250 */
@@ -106,6 +128,11 @@ void * bamd_janus_test_new(const bamd_vocab * v, float scale, float hi, float lo
 void bamd_janus_test_tables(void * janus, float * types, float * scales);
 int bamd_janus_test_sample(void * janus, float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed);
 void bamd_janus_test_free(void * janus);
+/* Test hook, GPU: one draw of a pod's sampler (ctx = what initContext returned) on scripted logits; device = 1 runs the penalties and
+ * the shortlist on the device (bamd_logits_shortlist), 0 the host sampler.  logits_after / counts[2] (device draws, host-path draws)
+ * may be NULL.  Returns the token, or -1. */
+int bamd_bridge_sample_test(void * ctx, const float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed,
+                            int device, float * logits_after, int64_t * counts);
 
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode

@@ -89,3 +89,36 @@ def test_layer_split_on_one_device_and_stop(lib, bamd, tmp_path):
     th = threading.Thread(target=lambda: res.setdefault("n", lib.doInference(1, ctx, b"job-long", b"", b"hello there")))
     th.start(); time.sleep(0.15); lib.stopInference(1); th.join(timeout=60)
     assert not th.is_alive() and 0 < res["n"] < 1500
+
+
+@pytest.mark.parametrize("name,idx", [("l2", 2), ("l2b", 3), ("l3", 4)])
+def test_device_sampler_equals_reference(lib, bamd, tmp_path, name, idx):
+    """the Janus penalties + shortlist on the device (bamd_logits_shortlist) against the fixtures recorded from the genuine
+    reference sampler (tests/golden/gen_janus_kats.py): logits after the penalties bit for bit, the same token from the same mt19937
+    seed — through the device shortlist and through the host sampler, including the cases that must fall back to the full sort."""
+    import os
+    from janus_cases import N_LAST, case_logits, digest
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "janus_kats.npz"))
+    g = lambda key: k[name + "_" + key]
+    V = int(g("V")[0]); scale, hi, lo, depth = g("params")
+    vocab = gguf.synthetic_janus_vocab(V)
+    path = str(tmp_path / "janus.gguf")
+    gguf.write_synthetic_llama(path, E=256, H=2, Hkv=1, L=1, F=256, V=V, seed=3, vocab=vocab)
+    ctx = lib.initContext(idx, path.encode(), 4, 512, 100, 0, 0, 0, 128, 16, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64,
+                          1, int(depth), float(scale), float(hi), float(lo), 42, b"")
+    assert ctx
+    lib.bamd_bridge_sample_test.restype = C.c_int
+    lib.bamd_bridge_sample_test.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    counts = np.zeros(2, np.int64)
+    n = len(g("token"))
+    for c in range(n):
+        logits = case_logits(g("seed")[c], V, g("negative")[c], g("ov_ids")[c], g("ov_vals")[c])
+        last = np.ascontiguousarray(g("last")[c], np.int32)
+        for device in (1, 0):
+            after = np.zeros(V, np.float32)
+            tok = lib.bamd_bridge_sample_test(ctx, logits.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), N_LAST, int(g("prompt_len")[c]),
+                                              int(g("pos")[c]), int(g("max")[c]), int(g("rng_seed")[c]), device, after.ctypes.data_as(C.c_void_p),
+                                              counts.ctypes.data_as(C.c_void_p))
+            assert digest(after) == str(g("digest")[c]), "case %d device=%d: logits after the penalties" % (c, device)
+            assert tok == int(g("token")[c]), "case %d device=%d: sampled token" % (c, device)
+    assert counts[0] >= n // 2 and counts[1] >= 1 and counts[0] + counts[1] == n     # most draws from the device shortlist, the tie / negative cases through the host path
