@@ -119,6 +119,8 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
 // MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3);
 // C/D rows 4g + i, token m (cdna_hip_programming.md, fragment layout).  One wave = 16 rows x 16 tokens over the whole K.
 typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void * bamd_lds_vp;
+typedef const __attribute__((address_space(1))) void * bamd_glb_vp;
 typedef float bamd_f4 __attribute__((ext_vector_type(4)));
 struct bamd_mma_args {
     const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
@@ -155,24 +157,29 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
     uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
     // staging plan: 33 uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
-    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int idx = tid + k * 512;
-            if (idx < BAMD_MMA_TOK * 33) {
-                const int tok = idx / 33, q = idx - tok * 33;
-                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
-                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
-            }
-        }
-        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    // Per-thread source offsets, fixed over the K loop.  The records go global -> LDS directly (global_load_lds_dwordx4: each wave's 64
+    // lanes fill 1 KiB of consecutive LDS, the source address is per lane), so the stage costs no registers and no ds_write pass; the
+    // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
+    // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
+    // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
+    const bool third = tid + 1024 < BAMD_MMA_TOK * 33;
+    auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
+        const int tok = idx / 33, q = idx - tok * 33;
+        const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+        return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
-    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
-        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
-        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
-    };
+    const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
+    uint32_t ysrc;
+    { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
+    float sy;
+#define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
+        unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
+        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc0), (bamd_lds_vp) st_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc1), (bamd_lds_vp) (st_ + 512 * 16), 16, 0, 0); \
+        if (third) __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc2), (bamd_lds_vp) (st_ + 1024 * 16), 16, 0, 0); \
+        sy = *(const float *) (a.blob16 + ysrc + (size_t) (ci_) * 4); } while (0)
+#define BAMD_STAGE_COMMIT(buf_) do { \
+        if (tid < BAMD_MMA_TOK) *(float *) (stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = sy; } while (0)
     const int rtc = live ? rt : 0;
     const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1152, * rec1 = rec0 + (size_t) nb * 1152;     // record groups of rows 0-7 / 8-15
     const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + 1024 + (m & 7) * 16;                                    // header of row m (lanes g == 0)
@@ -185,15 +192,14 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         for (int l = 0; l < 4; ++l) accm[n][l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
     }
     // prologue: stage super-block 0, prefetch the weights of super-block 0
-    uint4 sr[3]; float sy = 0.f;
-    stage_issue(0, sr, sy);
+    BAMD_STAGE_ISSUE(0, 0);
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
-    stage_commit(0, sr, sy);
+    BAMD_STAGE_COMMIT(0);
     __syncthreads();
     for (int ci = 0; ci < nb; ++ci) {
         const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
-        if (more) stage_issue(ci + 1, sr, sy);               // global loads of the next stage in flight during the math
+        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);  // the next stage in flight during the math (at the end: this one again, into the idle buffer)
         // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
         {
             const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
@@ -208,8 +214,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 *(uint4 *) (hl + m * 8) = h0; *(uint4 *) (hl + m * 8 + 4) = h1;
             }
         }
-        if (more) {                                          // prefetch the next super-block's weights
-            const uint32_t ro = (uint32_t) (ci + 1) * 1152u;
+        {                                                    // prefetch the next super-block's weights (the last one again at the end: unconditional)
+            const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1152u;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
         }
         // headers of the four C rows 4g + i; d products per token tile
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        if (more) BAMD_STAGE_COMMIT((ci + 1) & 1);
         __syncthreads();                                     // next stage visible; this stage and the wave tiles free again
     }
     if (!live) return;
@@ -316,24 +322,31 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
     uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA6_WAVE_LDS);    // ql tile [2][288]
     uint32_t * ql2 = wl + 2 * 288;                                                           // qh tile [2][144]
     uint32_t * hl = ql2 + 2 * 144;                                                           // row headers [16][8]
-    auto stage_issue = [&](int ci, uint4 (&r)[3], float & y) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int idx = tid + k * 512;
-            if (idx < BAMD_MMA_TOK * 33) {
-                const int tok = idx / 33, q = idx - tok * 33;
-                const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
-                r[k] = *(const uint4 *) (a.blob16 + (size_t) tg * b16 + (size_t) ci * BAMD_B16_REC + q * 16);
-            }
-        }
-        if (tid < BAMD_MMA_TOK) { const int tg = t0 + tid < a.T ? t0 + tid : a.T - 1; y = *(const float *) (a.blob16 + (size_t) tg * b16 + (size_t) nb * BAMD_B16_REC + ci * 4); }
+    // Per-thread source offsets, fixed over the K loop.  The records go global -> LDS directly (global_load_lds_dwordx4: each wave's 64
+    // lanes fill 1 KiB of consecutive LDS, the source address is per lane), so the stage costs no registers and no ds_write pass; the
+    // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
+    // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
+    // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
+    const bool third = tid + 1024 < BAMD_MMA_TOK * 33;
+    auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
+        const int tok = idx / 33, q = idx - tok * 33;
+        const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
+        return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
-    auto stage_commit = [&](int buf, const uint4 (&r)[3], float y) {
-        unsigned char * st = stage + (size_t) buf * BAMD_MMA_STAGE;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const int idx = tid + k * 512; if (idx < BAMD_MMA_TOK * 33) *(uint4 *) (st + (size_t) idx * 16) = r[k]; }
-        if (tid < BAMD_MMA_TOK) *(float *) (st + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = y;
-    };
+    const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
+    uint32_t ysrc;
+    { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
+    float sy;
+#undef BAMD_STAGE_ISSUE
+#undef BAMD_STAGE_COMMIT
+#define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
+        unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
+        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc0), (bamd_lds_vp) st_, 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc1), (bamd_lds_vp) (st_ + 512 * 16), 16, 0, 0); \
+        if (third) __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc2), (bamd_lds_vp) (st_ + 1024 * 16), 16, 0, 0); \
+        sy = *(const float *) (a.blob16 + ysrc + (size_t) (ci_) * 4); } while (0)
+#define BAMD_STAGE_COMMIT(buf_) do { \
+        if (tid < BAMD_MMA_TOK) *(float *) (stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = sy; } while (0)
     const int rtc = live ? rt : 0;
     const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = rec0 + (size_t) nb * 1680;
     const uint8_t * recm = m < 8 ? rec0 : rec1;                                             // record group of row m (lanes g == 0)
@@ -343,17 +356,16 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
     }
-    uint4 sr[3]; float sy = 0.f;
-    stage_issue(0, sr, sy);
+    BAMD_STAGE_ISSUE(0, 0);
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u);
     uint2 qa = ldnt<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldnt<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
     uint4 hsc = *(const uint4 *) (recm + 1536 + (m & 7) * 16); uint32_t hd = *(const unsigned short *) (recm + 1664 + (m & 7) * 2);
-    stage_commit(0, sr, sy);
+    BAMD_STAGE_COMMIT(0);
     __syncthreads();
     for (int ci = 0; ci < nb; ++ci) {
         const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
-        if (more) stage_issue(ci + 1, sr, sy);
+        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
         {
             const int r = lane >> 3, e = lane & 7;
             *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
@@ -362,8 +374,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
             *(uint2 *) (ql2 + 1 * 144 + r * 18 + e * 2) = qb;
             if (g == 0) { *(uint4 *) (hl + m * 8) = hsc; hl[m * 8 + 4] = hd; }
         }
-        if (more) {
-            const uint32_t ro = (uint32_t) (ci + 1) * 1680u;
+        {
+            const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1680u;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u);
             qa = ldnt<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldnt<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
             hsc = *(const uint4 *) (recm + ro + 1536 + (m & 7) * 16); hd = *(const unsigned short *) (recm + ro + 1664 + (m & 7) * 2);
@@ -423,7 +435,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        if (more) stage_commit((ci + 1) & 1, sr, sy);
+        if (more) BAMD_STAGE_COMMIT((ci + 1) & 1);
         __syncthreads();
     }
     if (!live) return;
