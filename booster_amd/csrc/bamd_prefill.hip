@@ -121,6 +121,21 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
 typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void * bamd_lds_vp;
 typedef const __attribute__((address_space(1))) void * bamd_glb_vp;
+// global -> LDS copy without registers: each active lane moves 16 (4) bytes from ITS global address to LDS base + lane * 16 (4).
+// Issued through inline asm on purpose: for the builtin the compiler cannot tell the destination buffer from the buffer being read
+// (both index the same dynamic LDS array) and puts s_waitcnt vmcnt(0) in front of the next LDS read, which serialises the copy with
+// the math it is meant to overlap.  The asm is invisible to the wait-count pass, so the consumer side waits explicitly
+// (lds_dma_wait before the barrier that publishes the stage); the compiler's own counted waits stay valid (completion is in order).
+__device__ __forceinline__ void lds_dma16(const void * gsrc, void * lds_wave_base) {
+    uint32_t keep; const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t) (size_t) (bamd_lds_vp) lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void * gsrc, void * lds_wave_base) {
+    uint32_t keep; const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t) (size_t) (bamd_lds_vp) lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// vmcnt(0) as the BUILTIN (imm: vmcnt 0, expcnt 7, lgkmcnt 15): the wait-count pass sees it and does not repeat it behind the next issue
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 typedef float bamd_f4 __attribute__((ext_vector_type(4)));
 struct bamd_mma_args {
     const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
@@ -171,15 +186,12 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
     uint32_t ysrc;
     { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
-    float sy;
 #define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
         unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
-        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc0), (bamd_lds_vp) st_, 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc1), (bamd_lds_vp) (st_ + 512 * 16), 16, 0, 0); \
-        if (third) __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc2), (bamd_lds_vp) (st_ + 1024 * 16), 16, 0, 0); \
-        sy = *(const float *) (a.blob16 + ysrc + (size_t) (ci_) * 4); } while (0)
-#define BAMD_STAGE_COMMIT(buf_) do { \
-        if (tid < BAMD_MMA_TOK) *(float *) (stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = sy; } while (0)
+        lds_dma16(sb_ + ssrc0, st_); lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
+        if (third) lds_dma16(sb_ + ssrc2, st_ + 1024 * 16); \
+        if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
+            lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
     const int rtc = live ? rt : 0;
     const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1152, * rec1 = rec0 + (size_t) nb * 1152;     // record groups of rows 0-7 / 8-15
     const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + 1024 + (m & 7) * 16;                                    // header of row m (lanes g == 0)
@@ -194,12 +206,11 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     // prologue: stage super-block 0, prefetch the weights of super-block 0
     BAMD_STAGE_ISSUE(0, 0);
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
-    BAMD_STAGE_COMMIT(0);
+    lds_dma_wait();
     __syncthreads();
     for (int ci = 0; ci < nb; ++ci) {
         const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
-        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);  // the next stage in flight during the math (at the end: this one again, into the idle buffer)
         // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
         {
             const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
@@ -214,10 +225,15 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 *(uint4 *) (hl + m * 8) = h0; *(uint4 *) (hl + m * 8 + 4) = h1;
             }
         }
-        {                                                    // prefetch the next super-block's weights (the last one again at the end: unconditional)
+        // the next stage and the next weights in flight during the math (at the end: this super-block again, the stage into the idle
+        // buffer).  Issued AFTER the registers of the previous prefetch were consumed: with a global_load_lds in flight the compiler
+        // waits vmcnt(0) at the next use of an ordinary load result, which would otherwise sit right behind the issue.
+        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
+        {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1152u;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
         }
+        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the math (the scheduler would sink it to the loop end)
         // headers of the four C rows 4g + i; d products per token tile
         float D[BAMD_MMA_NT][4], Dm[BAMD_MMA_NT][4]; uint4 mp[4];
         {
@@ -279,7 +295,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        if (more) BAMD_STAGE_COMMIT((ci + 1) & 1);
+        lds_dma_wait();
         __syncthreads();                                     // next stage visible; this stage and the wave tiles free again
     }
     if (!live) return;
@@ -336,17 +352,13 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
     const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
     uint32_t ysrc;
     { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
-    float sy;
 #undef BAMD_STAGE_ISSUE
-#undef BAMD_STAGE_COMMIT
 #define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
         unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
-        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc0), (bamd_lds_vp) st_, 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc1), (bamd_lds_vp) (st_ + 512 * 16), 16, 0, 0); \
-        if (third) __builtin_amdgcn_global_load_lds((bamd_glb_vp) (sb_ + ssrc2), (bamd_lds_vp) (st_ + 1024 * 16), 16, 0, 0); \
-        sy = *(const float *) (a.blob16 + ysrc + (size_t) (ci_) * 4); } while (0)
-#define BAMD_STAGE_COMMIT(buf_) do { \
-        if (tid < BAMD_MMA_TOK) *(float *) (stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC + tid * 4) = sy; } while (0)
+        lds_dma16(sb_ + ssrc0, st_); lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
+        if (third) lds_dma16(sb_ + ssrc2, st_ + 1024 * 16); \
+        if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
+            lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
     const int rtc = live ? rt : 0;
     const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = rec0 + (size_t) nb * 1680;
     const uint8_t * recm = m < 8 ? rec0 : rec1;                                             // record group of row m (lanes g == 0)
@@ -360,12 +372,11 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u);
     uint2 qa = ldnt<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldnt<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
     uint4 hsc = *(const uint4 *) (recm + 1536 + (m & 7) * 16); uint32_t hd = *(const unsigned short *) (recm + 1664 + (m & 7) * 2);
-    BAMD_STAGE_COMMIT(0);
+    lds_dma_wait();
     __syncthreads();
     for (int ci = 0; ci < nb; ++ci) {
         const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
-        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
         {
             const int r = lane >> 3, e = lane & 7;
             *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
@@ -374,12 +385,14 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
             *(uint2 *) (ql2 + 1 * 144 + r * 18 + e * 2) = qb;
             if (g == 0) { *(uint4 *) (hl + m * 8) = hsc; hl[m * 8 + 4] = hd; }
         }
+        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);  // after the previous prefetch was consumed (see the Q4_K kernel)
         {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1680u;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u);
             qa = ldnt<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldnt<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
             hsc = *(const uint4 *) (recm + ro + 1536 + (m & 7) * 16); hd = *(const unsigned short *) (recm + ro + 1664 + (m & 7) * 2);
         }
+        __builtin_amdgcn_sched_barrier(0);
         float D[BAMD_MMA_NT][4];
         {
             float dw[4];
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        if (more) BAMD_STAGE_COMMIT((ci + 1) & 1);
+        lds_dma_wait();
         __syncthreads();
     }
     if (!live) return;
