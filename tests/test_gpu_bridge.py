@@ -122,3 +122,37 @@ def test_device_sampler_equals_reference(lib, bamd, tmp_path, name, idx):
             assert digest(after) == str(g("digest")[c]), "case %d device=%d: logits after the penalties" % (c, device)
             assert tok == int(g("token")[c]), "case %d device=%d: sampled token" % (c, device)
     assert counts[0] >= n // 2 and counts[1] >= 1 and counts[0] + counts[1] == n     # most draws from the device shortlist, the tie / negative cases through the host path
+
+
+def test_device_sampler_fallbacks(lib, bamd, tmp_path):
+    """device shortlist vs host sampler where the device path must hand over: more candidates inside the cut-off than its buffer holds
+    (1024), and no penalties at all (first generated token); same token, same logits after the penalties."""
+    V = 30100
+    vocab = gguf.synthetic_janus_vocab(V)
+    path = str(tmp_path / "janus_fb.gguf")
+    gguf.write_synthetic_llama(path, E=256, H=2, Hkv=1, L=1, F=256, V=V, seed=3, vocab=vocab)
+    ctx = lib.initContext(5, path.encode(), 4, 512, 100, 0, 0, 0, 128, 16, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64, 1, 200, 0.96, 0.99, 0.90, 42, b"")
+    assert ctx
+    lib.bamd_bridge_sample_test.restype = C.c_int
+    lib.bamd_bridge_sample_test.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(99)
+    counts = np.zeros(2, np.int64)
+    for case in range(6):
+        logits = rng.normal(2.0, 1.0, V).astype(np.float32)
+        if case < 3:                                     # 3000 candidates within 0.5 % of a unique top: inside either cut-off
+            ids = rng.choice(V - 300, 3000, replace=False) + 300
+            logits[ids] = (30.0 * (1.0 - rng.uniform(0.0, 0.004, 3000))).astype(np.float32)
+            logits[ids[0]] = np.float32(30.01)
+        else:
+            logits[int(rng.integers(300, V))] = np.float32(25.0)
+        last = rng.integers(300, V, 64).astype(np.int32)
+        prompt_len, pos = 10, (10 if case >= 3 else 40)   # pos == prompt_len: depth 0, only the EOS factor (x 1.0)
+        res = []
+        for device in (1, 0):
+            after = np.zeros(V, np.float32)
+            tok = lib.bamd_bridge_sample_test(ctx, logits.ctypes.data_as(C.c_void_p), last.ctypes.data_as(C.c_void_p), 64, prompt_len, pos, 100, 1234 + case,
+                                              device, after.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p))
+            res.append((tok, after))
+        assert res[0][0] == res[1][0] >= 0, "case %d" % case
+        assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)), "case %d: logits after the penalties" % case
+    assert counts[1] >= 3 and counts[0] >= 3            # the crowded cases went through the host path, the others stayed on the device
