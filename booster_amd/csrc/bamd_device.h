@@ -592,4 +592,4 @@ static inline size_t act_lds_bytes(int K) {
 #define BAMD_TT 8                       /* tokens per workgroup tile of matmul_batch_kernel */
 #define BAMD_BLOB_BYTES(nb) (BAMD_ACT_RED_OFF(nb))
 #define BAMD_B16_REC 528
-#define BAMD_BLOB16_BYTES(nb) ((size_t) (nb) * (BAMD_B16_REC + 4))
+#define BAMD_BLOB16_BYTES(nb) ((((size_t) (nb) * (BAMD_B16_REC + 4)) + 15) & ~(size_t) 15)   /* per-token stride: records + d_y floats, 16-byte multiple */

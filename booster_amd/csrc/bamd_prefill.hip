@@ -558,7 +558,7 @@ int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStrea
 }
 int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
                             hipStream_t s) {
-    if ((type != BAMD_Q4_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 1023)) return 1;     // K % 1024: 16-byte alignment of the per-token f16 blobs
+    if ((type != BAMD_Q4_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 255)) return 1;
     bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
     dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
     if (type == BAMD_Q6_K) {
