@@ -227,10 +227,21 @@ def main():
                    warmup=warmup, ms_per_step=result.pop("ms_per_step"), higher_is_better=True, scaling=result.pop("scaling"),
                    vs_baseline=None, dtype="int8xint4/6 dot -> f32 (Q4_K/Q6_K weights x Q8_K activations), f16 KV", data="synthetic")
         out.update(result)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line must be the LAST thing on stdout: RCCL writes a version banner through C stdio, which would otherwise be flushed
+    # at process exit, after Python's own buffer.  Drain C stdio first, print, flush, and leave without running more exit hooks.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
