@@ -1,3 +1,4 @@
+"""Mode-A mat-vec shapes only (gate/up, ffn_down forced to mode A, lm_head in Q6_K and Q4_K) — a quick A/B target for kernel edits (GPU box only)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import booster_amd as b

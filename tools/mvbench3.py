@@ -1,3 +1,4 @@
+"""Streaming rate of the mode-A mat-vec kernel by matrix size: Infinity-Cache-resident (75 MB) up to HBM-bound (0.9 GB) — the ceiling curve (GPU box only)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import booster_amd as b
