@@ -445,9 +445,9 @@ static bool prefill_batch_supported(const bamd_context * c) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
     if (!(g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 8192 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8))) return false;
-    // every mat-mul needs a kernel: the MFMA kernels take Q4_K / Q6_K at any K; the integer-dot kernel takes any
+    // every mat-mul needs a kernel: the MFMA kernels take every K-quant at any K; the integer-dot kernel takes any
     // K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
-    auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
+    auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
     for (const DevLayer & ly : m->layers)
         if (!ok(ly.wq.type, m->E) || !ok(ly.wk.type, m->E) || !ok(ly.wv.type, m->E) || !ok(ly.wo.type, m->E) || !ok(ly.wg.type, m->E) || !ok(ly.wu.type, m->E) || !ok(ly.wd.type, m->F)) return false;
     return true;
@@ -469,7 +469,7 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     bamd_model * m = c->m;
     const bool mfma_ok = g_prefill_mfma;
     if (epi == BAMD_EPI_SILU_MUL) {
-        if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
+        if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q5_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
             const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
             if (bamd_launch_matmul_mfma(a.seg[0].w, a.seg[0].type, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, a.ldo, s)) return 1;   // gate -> h
             if (bamd_launch_matmul_mfma(a.seg[1].w, a.seg[1].type, nv, a.seg[1].nrows, a.K, c->bblob16, T, c->bu, nullptr, a.ldo, s)) return 1;          // up
@@ -480,7 +480,7 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     }
     bamd_mm_args rest = a; rest.nseg = 0;
     for (int i = 0; i < a.nseg; ++i) {
-        if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q6_K)) {
+        if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q5_K || a.seg[i].type == BAMD_Q6_K)) {
             const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
             const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
             if (bamd_launch_matmul_mfma(a.seg[i].w, a.seg[i].type, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, a.ldo, s)) return 1;

@@ -156,9 +156,14 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 #define BAMD_MMA_NT 2
 #define BAMD_MMA_TOK (16 * BAMD_MMA_NT)
 #define BAMD_MMA_STAGE (BAMD_MMA_TOK * BAMD_B16_REC + BAMD_MMA_TOK * 4)          /* B records + yd */
-#define BAMD_MMA_WAVE_LDS (2 * 288 * 4 + 16 * 32)                                /* transposed A tile + row headers */
-template <int EPI>
+#define BAMD_MMA_WAVE_LDS (2 * 288 * 4 + 16 * 32 + 2 * 72 * 4)                   /* transposed A tile + row headers + Q5_K high-bit tile */
+// Q5 = true: Q5_K records (1408 B: + one dword of high bits per lane).  The fifth bit joins the nibble before the f16 build
+// (values <= 31, scale x value <= 1953: exact); (1024 + n) * s would overflow f16 at s = 63, so the bias is subtracted first (exact)
+// and the product takes one more packed instruction; the min terms follow ggml_vec_dot_q5_K_q8_K: ONE float per row,
+// summs = summs + dmin * (float) sum_j m_j S_j (multiply, then add: ggml-quants.c:7515-7518), added after the hsum tree.
+template <int EPI, bool Q5>
 __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
+    constexpr uint32_t RECB = Q5 ? 1408u : 1152u, HDRO = Q5 ? 1280u : 1024u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef short s2_t __attribute__((ext_vector_type(2)));
@@ -171,6 +176,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     unsigned char * stage = smem;                                            // [2][BAMD_MMA_STAGE]
     uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
     uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
+    uint32_t * qht = hl + 16 * 8;                                            // Q5_K: high-bit dwords [2][8 rows][9] (row stride padded)
     // staging plan: 33 uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
     // Per-thread source offsets, fixed over the K loop.  The records go global -> LDS directly (global_load_lds_dwordx4: each wave's 64
     // lanes fill 1 KiB of consecutive LDS, the source address is per lane), so the stage costs no registers and no ds_write pass; the
@@ -193,8 +199,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
             lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
     const int rtc = live ? rt : 0;
-    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1152, * rec1 = rec0 + (size_t) nb * 1152;     // record groups of rows 0-7 / 8-15
-    const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + 1024 + (m & 7) * 16;                                    // header of row m (lanes g == 0)
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * RECB, * rec1 = rec0 + (size_t) nb * RECB;     // record groups of rows 0-7 / 8-15
+    const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + HDRO + (m & 7) * 16;                                    // header of row m (lanes g == 0)
     bamd_f4 acc[BAMD_MMA_NT][8], accm[BAMD_MMA_NT][4];
 #pragma unroll
     for (int n = 0; n < BAMD_MMA_NT; ++n) {
@@ -206,6 +212,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     // prologue: stage super-block 0, prefetch the weights of super-block 0
     BAMD_STAGE_ISSUE(0, 0);
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
+    uint32_t qha = 0u, qhb = 0u;
+    if (Q5) { qha = ldnt<uint32_t>(rec0, 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, 1024u + (uint32_t) lane * 4u); }
     lds_dma_wait();
     __syncthreads();
     for (int ci = 0; ci < nb; ++ci) {
@@ -216,6 +224,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
             const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
             *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
             *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
+            if (Q5) { qht[0 * 72 + r * 9 + e] = qha; qht[1 * 72 + r * 9 + e] = qhb; }
             if (g == 0) {                                    // lanes 0..15: row m
                 uint32_t sc03, sc47, mn03, mn47; unpack_k4_(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
                 uint4 h0, h1;
@@ -230,8 +239,9 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         // waits vmcnt(0) at the next use of an ordinary load result, which would otherwise sit right behind the issue.
         BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
         {
-            const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1152u;
+            const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * RECB;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
+            if (Q5) { qha = ldnt<uint32_t>(rec0, ro + 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, ro + 1024u + (uint32_t) lane * 4u); }
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the math (the scheduler would sink it to the loop end)
         // headers of the four C rows 4g + i; d products per token tile
@@ -262,12 +272,22 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const uint32_t wq = wrow[e * 4];
-                const uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+                uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+                if (Q5) {                                    // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
+                    const uint32_t qh = qht[(m >> 3) * 72 + (m & 7) * 9 + e];
+                    lo |= ((qh >> (2 * g)) & 0x01010101u) << 4; hi |= ((qh >> (2 * g + 1)) & 0x01010101u) << 4;
+                }
                 union { uint32_t u; h2_t h; } c0, c1, c2, c3;
                 c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
                 c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
-                const h2_t a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2), a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
-                const h2_t a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2), a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+                h2_t a0, a1, a2, a3;
+                if (Q5) {
+                    const h2_t k1024 = { (_Float16) 1024.f, (_Float16) 1024.f };
+                    a0 = (c0.h - k1024) * slo2; a1 = (c1.h - k1024) * slo2; a2 = (c2.h - k1024) * shi2; a3 = (c3.h - k1024) * shi2;
+                } else {
+                    a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2); a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
+                    a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2); a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+                }
                 const bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
 #pragma unroll
                 for (int n = 0; n < BAMD_MMA_NT; ++n) {
@@ -287,11 +307,19 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t mpl[4] = { mp[i].x, mp[i].y, mp[i].z, mp[i].w };
+                if (Q5) {
+                    int hs = 0;
 #pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l];
-                    const float pm = (float) __builtin_amdgcn_sdot2(ma.v, sb.v, 0, false);
-                    accm[n][l][i] = fmaf(Dm[n][i], pm, accm[n][l][i]);
+                    for (int l = 0; l < 4; ++l) { union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l]; hs = __builtin_amdgcn_sdot2(ma.v, sb.v, hs, false); }
+                    const float t = Dm[n][i] * (float) hs;
+                    accm[n][0][i] = accm[n][0][i] + t;
+                } else {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l];
+                        const float pm = (float) __builtin_amdgcn_sdot2(ma.v, sb.v, 0, false);
+                        accm[n][l][i] = fmaf(Dm[n][i], pm, accm[n][l][i]);
+                    }
                 }
             }
         }
@@ -306,7 +334,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
-            const float mm = (accm[n][0][i] + accm[n][2][i]) + (accm[n][1][i] + accm[n][3][i]);
+            const float mm = Q5 ? accm[n][0][i] : (accm[n][0][i] + accm[n][2][i]) + (accm[n][1][i] + accm[n][3][i]);
             const float val = v + mm;
             const int row = rt * 16 + 4 * g + i;
             if (t < a.T && row < a.nrows) {
@@ -558,7 +586,7 @@ int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStrea
 }
 int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
                             hipStream_t s) {
-    if ((type != BAMD_Q4_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 255)) return 1;
+    if ((type != BAMD_Q4_K && type != BAMD_Q5_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 255)) return 1;
     bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
     dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
     if (type == BAMD_Q6_K) {
@@ -568,8 +596,13 @@ int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrow
         return 0;
     }
     const size_t lds = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
-    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds, s, a);
-    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds, s, a);
+    if (type == BAMD_Q5_K) {
+        if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD, true>),   grid, dim3(512), lds, s, a);
+        else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE, true>), grid, dim3(512), lds, s, a);
+        return 0;
+    }
+    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD, false>),   grid, dim3(512), lds, s, a);
+    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE, false>), grid, dim3(512), lds, s, a);
     return 0;
 }
 void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s) {

@@ -190,7 +190,8 @@ def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
 @pytest.mark.parametrize("t,K,rows,T,impl", [(12, 1024, 64, 5, 0), (14, 2048, 40, 19, 0), (13, 1024, 24, 9, 0),
                                                (12, 1024, 64, 16, 1), (12, 2048, 40, 21, 1), (12, 4096, 528, 37, 1), (12, 14336, 32, 16, 1),
                                                (14, 1024, 64, 16, 1), (14, 2048, 40, 21, 1), (14, 4096, 528, 37, 1), (14, 14336, 32, 33, 1),
-                                               (12, 768, 40, 21, 1), (14, 2816, 24, 17, 1), (12, 11008, 32, 16, 1), (14, 256, 16, 3, 1)])
+                                               (12, 768, 40, 21, 1), (14, 2816, 24, 17, 1), (12, 11008, 32, 16, 1), (14, 256, 16, 3, 1),
+                                               (13, 1024, 64, 16, 1), (13, 2048, 40, 21, 1), (13, 4096, 528, 37, 1), (13, 8192, 48, 33, 1), (13, 768, 24, 9, 1)])
 def test_mul_mat_batch(bamd, po, t, K, rows, T, impl):
     """batched prefill mat-mul (impl 0: integer-dot kernel, 1: MFMA kernel) == the reference's mul_mat per activation row, bit for bit;
     ragged token tiles, rows % 16 != 0, residual epilogue, K with an odd number of super-blocks (Llama-2's 11008)"""
