@@ -1,4 +1,4 @@
-// bamd_attention.hip — attention kernels: fused single-launch (decode, n_ctx <= 2048), three-launch long-context path, batched
+// bamd_attention.hip — attention kernels: fused single-launch (decode of short sequences), three-launch long-sequence path, batched
 // prefill attention with all query heads of a KV head per workgroup, batched KV store.  Helpers and layout: bamd_device.h.
 #include "bamd_device.h"
 
@@ -151,18 +151,17 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
 }
 
 // ---- ONE launch per layer, one workgroup per QUERY head (and per token of a prefill micro-batch) ---------------------------
-// scores and probabilities live in dynamic LDS (2 x n_ctx floats).  Single-token decode uses this kernel up to
-// BAMD_ATTN_FUSED_MAX positions (beyond that one workgroup per head no longer has the bandwidth: three-kernel path);
-// batched prefill, with T x H workgroups, up to BAMD_ATTN_BATCH_MAX.
-#define BAMD_ATTN_FUSED_MAX 2048
-#define BAMD_ATTN_BATCH_MAX 8192
+// scores and probabilities live in dynamic LDS (2 x ld floats, ld = the caller's bound on the padded sequence length, independent
+// of n_ctx).  Single-token decode uses this kernel for short sequences (beyond a few hundred positions one workgroup per head no
+// longer has the bandwidth: three-kernel path); batched prefill, with T x H workgroups, while the rows fit the LDS.
+#define BAMD_ATTN_LDS_MAX (144 * 1024)    /* score + probability rows of one workgroup */
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
     __shared__ __attribute__((aligned(16))) float qt[256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
-    float * sc = (float *) attn_dyn;                                         // [n_ctx] scores, then exp values (natural order)
-    float * pt = sc + a.n_ctx;                                               // [n_ctx] probabilities in V^T position order
+    float * sc = (float *) attn_dyn;                                         // [ld] scores, then exp values (natural order)
+    float * pt = sc + (a.lds_ld ? a.lds_ld : a.n_ctx);                       // [ld] probabilities in V^T position order (ld bounds the padded sequence length)
     __shared__ float redf[8];
     __shared__ double redd[8];
     const bamd_step_state * st = a.st;
@@ -318,8 +317,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __shared__ float redf[GQH][8];
     __shared__ double redd[GQH][8];
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
-    float * sc = (float *) attn_dyn;                                         // [GQH][n_ctx] scores, then exp values
-    float * pt = sc + (size_t) GQH * a.n_ctx;                                // [GQH][n_ctx] probabilities in V^T position order
+    const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;                            // LDS row length: bounds the padded sequence length of the micro-batch
+    float * sc = (float *) attn_dyn;                                         // [GQH][ld] scores, then exp values
+    float * pt = sc + (size_t) GQH * ld;                                     // [GQH][ld] probabilities in V^T position order
     const bamd_step_state * st = a.st;
     const int tokb = blockIdx.y;
     const int pos = st->pos + tokb;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int hh = 0; hh < GQH; ++hh) {
             float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
             if (valid) v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
-            if (e == 0 && i < n_kv) sc[(size_t) hh * n_ctx + i] = v;
+            if (e == 0 && i < n_kv) sc[(size_t) hh * ld + i] = v;
         }
     }
     __syncthreads();
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float scale = a.kq_scale;
 #pragma unroll
     for (int hh = 0; hh < GQH; ++hh) {
-        const float * s_ = sc + (size_t) hh * n_ctx;
+        const float * s_ = sc + (size_t) hh * ld;
         float mx = -INFINITY;
         for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s_[i] * scale; mx = w > mx ? w : mx; }
         uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
 #pragma unroll
     for (int hh = 0; hh < GQH; ++hh) {
-        float * s_ = sc + (size_t) hh * n_ctx;
+        float * s_ = sc + (size_t) hh * ld;
         float mx = redf[hh][0];
         for (int w = 1; w < 8; ++w) mx = redf[hh][w] > mx ? redf[hh][w] : mx;
         double sum = 0.0;
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
 #pragma unroll
     for (int hh = 0; hh < GQH; ++hh) {
-        const float * s_ = sc + (size_t) hh * n_ctx; float * p_ = pt + (size_t) hh * n_ctx;
+        const float * s_ = sc + (size_t) hh * ld; float * p_ = pt + (size_t) hh * ld;
         double tot = 0.0;
         for (int w = 0; w < 8; ++w) tot += redd[hh][w];
         const float fs = (float) (1.0 / tot);
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int u = 0; u < 8; ++u) vf[u] = h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu);
 #pragma unroll
                 for (int hh = 0; hh < GQH; ++hh) {
-                    const float * p_ = pt + (size_t) hh * n_ctx + b0 + e * 8;
+                    const float * p_ = pt + (size_t) hh * ld + b0 + e * 8;
                     const float4 pa = *(const float4 *) p_, pb = *(const float4 *) (p_ + 4);
                     const float pv[8] = { pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w };
                     float c = acc[hh][dd];
@@ -451,28 +451,29 @@ __global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
 // ===========================================================================================================
 // attention of a micro-batch of T tokens (a.batch = 1, a.ld_qkv / a.ld_out set): KV store for all tokens, then (head, token) workgroups
 int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
-    if (a.hd > 256 || (a.hd & 63) || a.n_ctx > BAMD_ATTN_BATCH_MAX || !a.batch) return 1;
+    const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
+    if (a.hd > 256 || (a.hd & 63) || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || !a.batch) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    // as many query heads of a KV head per workgroup as have their score buffers fit the LDS (2 x n_ctx floats each); else one
+    // as many query heads of a KV head per workgroup as have their score buffers fit the LDS (2 x ld floats each); else one
     int gqh = gq;
-    while (gqh > 1 && (size_t) gqh * a.n_ctx * 8 > 144 * 1024) gqh >>= 1;
-    const size_t lds_g = (size_t) gqh * a.n_ctx * 8;
+    while (gqh > 1 && (size_t) gqh * ld * 8 > BAMD_ATTN_LDS_MAX) gqh >>= 1;
+    const size_t lds_g = (size_t) gqh * ld * 8;
     const dim3 grid(a.Hkv * gq / (gqh > 1 ? gqh : 1), T);
     if (gqh == 8)      hipLaunchKernelGGL((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
     else if (gqh == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
     else if (gqh == 2) hipLaunchKernelGGL((attn_batch_kernel<2>), grid, dim3(512), lds_g, s, a, gq);
-    else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+    else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) ld * 8, s, a, gq);
     return 0;
 }
 
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
-    if (a.n_ctx <= BAMD_ATTN_BATCH_MAX && max_tiles >= 0) {
-        // the caller knows n_kv <= BAMD_ATTN_FUSED_MAX for this launch and the score buffers fit the LDS: one fused launch per
-        // layer, one workgroup per query head
-        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) a.n_ctx * 8, s, a, gq);
+    const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
+    if (max_tiles >= 0 && !(ld & 63) && (size_t) ld * 8 <= BAMD_ATTN_LDS_MAX) {
+        // the caller knows the sequence is short enough for one workgroup per query head and that ld bounds its padded length
+        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) ld * 8, s, a, gq);
         return 0;
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;

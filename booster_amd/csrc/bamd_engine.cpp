@@ -364,9 +364,11 @@ static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.s
 // enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
 // pos_hi: the highest position this enqueue (or every replay of the graph being captured) will see.  The single-launch attention
 // kernel (one workgroup per query head, serial over the sequence) wins below ~450 positions (measured crossover, 8B shape: 1.73 vs
-// 1.85 ms/token at 240, equal at 440, 2.06 vs 1.88 at 740) at any n_ctx <= 8192 (its LDS score buffers); longer sequences take the
+// 1.85 ms/token at 240, equal at 440, 2.06 vs 1.88 at 740) at any n_ctx (its LDS score rows are sized by the sequence bound, not by n_ctx); longer sequences take the
 // three-kernel path, whose cost is nearly flat up to a few thousand positions.
-static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && c->n_ctx_pad <= 8192 && pos_hi < 448; }
+static bool attn_fused_for(const bamd_context * c, int pos_hi) { (void) c; return g_attn_fused && pos_hi < 448; }
+// LDS row length of the single-launch / batched attention kernels for sequences up to position pos_hi: a multiple of 64, independent of n_ctx
+static int attn_lds_ld(const bamd_context * c, int pos_hi) { return std::min((pos_hi + 1 + 63) / 64 * 64, c->n_ctx_pad); }
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
     bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
@@ -391,6 +393,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         if (tm) tm->begin(s, 1, 0.0);
         // three-kernel path (scores | softmax | P.V) everywhere for now: the fused single-launch kernel is correct (tests)
         // but not yet faster at n_kv ~ 256 (14.9 vs 12.8 us on MI355X) — BAMD_ATTN_FUSED=1 selects it
+        t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances
         if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
         if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
@@ -441,10 +444,11 @@ extern "C" int bamd_stage_step(bamd_context * c, int32_t token, const void * tok
                                int prefill_mode, void * hip_stream);
 // ---- batched prefill: a micro-batch of T > 1 tokens through the layers at once (llama_decode with n_tokens > 1) -----------
 #define BAMD_PREFILL_CAP 512            /* the reference's default n_batch / n_ubatch */
-static bool prefill_batch_supported(const bamd_context * c) {
+// pos_hi: last position of the micro-batch — its score rows (2 x padded length floats per head) must fit the LDS: 18 432 positions
+static bool prefill_batch_supported(const bamd_context * c, int pos_hi) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
-    if (!(g_prefill_batch && g_attn_fused && c->n_ctx_pad <= 8192 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8))) return false;
+    if (!(g_prefill_batch && g_attn_fused && (size_t) attn_lds_ld(c, pos_hi) * 8 <= 144 * 1024 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8))) return false;
     // every mat-mul needs a kernel: the MFMA kernels take every K-quant at any K; the integer-dot kernel takes any
     // K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
     auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
@@ -519,7 +523,7 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = 1;
-        t.batch = 1; t.ld_qkv = ldq; t.ld_out = E;
+        t.batch = 1; t.ld_qkv = ldq; t.ld_out = E; t.lds_ld = attn_lds_ld(c, n_past + T - 1);
         if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
         // x2 = x + Wo . att
         bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, c->bblob16, s);
@@ -550,7 +554,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
     hipStream_t s = c->stream;
     if (hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s) != hipSuccess) { fail("H2D tokens"); return 1; }
-    if (n_tokens > 1 && n_tokens <= BAMD_PREFILL_CAP && prefill_batch_supported(c)) {
+    if (n_tokens > 1 && n_tokens <= BAMD_PREFILL_CAP && prefill_batch_supported(c, n_past + n_tokens - 1)) {
         // one micro-batch: every layer once for all tokens (each weight record unpacked once per 8 tokens), lm_head for the last
         if (ensure_batch_buffers(c)) return 1;
         if (enqueue_prefill_batch(c, n_tokens, n_past, s)) return 1;
@@ -582,7 +586,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_co
     bamd_model * m = c->m;
     HIPC(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t) hip_stream;
-    if (n_tokens < 2 || n_tokens > BAMD_PREFILL_CAP || !prefill_batch_supported(c)) return 2;
+    if (n_tokens < 2 || n_tokens > BAMD_PREFILL_CAP || !prefill_batch_supported(c, n_past + n_tokens - 1)) return 2;
     if (n_past < 0 || n_past + n_tokens > c->n_ctx) return fail("context overflow");
     if (m->with_embd) { if (!tokens) return fail("bamd_stage_prefill: tokens required on the first stage"); HIPC(hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s)); }
     else if (!hidden_in_dev) return fail("bamd_stage_prefill: hidden_in required");

@@ -41,6 +41,8 @@ struct bamd_attn_args {
     float kq_scale;
     int prefill_mode;              // 1: KQ with the T>1 semantics of the reference (q -> f16, ggml_vec_dot_f16)
     int batch, ld_qkv, ld_out;     // batched prefill: q/k/v and out are [T][ld_*] f32, token = blockIdx.y, position st->pos + token
+    int lds_ld;                    // single-launch / batched kernels: floats per score / probability row in LDS — a multiple of 64 that bounds the padded
+                                   // sequence length of this launch (or of every replay of the graph it is captured in); 0 = n_ctx
 };
 
 // batched prefill mat-mul: Y[t][row] = W[row,:] . Q8_K(a_t), T tokens

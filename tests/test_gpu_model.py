@@ -144,6 +144,31 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
     m.close()
 
 
+def test_large_context_uses_the_same_kernels(bamd, tmp_path):
+    """n_ctx = 32768 (a Mistral / Llama-3.1 GGUF opened with its training context): the LDS score rows of the batched and the
+    single-launch attention kernels are sized by the sequence, not by n_ctx, so prompts are still evaluated in micro-batches and short
+    sequences still decode through the single launch — bit-identical to token-by-token evaluation, also for a micro-batch that
+    starts beyond position 8192 (on a zero-initialised cache, the same in both modes)."""
+    p = str(tmp_path / "bigctx.gguf")
+    gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=2, L=2, F=1792, V=1024, seed=23)
+    m = bamd.Model(p)
+    toks = [(7919 * i + 13) % 1024 for i in range(70)]
+    out = {}
+    for mode in (1, 0):
+        bamd.set_prefill_batch(mode)
+        ctx = bamd.Context(m, 32768)
+        l1 = ctx.decode(toks[:41], 0).copy()
+        l2 = ctx.decode([7], 41).copy()                      # single-launch attention at n_ctx 32768
+        l3 = ctx.decode(toks[41:], 9000).copy()              # micro-batch at positions 9000..9028
+        l4 = ctx.decode([9], 9029).copy()
+        out[mode] = (l1, l2, l3, l4)
+        ctx.close()
+    bamd.set_prefill_batch(1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(bits(a), bits(b)), "max |d| = %g" % np.abs(a - b).max()
+    m.close()
+
+
 @pytest.mark.parametrize("cfg", ["mistral-q6k-8k", "70b-proportions-q5k"])
 def test_baseline_config_shapes_vs_oracle(bamd, po, tmp_path, cfg):
     """BASELINE.json configs 4 and 5 as parity cases at reduced width: (5) every tensor Q6_K, theta 10000, n_ctx 8192 (the
