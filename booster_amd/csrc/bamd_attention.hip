@@ -310,16 +310,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // ---- batched prefill attention: one workgroup per (KV head, token) computes ALL GQH query heads that share the KV head -------
 // Same arithmetic per (token, head) as attn_fused_kernel in its T > 1 mode (q rounded to f16, ggml_vec_dot_f16 order for the scores,
 // softmax with the reference's 8-wide partial sums, tinyBLAS chains for P.V), but every K row and V^T chunk is loaded once for the
-// GQH heads, and the token's own K/V are already in the cache (kv_store_batch_kernel).  Dynamic LDS: GQH x 2 x n_ctx floats.
+// GQH heads, and the token's own K/V are already in the cache (kv_store_batch_kernel).  Dynamic LDS: GQH x ld floats.
 template <int GQH>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_kernel(bamd_attn_args a, int gq) {
+__global__ void __launch_bounds__(512) attn_batch_kernel(bamd_attn_args a, int gq) {
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQH][256];
     __shared__ float redf[GQH][8];
     __shared__ double redd[GQH][8];
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_dyn[];
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;                            // LDS row length: bounds the padded sequence length of the micro-batch
-    float * sc = (float *) attn_dyn;                                         // [GQH][ld] scores, then exp values
-    float * pt = sc + (size_t) GQH * ld;                                     // [GQH][ld] probabilities in V^T position order
+    float * sc = (float *) attn_dyn;                                         // [GQH][ld] scores, then exp values, then — IN PLACE — the
+    float * pt = sc;                                                         // probabilities in V^T position order (vperm stays inside a 64-block)
     const bamd_step_state * st = a.st;
     const int tokb = blockIdx.y;
     const int pos = st->pos + tokb;
@@ -389,8 +389,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         double tot = 0.0;
         for (int w = 0; w < 8; ++w) tot += redd[hh][w];
         const float fs = (float) (1.0 / tot);
-        for (int i = tid; i < n_kv; i += blockDim.x) p_[vperm(i)] = s_[i] * fs;
-        for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) p_[vperm(i)] = 0.f;   // half-filled last block: exact no-ops
+        // one wave per 64-block: all 64 values are read before the permuted ones are written, so the block is permuted in place;
+        // the idle half of a half-filled last block becomes zeros (exact no-ops in the chains)
+        for (int i = tid; i < ((n_kv + 63) & ~63); i += blockDim.x) { const float val = i < n_kv ? s_[i] * fs : 0.f; p_[vperm(i)] = val; }
     }
     __syncthreads();
     // ---- P.V: V^T chunk once, GQH chains; lane (d, e) carries Cv[e] of output d, up to 4 rows d per lane ----
@@ -455,10 +456,11 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     if (a.hd > 256 || (a.hd & 63) || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || !a.batch) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    // as many query heads of a KV head per workgroup as have their score buffers fit the LDS (2 x ld floats each); else one
+    // as many query heads of a KV head per workgroup as have their score rows fit the LDS (ld floats each: the probabilities replace
+    // the scores in place); a single head per workgroup runs on attn_fused_kernel (separate rows: 2 x ld floats)
     int gqh = gq;
-    while (gqh > 1 && (size_t) gqh * ld * 8 > BAMD_ATTN_LDS_MAX) gqh >>= 1;
-    const size_t lds_g = (size_t) gqh * ld * 8;
+    while (gqh > 1 && (size_t) gqh * ld * 4 > BAMD_ATTN_LDS_MAX) gqh >>= 1;
+    const size_t lds_g = (size_t) gqh * ld * 4;
     const dim3 grid(a.Hkv * gq / (gqh > 1 ? gqh : 1), T);
     if (gqh == 8)      hipLaunchKernelGGL((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
     else if (gqh == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
