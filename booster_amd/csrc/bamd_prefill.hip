@@ -136,6 +136,16 @@ __device__ __forceinline__ void lds_dma4(const void * gsrc, void * lds_wave_base
 }
 // vmcnt(0) as the BUILTIN (imm: vmcnt 0, expcnt 7, lgkmcnt 15): the wait-count pass sees it and does not repeat it behind the next issue
 __device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+// four i16-pair dot products -> float in one asm block: VOP3P v_dot2_i32_i16 d, a, b, 0 (the builtin becomes v_dot2c + a zero-init move per
+// product), the conversions four instructions behind their dots (a DOT result needs 3 wait states before a VALU read; inline asm is
+// not hazard-checked)
+__device__ __forceinline__ void dot2x4_f32(const uint32_t (&m)[4], const uint32_t (&sv)[4], float (&p)[4]) {
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %4, %8, %12, 0\n\t" "v_dot2_i32_i16 %5, %9, %13, 0\n\t" "v_dot2_i32_i16 %6, %10, %14, 0\n\t" "v_dot2_i32_i16 %7, %11, %15, 0\n\t"
+        "v_cvt_f32_i32 %0, %4\n\t" "v_cvt_f32_i32 %1, %5\n\t" "v_cvt_f32_i32 %2, %6\n\t" "v_cvt_f32_i32 %3, %7"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]));
+}
 typedef float bamd_f4 __attribute__((ext_vector_type(4)));
 struct bamd_mma_args {
     const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
@@ -314,12 +324,10 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                     const float t = Dm[n][i] * (float) hs;
                     accm[n][0][i] = accm[n][0][i] + t;
                 } else {
+                    float pm[4];
+                    dot2x4_f32(mpl, spl, pm);
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) {
-                        union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l];
-                        const float pm = (float) __builtin_amdgcn_sdot2(ma.v, sb.v, 0, false);
-                        accm[n][l][i] = fmaf(Dm[n][i], pm, accm[n][l][i]);
-                    }
+                    for (int l = 0; l < 4; ++l) accm[n][l][i] = fmaf(Dm[n][i], pm[l], accm[n][l][i]);
                 }
             }
         }
