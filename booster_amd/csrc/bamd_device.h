@@ -526,6 +526,21 @@ __device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, i
 __device__ __forceinline__ int kperm(int n, int L) { return (n & 7) * L + (n >> 3); }
 __device__ __forceinline__ int vperm(int p) { return (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3); }
 
+// eight steps of ggml_vec_dot_f16's four interleaved accumulators on f16 pairs: v_fma_mix_f32 extends both halves and fuses the
+// multiply-add in one instruction (= fmaf((float) k, (float) q, acc) exactly); hipcc emits two conversions + half a v_pk_fma_f32 per
+// step instead.  Element u is the low (u even) / high half of word u >> 1; steps u and u + 4 share an accumulator (distance 4).
+__device__ __forceinline__ void fma_mix8(float (&a4)[4], const uint32_t (&k)[4], const uint32_t (&q)[4]) {
+    asm("v_fma_mix_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %1, %4, %8, %1 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %2, %5, %9, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %3, %5, %9, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %0, %6, %10, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %1, %6, %10, %1 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %2, %7, %11, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %3, %7, %11, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]"
+        : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3])
+        : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+}
 // dot of up to 32 steps for lane e: k8 = this lane's L halves of the K row (L <= 32), q = this lane's L floats / halves
 template <bool PREFILL>
 __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const float * qf, const unsigned short * qh) {
@@ -550,9 +565,7 @@ __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const flo
                 const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
                 const uint4 qq = *(const uint4 *) (qh + g * 8);
                 const uint32_t qw[4] = { qq.x, qq.y, qq.z, qq.w };
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    a4[u & 3] = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), h2f((qw[u >> 1] >> (16 * (u & 1))) & 0xffffu), a4[u & 3]);
+                fma_mix8(a4, w, qw);                               // a4[u & 3] = fmaf((float) k_u, (float) q_u, a4[u & 3]), u = 0..7
             }
         }
         const float s02 = a4[0] + a4[2], s13 = a4[1] + a4[3];
