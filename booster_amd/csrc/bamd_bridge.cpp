@@ -561,6 +561,26 @@ BAMD_API bamd_vocab * bamd_vocab_load(const char * gguf_path) {
     return h.release();
 }
 BAMD_API void bamd_vocab_free(bamd_vocab * h) { delete h; }
+// CPU-only probe of the GGUF reader (single file or the first shard of a split model): tensor count, total tensor bytes and an
+// FNV-1a digest over the tensors in name order (name, type, shape, data) — equal for a model and its gguf-split shards
+BAMD_API int bamd_gguf_probe(const char * gguf_path, int64_t * n_tensors, int64_t * n_bytes, uint64_t * digest) {
+    GgufFile f; std::string err;
+    if (!f.open(gguf_path, err)) { fprintf(stderr, "bamd_gguf_probe: %s\n", err.c_str()); return 1; }
+    std::vector<const GgufTensor *> order;
+    for (const GgufTensor & t : f.tensors) order.push_back(&t);
+    std::sort(order.begin(), order.end(), [](const GgufTensor * a, const GgufTensor * b) { return a->name < b->name; });
+    uint64_t h = 1469598103934665603ull; int64_t bytes = 0;
+    auto mix = [&](const void * p, size_t n) { const uint8_t * b = (const uint8_t *) p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    for (const GgufTensor * t : order) {
+        mix(t->name.data(), t->name.size()); mix(&t->type, sizeof t->type);
+        for (int64_t d : t->ne) mix(&d, sizeof d);
+        mix(t->data, t->nbytes); bytes += (int64_t) t->nbytes;
+    }
+    if (n_tensors) *n_tensors = (int64_t) f.tensors.size();
+    if (n_bytes) *n_bytes = bytes;
+    if (digest) *digest = h;
+    return 0;
+}
 // test hooks: the host Janus sampler (init_janus + sample_janus) on a vocabulary-only GGUF and scripted logits — no GPU involved
 BAMD_API void * bamd_janus_test_new(const bamd_vocab * h, float scale, float hi, float lo, int depth) {
     Pod * p = new Pod();

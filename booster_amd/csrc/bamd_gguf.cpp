@@ -2,6 +2,7 @@
 #include "bamd_gguf.h"
 #include "bamd_formats.h"
 #include <fcntl.h>
+#include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -58,7 +59,7 @@ GgufFile::~GgufFile() {
     if (fd_ >= 0) close(fd_);
 }
 
-bool GgufFile::open(const std::string & path, std::string & err) {
+bool GgufFile::open_one(const std::string & path, std::string & err) {
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) { err = "cannot open " + path; return false; }
     struct stat st;
@@ -112,6 +113,35 @@ bool GgufFile::open(const std::string & path, std::string & err) {
         if (data_off + t.offset + t.nbytes > size_) { err = "tensor " + t.name + " out of file bounds"; return false; }
         t.data = map_ + data_off + t.offset;
         index_[t.name] = i;
+    }
+    return true;
+}
+
+// the model file, or the first shard of a split model (llama_model_loader, llama.cpp:3659-3714: the KV pairs of the first shard describe
+// the model; every shard carries its own tensor table and data section)
+bool GgufFile::open(const std::string & path, std::string & err) {
+    if (!open_one(path, err)) return false;
+    uint32_t n_split = 0, idx = 0, n_expected = 0;
+    if (!get_u32("split.count", n_split) || n_split <= 1) return true;
+    get_u32("split.no", idx);
+    if (idx != 0) { err = "illegal split file: model must be loaded with the first split"; return false; }
+    char postfix[32]; snprintf(postfix, sizeof postfix, "-%05d-of-%05d.gguf", 1, (int) n_split);
+    const size_t pl = strlen(postfix);
+    if (path.size() <= pl || path.compare(path.size() - pl, pl, postfix) != 0) { err = "invalid split file name: " + path; return false; }
+    const std::string prefix = path.substr(0, path.size() - pl);
+    for (uint32_t k = 1; k < n_split; ++k) {
+        char name[64]; snprintf(name, sizeof name, "-%05d-of-%05d.gguf", (int) k + 1, (int) n_split);
+        std::unique_ptr<GgufFile> part(new GgufFile());
+        if (!part->open_one(prefix + name, err)) { err = "failed to load GGUF split " + prefix + name + ": " + err; return false; }
+        for (const GgufTensor & t : part->tensors) {
+            if (index_.count(t.name)) { err = "tensor " + t.name + " appears in two splits"; return false; }
+            index_[t.name] = tensors.size();
+            tensors.push_back(t);                            // data points into the shard's mapping, kept alive by parts_
+        }
+        parts_.push_back(std::move(part));
+    }
+    if (get_u32("split.tensors.count", n_expected) && n_expected != (uint32_t) tensors.size()) {
+        err = "corrupted model: " + std::to_string(n_expected) + " tensors expected but " + std::to_string(tensors.size()) + " found"; return false;
     }
     return true;
 }

@@ -1,12 +1,14 @@
 // bamd_gguf.h — GGUF v2/v3 reader (mmap).  Same on-disk format the reference reads in
 // cpp/ggml/src/ggml.c:20896-21260 (gguf_init_from_file): magic "GGUF", u32 version, u64 n_tensors, u64 n_kv,
 // KV pairs {string key, u32 type, value}, tensor infos {string name, u32 n_dims, u64 ne[], u32 type, u64 offset},
-// data section aligned to general.alignment (default 32).
+// data section aligned to general.alignment (default 32).  Split models (gguf-split: <prefix>-00001-of-0000N.gguf, split.count / split.no /
+// split.tensors.count, llama.cpp:3659-3714): open the FIRST shard; the others are mapped alongside and their tensors join the table.
 #pragma once
 #include <stdint.h>
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 
 struct GgufValue {
     uint32_t type = 0;                 // gguf_type
@@ -42,6 +44,8 @@ class GgufFile {
     size_t alignment = 32;
 
   private:
+    bool open_one(const std::string & path, std::string & err);
+    std::vector<std::unique_ptr<GgufFile>> parts_;   // shards 2..n of a split model (split.count > 1): their tensors are merged into `tensors`
     int fd_ = -1;
     const uint8_t * map_ = nullptr;
     size_t size_ = 0;

@@ -102,6 +102,7 @@ class GGUFWriter:
         self.kv = []          # (key, type, value)
         self.tensors = []     # (name, shape(ggml order), type, bytes ndarray)
 
+    def add_u16(self, k, v): self.kv.append((k, T_U16, int(v)))
     def add_u32(self, k, v): self.kv.append((k, T_U32, int(v)))
     def add_i32(self, k, v): self.kv.append((k, T_I32, int(v)))
     def add_f32(self, k, v): self.kv.append((k, T_F32, float(v)))
@@ -152,6 +153,22 @@ class GGUFWriter:
                 f.write(b"\0" * ((-data.size) % DEFAULT_ALIGNMENT))
 
 
+    def write_split(self, path_prefix, n_split):
+        """gguf-split layout (llama.cpp:3659-3714): <prefix>-0000k-of-0000n.gguf, every shard with its own tensor table and data section and the
+        keys split.no / split.count / split.tensors.count; the model's own keys live in the first shard.  Returns the shard paths."""
+        per = (len(self.tensors) + n_split - 1) // n_split
+        paths = []
+        for k in range(n_split):
+            w = GGUFWriter()
+            if k == 0:
+                w.kv = list(self.kv)
+            w.add_u16("split.no", k); w.add_u16("split.count", n_split); w.add_i32("split.tensors.count", len(self.tensors))
+            w.tensors = self.tensors[k * per:(k + 1) * per]
+            path = "%s-%05d-of-%05d.gguf" % (path_prefix, k + 1, n_split)
+            w.write(path); paths.append(path)
+        return paths
+
+
 # ---------------------------------------------------------------------------------------------------------
 # synthetic K-quant tensors: random but well-formed blocks (finite f16 scales), for throughput / parity runs
 # ---------------------------------------------------------------------------------------------------------
@@ -189,7 +206,7 @@ def q4_k_m_type(name, il, n_layer):
 
 
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
-                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None):
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0):
     """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.
     reuse_layers: generate each (tensor kind, type) once and reuse the bytes in every layer (fast path for the
     multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged)."""
@@ -261,6 +278,8 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
         for nm, rows, cols, amp in (("ffn_gate", F, E, 1.5), ("ffn_up", F, E, 1.5), ("ffn_down", E, F, 1.0)):
             t = type_fn(nm, il)
             w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
+    if n_split > 1:                  # `path` is then the prefix; returns the shard paths (open the first)
+        return w.write_split(path, n_split)
     w.write(path)
 
 

@@ -117,6 +117,10 @@ int bamd_vocab_is_eog(const bamd_vocab * v, int id);                    /* llama
 int bamd_vocab_eos(const bamd_vocab * v);
 int bamd_vocab_eot(const bamd_vocab * v);
 
+/* CPU only: open a GGUF (or the FIRST shard of a gguf-split model, llama.cpp:3659-3714) with the library's reader and report the tensor
+ * count, the total tensor bytes and an FNV-1a digest over (name, type, shape, data) in name order.  Returns 0, or 1 with a message on stderr. */
+int bamd_gguf_probe(const char * gguf_path, int64_t * n_tensors, int64_t * n_bytes, uint64_t * digest);
+
 /* Test hook, CPU only: the candidate shortlist of the Janus sampler (janus.cpp:262-300 — full descending sort, cut at the first
  * candidate with logit / top < cutoff) through the linear-time path (fast = 1; falls back by itself when ties or a non-positive top
  * make the order depend on the full sort) or the full-sort path (fast = 0).  Writes up to `cap` ids in order, returns the count. */

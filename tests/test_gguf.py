@@ -33,3 +33,31 @@ def test_q4_k_m_recipe():
     n = sum(gguf.q4_k_m_type("ffn_down", il, 32) == gguf.Q6_K for il in range(32))
     assert n == 16
     assert gguf.q4_k_m_type("attn_q", 0, 32) == gguf.Q4_K and gguf.q4_k_m_type("output", 0, 32) == gguf.Q6_K
+
+
+def test_split_model_reads_like_the_single_file(tmp_path):
+    """gguf-split shards: the C++ reader opened on the first shard sees the same tensors (names, types, shapes, bytes) as on
+    the un-split file; opening a later shard, a wrongly named shard or an incomplete set fails."""
+    import ctypes as C
+    import booster_amd
+    L = booster_amd.lib()
+    L.bamd_gguf_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def probe(path):
+        n, b, d = C.c_int64(0), C.c_int64(0), C.c_uint64(0)
+        rc = L.bamd_gguf_probe(path.encode(), C.byref(n), C.byref(b), C.byref(d))
+        return rc, n.value, b.value, d.value
+
+    single = str(tmp_path / "one.gguf")
+    gguf.write_synthetic_llama(single, E=256, H=2, Hkv=1, L=3, F=512, V=64, seed=5, rope_freqs=True)
+    shards = gguf.write_synthetic_llama(str(tmp_path / "model"), E=256, H=2, Hkv=1, L=3, F=512, V=64, seed=5, rope_freqs=True, n_split=3)
+    assert [os.path.basename(p) for p in shards] == ["model-00001-of-00003.gguf", "model-00002-of-00003.gguf", "model-00003-of-00003.gguf"]
+    want = probe(single)
+    assert want[0] == 0 and want[1] == 3 + 1 + 3 * 9
+    assert probe(shards[0]) == want
+    assert probe(shards[1])[0] == 1                              # must be loaded with the first split
+    os.rename(shards[2], shards[2] + ".away")
+    assert probe(shards[0])[0] == 1                              # a shard is missing
+    os.rename(shards[2] + ".away", shards[2])
+    odd = str(tmp_path / "renamed.gguf"); os.rename(shards[0], odd)
+    assert probe(odd)[0] == 1                                    # the first shard must carry the -00001-of-0000N.gguf name

@@ -144,6 +144,22 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
     m.close()
 
 
+def test_split_gguf_model_equals_single_file(bamd, tmp_path):
+    """a gguf-split model (three shards, opened by its first shard) runs exactly like the un-split file"""
+    single = str(tmp_path / "one.gguf")
+    kw = dict(E=512, H=4, Hkv=2, L=3, F=768, V=512, seed=41)
+    gguf.write_synthetic_llama(single, **kw)
+    shards = gguf.write_synthetic_llama(str(tmp_path / "model"), n_split=3, **kw)
+    toks = [(31 * i + 7) % 512 for i in range(19)]
+    out = []
+    for path in (single, shards[0]):
+        m = bamd.Model(path); ctx = bamd.Context(m, 64)
+        l1 = ctx.decode(toks, 0).copy(); l2 = ctx.decode([3], len(toks)).copy()
+        out.append((l1, l2)); ctx.close(); m.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(bits(a), bits(b))
+
+
 def test_large_context_uses_the_same_kernels(bamd, tmp_path):
     """n_ctx = 32768 (a Mistral / Llama-3.1 GGUF opened with its training context): the LDS score rows of the batched and the
     single-launch attention kernels are sized by the sequence, not by n_ctx, so prompts are still evaluated in micro-batches and short
