@@ -551,6 +551,12 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     if (!m->with_embd || !m->with_output) { fail("bamd_decode needs a stage that owns embedding and output"); return 1; }
     if (n_tokens < 1 || n_tokens > c->forced_cap) { fail("n_tokens out of range"); return 1; }
     if (n_past < 0 || n_past + n_tokens > c->n_ctx) { fail("context overflow"); return 1; }
+    if (n_tokens > BAMD_PREFILL_CAP && g_prefill_batch) {
+        // llama_decode's n_ubatch split (llama.cpp:14615): micro-batches of 512, the logits are those of the last token
+        for (int i = 0; i < n_tokens; i += BAMD_PREFILL_CAP)
+            if (bamd_decode(c, tokens + i, std::min(BAMD_PREFILL_CAP, n_tokens - i), n_past + i)) return 1;
+        return 0;
+    }
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
     hipStream_t s = c->stream;
     if (hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s) != hipSuccess) { fail("H2D tokens"); return 1; }

@@ -50,7 +50,8 @@ void           bamd_kv_cache_clear(bamd_context * c);                   /* llama
 /* llama_decode(ctx, llama_batch_get_one(tokens, n_tokens, n_past, 0)) (llama.cpp:18517, :14537).
  * Processes the tokens at positions n_past.. with the reference's semantics for a micro-batch of n_tokens
  * (n_tokens > 1: attention scores use the f16-rounded q of the reference's T>1 path) and leaves the logits of
- * the LAST token for bamd_get_logits.  Returns 0, or 1 on failure like llama_decode. */
+ * the LAST token for bamd_get_logits.  More than 512 tokens are evaluated in micro-batches of 512 (n_ubatch, llama.cpp:14615).
+ * Returns 0, or 1 on failure like llama_decode. */
 int           bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past);
 const float * bamd_get_logits(bamd_context * c);                        /* llama_get_logits: host, n_vocab floats */
 

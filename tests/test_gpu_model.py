@@ -136,6 +136,11 @@ def test_batched_prefill_equals_token_by_token(bamd, tmp_path):
         l2 = ctx.decode(toks[37:], 37).copy()
         l3 = ctx.decode([5], 59).copy()                      # a decode step on top of the batched KV cache
         out[mode] = (l1, l2, l3)
+        if mode == 1:                                        # one call with more than 512 tokens = llama_decode's n_ubatch split
+            long_toks = [(11 * i + 5) % 1024 for i in range(700)]
+            c2 = bamd.Context(m, 1024); la = c2.decode(long_toks, 0).copy(); c2.close()
+            c3 = bamd.Context(m, 1024); c3.decode(long_toks[:512], 0); lb = c3.decode(long_toks[512:], 512).copy(); c3.close()
+            assert np.array_equal(bits(la), bits(lb))
         ctx.close()
     bamd.set_prefill_batch(1)
     for mode in (1, 2):
