@@ -107,13 +107,13 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
 }
 // P.V: grid (H, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d).  sgemm.cpp:405-431 with
 // A = V^T rows (f16), B = p (f32).  The chain over positions is sequential per lane, but the loads are not: BAMD_PV_U blocks of 64
-// positions are requested together (16 KiB of V^T per wave in flight).  Workgroup = the gq query heads of one KV head, one wave
-// each: they stream the same V^T rows in step, so three of the four reads hit the CU's vector L1.
+// positions are requested together (16 KiB of V^T per wave in flight).  Workgroup = half of the gq query heads of one KV head (grid z = 2:
+// Hkv x hd/8 alone would occupy only 128 of the 256 CUs), one wave each: they stream the same V^T rows in step and share the CU's vector L1.
 #define BAMD_PV_U 8
 __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) {
     const bamd_step_state * st = a.st;
     const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
-    const int hk = blockIdx.x, h = hk * gq + wave_id();
+    const int hk = blockIdx.x, h = hk * gq + (int) blockIdx.z * (int) (blockDim.x >> 6) + wave_id();   // blockIdx.z: which part of the KV head's query heads
     const int lane = threadIdx.x & 63, e = lane & 7;
     const int d = blockIdx.y * 8 + (lane >> 3);
     const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx + e * 8;
@@ -485,7 +485,9 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
 #define CASE(G) case G: \
         hipLaunchKernelGGL((attn_qk_kernel<G>), g1, dim3(512), 0, s, a); \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
-        hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); break;
+        if (G >= 2) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2 > 0 ? G / 2 : 1)), 0, s, a, gq); /* two workgroups per KV head: all 256 CUs at Hkv x hd/8 = 128 */ \
+        else hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \
+        break;
         CASE(1) CASE(2) CASE(4) CASE(8)
 #undef CASE
         default: return 1;
