@@ -232,7 +232,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     # The JSON line must be the LAST thing on stdout: RCCL writes a version banner through C stdio, which would otherwise be flushed
-    # at process exit, after Python's own buffer.  Drain C stdio first, print, flush, and leave without running more exit hooks.
+    # at process exit, after Python's own buffer.  Drain C stdio first, then print and flush as the last act of the program (a normal
+    # return, so that a profiler attached to the process still writes its output at exit).
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
@@ -242,7 +243,6 @@ def main():
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":
