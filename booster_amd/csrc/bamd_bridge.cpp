@@ -301,15 +301,22 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
 }
 
 // ---- model placement: Booster's gpus: split (cpp/bridge.cpp:745-750, llama.cpp:5932-5969) ----------------------------------
-bool plan_stages(int n_layer, const int gpu[4], std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
+// llm_load_tensors (llama.cpp:5932-5969) with the bridge's settings (bridge.cpp:745-750: n_gpu_layers = gpu1+..+gpu4, tensor_split = gpuN):
+// only the first `device_count` entries of the split count; if those are all zero the reference splits by free device memory (equal
+// here: identical GPUs); layer i lives on upper_bound(cumulative normalised splits, i / act), the output layer with fraction (act-1)/act.
+bool plan_stages(int n_layer, const int gpu[4], int device_count, std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
     const int n_gpu_layers = gpu[0] + gpu[1] + gpu[2] + gpu[3];
     if (n_gpu_layers <= 0) { err = "gpu1..gpu4 are all zero: this build has no CPU path"; return false; }
     if (n_gpu_layers <= n_layer) { err = "sum(gpuN) must exceed the layer count (partial CPU offload is not supported: no CPU path)"; return false; }
+    const int dc = std::min(device_count, 4);
+    if (dc < 1) { err = "no HIP device"; return false; }
     const int act = std::min(n_gpu_layers, n_layer + 1);
+    bool all_zero = true;
+    for (int i = 0; i < dc; ++i) all_zero = all_zero && gpu[i] == 0;
     float splits[4], sum = 0.f;
-    for (int i = 0; i < 4; ++i) { sum += (float) gpu[i]; splits[i] = sum; }
-    for (int i = 0; i < 4; ++i) splits[i] /= sum;
-    auto dev_of = [&](int i) { const float f = (float) i / (float) act; int d = 0; while (d < 3 && !(f < splits[d])) ++d; return d; };   // std::upper_bound
+    for (int i = 0; i < dc; ++i) { sum += all_zero ? 1.0f : (float) gpu[i]; splits[i] = sum; }
+    for (int i = 0; i < dc; ++i) splits[i] /= sum;
+    auto dev_of = [&](int i) { const float f = (float) i / (float) act; int d = 0; while (d < dc - 1 && !(f < splits[d])) ++d; return d; };   // std::upper_bound
     int start = 0, cur = dev_of(0);
     for (int il = 1; il <= n_layer; ++il) {
         const int d = il < n_layer ? dev_of(il) : -1;
@@ -401,7 +408,7 @@ BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_si
     bamd_model_free(probe);
     const int gpu[4] = { gpu1, gpu2, gpu3, gpu4 };
     std::vector<std::pair<int, std::pair<int, int>>> plan;
-    if (!plan_stages(n_layer, gpu, plan, err)) { fprintf(stderr, "initContext: %s\n", err.c_str()); return nullptr; }
+    if (!plan_stages(n_layer, gpu, ndev, plan, err)) { fprintf(stderr, "initContext: %s\n", err.c_str()); return nullptr; }
     int n_ctx = context > 0 ? context : n_ctx_train;          // n_ctx 0 = from model (llama.cpp:16640)
     n_ctx = (n_ctx + 31) / 32 * 32;
     pod->n_ctx = n_ctx; pod->n_predict = predict;
@@ -561,6 +568,16 @@ BAMD_API bamd_vocab * bamd_vocab_load(const char * gguf_path) {
     return h.release();
 }
 BAMD_API void bamd_vocab_free(bamd_vocab * h) { delete h; }
+// test hook, CPU only: the device of every layer and of the output layer (index n_layer) for a gpu1..gpu4 setting on a box with
+// `device_count` GPUs; returns 0, or 1 when the setting is refused (no CPU path)
+BAMD_API int bamd_plan_stages_test(int n_layer, int g1, int g2, int g3, int g4, int device_count, int32_t * device_of) {
+    const int gpu[4] = { g1, g2, g3, g4 };
+    std::vector<std::pair<int, std::pair<int, int>>> plan; std::string err;
+    if (!plan_stages(n_layer, gpu, device_count, plan, err)) return 1;
+    for (const auto & st : plan) for (int il = st.second.first; il < st.second.second; ++il) device_of[il] = st.first;
+    device_of[n_layer] = plan.back().first;
+    return 0;
+}
 // CPU-only probe of the GGUF reader (single file or the first shard of a split model): tensor count, total tensor bytes and an
 // FNV-1a digest over the tensors in name order (name, type, shape, data) — equal for a model and its gguf-split shards
 BAMD_API int bamd_gguf_probe(const char * gguf_path, int64_t * n_tensors, int64_t * n_bytes, uint64_t * digest) {

@@ -118,6 +118,10 @@ int bamd_vocab_is_eog(const bamd_vocab * v, int id);                    /* llama
 int bamd_vocab_eos(const bamd_vocab * v);
 int bamd_vocab_eot(const bamd_vocab * v);
 
+/* Test hook, CPU only: Booster's `gpus:` split (bridge.cpp:745-750 + llm_load_tensors, llama.cpp:5932-5969) — the device of every layer and,
+ * at index n_layer, of the output layer, on a box with device_count GPUs.  Returns 1 when the setting is refused (it would need a CPU path). */
+int bamd_plan_stages_test(int n_layer, int gpu1, int gpu2, int gpu3, int gpu4, int device_count, int32_t * device_of);
+
 /* CPU only: open a GGUF (or the FIRST shard of a gguf-split model, llama.cpp:3659-3714) with the library's reader and report the tensor
  * count, the total tensor bytes and an FNV-1a digest over (name, type, shape, data) in name order.  Returns 0, or 1 with a message on stderr. */
 int bamd_gguf_probe(const char * gguf_path, int64_t * n_tensors, int64_t * n_bytes, uint64_t * digest);

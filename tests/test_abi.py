@@ -46,3 +46,47 @@ def test_bridge_symbols_exported(L):
     assert sorted(syms) == sorted(["init", "initContext", "doInference", "stopInference", "status", "promptEval", "getPromptTokenCount", "timing", "getSeed"])
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
+
+
+def test_gpus_split_rule():
+    """Booster's `gpus:` split (cpp/bridge.cpp:745-750 feeding llm_load_tensors, llama.cpp:5932-5969): restated here in numpy float32 —
+    n_gpu_layers = sum of the four weights, only the first device_count entries split, all-zero -> equal shares, std::upper_bound over
+    the cumulative normalised splits — against the planner of the bridge, for random settings."""
+    import ctypes as C
+    import numpy as np
+    import booster_amd
+    L = booster_amd.lib()
+    L.bamd_plan_stages_test.argtypes = [C.c_int] * 6 + [C.c_void_p]
+    rng = np.random.default_rng(3)
+
+    def ref(n_layer, gpu, dc):
+        n_gpu_layers = sum(gpu)
+        if n_gpu_layers <= n_layer:
+            return None                                   # layers would stay on the CPU: refused here
+        raw = np.array(gpu[:dc], np.float32)
+        if not raw.any():
+            raw = np.ones(dc, np.float32)
+        cum = np.zeros(dc, np.float32); acc = np.float32(0)
+        for i in range(dc):
+            acc = np.float32(acc + raw[i]); cum[i] = acc
+        splits = (cum / acc).astype(np.float32)
+        act = min(n_gpu_layers, n_layer + 1)
+        ub = lambda f: min(int(np.searchsorted(splits, np.float32(f), side="right")), dc - 1)   # upper_bound; f < 1 = splits[-1]
+        return [ub(np.float32(i) / np.float32(act)) for i in range(n_layer)] + [ub(np.float32(act - 1) / np.float32(act))]
+
+    cases = [(32, (100, 0, 0, 0), 1), (32, (17, 16, 0, 0), 2), (80, (11, 10, 10, 10), 4), (32, (2, 2, 0, 0), 1), (32, (0, 0, 40, 0), 2), (3, (1, 1, 1, 1), 4)]
+    for _ in range(200):
+        n_layer = int(rng.integers(1, 90)); dc = int(rng.integers(1, 5))
+        gpu = tuple(int(x) for x in rng.integers(0, 60, 4) * (rng.random(4) < 0.7))
+        cases.append((n_layer, gpu, dc))
+    n_ok = 0
+    for n_layer, gpu, dc in cases:
+        out = np.full(n_layer + 1, -1, np.int32)
+        rc = L.bamd_plan_stages_test(n_layer, *gpu, dc, out.ctypes.data_as(C.c_void_p))
+        want = ref(n_layer, list(gpu), dc)
+        if want is None:
+            assert rc == 1, (n_layer, gpu, dc)
+        else:
+            assert rc == 0 and out.tolist() == want, (n_layer, gpu, dc, out.tolist(), want)
+            n_ok += 1
+    assert n_ok > 50
