@@ -53,6 +53,7 @@ def lib():
         L.bamd_stage_prefill.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
+        L.bamd_timeline_step.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
         L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
@@ -137,6 +138,14 @@ class Context:
         launches = np.zeros(4, np.int32); ms = np.zeros(4, np.float64); nbytes = np.zeros(4, np.float64)
         _chk(lib().bamd_profile_step(self.h, pos, _p(launches), _p(ms), _p(nbytes)))
         return launches, ms, nbytes
+
+    def timeline_step(self, pos, replays=3):
+        """phase stamps of one decode step (BAMD_LIB=.../libbooster_amd_timing.so): u64 [launches][512 workgroups][2 waves][8 phases], 100 MHz"""
+        cap = 5 * self.model.n_layer + 1
+        out = np.zeros((cap, 512, 2, 8), np.uint64)
+        n = C.c_int(0)
+        _chk(lib().bamd_timeline_step(self.h, pos, replays, _p(out), cap, C.byref(n)))
+        return out[:n.value]
 
     def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr, token_dev_ptr=None):
         _chk(lib().bamd_stage_step(self.h, int(token), token_dev_ptr, int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits),

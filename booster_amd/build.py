@@ -12,43 +12,50 @@ LIB = os.path.join(HERE, "lib", "libbooster_amd.so")
 SOURCES = ["bamd_matvec.hip", "bamd_attention.hip", "bamd_prefill.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
 HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_device.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
 # -ffp-contract=off: the numerics contract (bit-parity with the reference CPU path) forbids implicit FMA fusion.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
+# -fno-slp-vectorize: SLP packs neighbouring f32 multiplies into v_pk_mul_f32, whose operands need even-aligned register pairs: the
+# copies it adds sit right behind the loads (a full s_waitcnt before the weight ring could be requested) and packed f32 is no faster here.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+LIB_TIMING = os.path.join(HERE, "lib", "libbooster_amd_timing.so")      # -DBAMD_TIMING: kernels write phase stamps (tools/timeline.py)
+
+
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, timing=False):
+    lib = LIB_TIMING if timing else LIB
+    if not force and not _stale(lib):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objdir = os.path.join(HERE, "lib", "timing") if timing else os.path.join(HERE, "lib")
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
             continue
-        obj = os.path.join(HERE, "lib", os.path.splitext(s)[0] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-DBAMD_TIMING"] if timing else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))

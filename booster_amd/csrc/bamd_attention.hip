@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int h = blockIdx.x, hk = h / gq;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
     const float * rope = a.rope + (size_t) pos * hd;
-    STAMP(0);
+    TL_STAMP(a.tl, 0);
     // requests that do not depend on RoPE go out first: this lane's K chunks of the first 4 x 64 positions and its V^T chunks
     const int r_pos = wave * 8 + (lane >> 3);                     // position inside a 64-tile (scores) / d inside a 64-block (P.V)
     uint4 kreg[4][4];
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
         }
     }
-    STAMP(1);
+    TL_STAMP(a.tl, 1);
     // ---- scores ----
 #define BAMD_SCORE_TILE(t0_, KL_) do { \
         const int i = (t0_) + r_pos; \
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 #undef BAMD_SCORE_TILE
     __syncthreads();
-    STAMP(2);
+    TL_STAMP(a.tl, 2);
     // ---- softmax (ggml.c:13682-13778 + :2619-2671): wp = s*scale (+mask), max, exp, 8-chunk f32 sums, double total ----
     const float scale = a.kq_scale;
     float mx = -INFINITY;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // half-filled last block (n_kv % 64 == 32): p = 0 for the missing positions, so the chain steps there are exact no-ops
     for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) pt[vperm(i)] = 0.f;
     __syncthreads();
-    STAMP(3);
+    TL_STAMP(a.tl, 3);
     // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (A = V^T row, B = p), up to 4 rows d per lane ----
     const unsigned short vcur[4] = { f2h(a.v[hk * hd + (r_pos < hd ? r_pos : 0)]), f2h(a.v[hk * hd + (r_pos + 64 < hd ? r_pos + 64 : 0)]),
                                      f2h(a.v[hk * hd + (r_pos + 128 < hd ? r_pos + 128 : 0)]), f2h(a.v[hk * hd + (r_pos + 192 < hd ? r_pos + 192 : 0)]) };
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int d = r_pos + 64 * dd;
         if (d < hd) { const float v = hsum8_tinyblas(acc4[dd]); if (e == 0) a.out[(size_t) h * hd + d] = v; }
     }
-    STAMP(4);
+    TL_STAMP(a.tl, 7);
 }
 
 // ---- batched prefill attention: one workgroup per (KV head, token) computes ALL GQH query heads that share the KV head -------

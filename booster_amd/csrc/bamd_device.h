@@ -40,13 +40,14 @@
 #define BAMD_SCHED_GROUP 1      /* records the scheduler may interleave between barriers (power of two) */
 #endif
 
-// optional in-kernel phase stamps (build with -DBAMD_TIMING): block 0 / lane 0 of each wave writes s_memtime
+// optional in-kernel phase stamps (build with -DBAMD_TIMING: booster_amd/lib/libbooster_amd_timing.so, tools/timeline.py): lane 0 of
+// waves 0 and 7 of every workgroup writes the 100 MHz wall clock (s_memrealtime, one time base for the whole device and across launches)
+// into the stamp block of its launch — [workgroup][wave 0 | wave 7][8 phases] u64, handed over in the kernel arguments (`tl`, null = off).
 #ifdef BAMD_TIMING
-static __device__ unsigned long long g_stamps[64 * 16];      // one copy per translation unit: tools/timing_*.cpp include the .hip they time
-static inline void bamd_read_stamps(unsigned long long * host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16); }
-#define STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TL_STAMP(tl, k) do { if ((tl) && (threadIdx.x & 63) == 0 && blockIdx.x < BAMD_TL_WG && blockIdx.y == 0) { const int w_ = (int) (threadIdx.x >> 6); \
+        if (w_ == 0 || w_ == 7) (tl)[(size_t) blockIdx.x * 16 + (w_ ? 8 : 0) + (k)] = wall_clock64(); } } while (0)
 #else
-#define STAMP(k) do { } while (0)
+#define TL_STAMP(tl, k) do { } while (0)
 #endif
 
 __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short) bits16)); }
@@ -141,6 +142,8 @@ __device__ __forceinline__ double wave_sum_f64(double s) {                  // f
 template <bool NORM>
 struct ActPro {
     float4 v[BAMD_ACT_BATCH], w[BAMD_ACT_BATCH];
+    int okmask;                                          // bit b: batch slot b holds a block of the vector (wave-uniform)
+    unsigned long long * tl = nullptr;                   // phase stamps (BAMD_TIMING builds)
 
     // the loads of this wave's first batch of blocks: issued at kernel entry, AHEAD of the bulk weight prefetch, so the
     // (tiny, latency-critical) activation read is not queued behind megabytes of weight requests
@@ -148,11 +151,18 @@ struct ActPro {
     __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0, int bstride = 0, int blimit = 0) {
         const int lane = threadIdx.x & 63;
         if (bstride == 0) { bstride = blockDim.x >> 6; blimit = K >> 8; }
+        // UNCONDITIONAL requests (a block index past the end is clamped to the last block and its values are
+        // never used): a conditional load becomes a branch around the request with a full s_waitcnt at the join, which serialised the
+        // batches into one memory round trip each — and held back the weight ring that is issued after them
+        okmask = 0;
 #pragma unroll
         for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
             const int i = i0 + b * bstride;
-            v[b] = i < blimit ? *(const float4 *) (x + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NORM) w[b] = i < blimit ? *(const float4 *) (nw + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = i < blimit;
+            okmask |= ok ? 1 << b : 0;
+            const int ic = ok ? i : blimit - 1;          // past the end: the last block again; its values are never used (okmask, i < nb below)
+            v[b] = *(const float4 *) (x + ic * 256 + lane * 4);
+            if (NORM) w[b] = *(const float4 *) (nw + ic * 256 + lane * 4);
         }
     }
 
@@ -232,6 +242,10 @@ struct ActPro {
         }
     }
 
+    // SMALLK: the caller guarantees K <= 256 * BAMD_ACT_BATCH * (waves per workgroup), so the first batch is the whole share of this
+    // wave and the loops over further batches (whose in-loop requests force a full s_waitcnt at their exit — which would also wait for
+    // the weight ring issued before this call) are compiled out
+    template <bool SMALLK = false>
     __device__ __forceinline__ void finish(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
                                            uint32_t * q8, int * S, float * yd, double * red) {
         const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
@@ -242,17 +256,18 @@ struct ActPro {
             double s = 0.0;
 #pragma unroll
             for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
-                s += (double) (v[b].x * v[b].x); s += (double) (v[b].y * v[b].y); s += (double) (v[b].z * v[b].z); s += (double) (v[b].w * v[b].w);
+                if (okmask >> b & 1) { s += (double) (v[b].x * v[b].x); s += (double) (v[b].y * v[b].y); s += (double) (v[b].z * v[b].z); s += (double) (v[b].w * v[b].w); }
             }
-            for (int i0 = wave + step; i0 < nb; i0 += step) {          // only for K > 256 * 4 * nwaves
+            if (!SMALLK) for (int i0 = wave + step; i0 < nb; i0 += step) {          // only for K > 256 * 4 * nwaves
                 ActPro<NORM> t; t.issue(x, nw, K, i0);
 #pragma unroll
                 for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
-                    s += (double) (t.v[b].x * t.v[b].x); s += (double) (t.v[b].y * t.v[b].y); s += (double) (t.v[b].z * t.v[b].z); s += (double) (t.v[b].w * t.v[b].w);
+                    if (t.okmask >> b & 1) { s += (double) (t.v[b].x * t.v[b].x); s += (double) (t.v[b].y * t.v[b].y); s += (double) (t.v[b].z * t.v[b].z); s += (double) (t.v[b].w * t.v[b].w); }
                 }
             }
             s = wave_sum_f64(s);
             if (lane == 0) red[wave] = s;
+            TL_STAMP(tl, 5);
             __syncthreads();
             double tot = 0.0;
             for (int w2 = 0; w2 < nwaves; ++w2) tot += red[w2];
@@ -262,10 +277,11 @@ struct ActPro {
             scale = 1.0f / sqrtf(mean + eps);
         }
         quantize_batch(scale, K, wave, q8, S, yd);
-        for (int i0 = wave + step; i0 < nb; i0 += step) {
+        if (!SMALLK) for (int i0 = wave + step; i0 < nb; i0 += step) {
             ActPro<NORM> t; t.issue(x, nw, K, i0);
             t.quantize_batch(scale, K, i0, q8, S, yd);
         }
+        TL_STAMP(tl, 6);
         __syncthreads();
     }
 };
@@ -457,9 +473,10 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, int row) {
     return ((unsigned long long) u << 32) | (unsigned long long) (0xffffffffu - (uint32_t) row);
 }
 
-struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S; float * yd; double * red; };
-#define BAMD_PRO_ISSUE(ap, pa) (ap).issue((pa).x, (pa).nw, (pa).K, wave_id())
+struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S; float * yd; double * red; unsigned long long * tl; };
+#define BAMD_PRO_ISSUE(ap, pa) do { (ap).tl = (pa).tl; (ap).issue((pa).x, (pa).nw, (pa).K, wave_id()); } while (0)
 #define BAMD_PRO_FINISH(ap, pa) (ap).finish((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
+#define BAMD_PRO_FINISH_SMALLK(ap, pa) (ap).template finish<true>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
 
 __device__ __forceinline__ void get_scale_min_k4(int j, const uint8_t * q, int & d, int & m) {
     if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; }

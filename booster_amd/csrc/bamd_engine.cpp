@@ -124,6 +124,8 @@ struct bamd_context {
     struct StageGraph { hipGraphExec_t exec = nullptr; const void * token_src = nullptr, * hin = nullptr; void * hout = nullptr; int fused = -1; };
     StageGraph sgraph[2][2];
     // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
+    // phase-stamp blocks (bamd_timeline_step, BAMD_TIMING builds): one block of BAMD_TL_SLOT_WORDS u64 per launch
+    unsigned long long * tl_base = nullptr; int tl_slot = 0, tl_cap = 0;
     int bcap = 0;
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr, * bu = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
@@ -359,6 +361,10 @@ struct StepTimer {                 // optional per-launch HIP-event timing (bamd
     void end(hipStream_t s) { if (!on) return; hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, s); ev.push_back(b); }
 };
 
+static unsigned long long * tl_next(bamd_context * c) {
+    if (!c->tl_base || c->tl_slot >= c->tl_cap) return nullptr;
+    return c->tl_base + (size_t) (c->tl_slot++) * BAMD_TL_SLOT_WORDS;
+}
 static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.stream; sg.out = out; sg.type = d.type; sg.nrows = d.nrows_pad; sg.nvalid = d.nrows; }
 
 // enqueue the layers of this stage for the token whose hidden state is in c->x; leaves the result in c->x
@@ -382,7 +388,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         else { seg_of(a.seg[a.nseg], ly.wk, c->k); a.nseg++; }
         if (ly.wv.type == ly.wk.type) { a.seg[a.nseg - 1].nrows += ly.wv.nrows; a.seg[a.nseg - 1].nvalid += ly.wv.nrows; }
         else { seg_of(a.seg[a.nseg], ly.wv, c->v); a.nseg++; }
-        a.x = c->x; a.normw = ly.attn_norm; a.eps = m->eps; a.K = m->E;
+        a.x = c->x; a.normw = ly.attn_norm; a.eps = m->eps; a.K = m->E; a.tl = tl_next(c);
         if (tm) tm->begin(s, 0, (double) (ly.wq.bytes + ly.wk.bytes + ly.wv.bytes));
         bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_STORE, m->n_cu, s);
         if (tm) tm->end(s);
@@ -391,26 +397,26 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
         if (tm) tm->begin(s, 1, 0.0);
-        // three-kernel path (scores | softmax | P.V) everywhere for now: the fused single-launch kernel is correct (tests)
-        // but not yet faster at n_kv ~ 256 (14.9 vs 12.8 us on MI355X) — BAMD_ATTN_FUSED=1 selects it
+        // single-launch kernel below 448 positions, three kernels (scores | softmax | P.V) above (attn_fused_for)
+        t.tl = tl_next(c);
         t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances
         if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
         if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
         memset(&a, 0, sizeof a);
-        seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x;
+        seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x; a.tl = tl_next(c);
         if (tm) tm->begin(s, 0, (double) ly.wo.bytes);
         bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
         if (tm) tm->end(s);
         // 4. h = silu(Wg . a) * (Wu . a),  a = Q8_K(rms_norm(x2) * ffn_norm)  (llama.cpp:8869-8885)
         memset(&a, 0, sizeof a);
-        seg_of(a.seg[0], ly.wg, c->h); seg_of(a.seg[1], ly.wu, c->h); a.nseg = 2; a.x = c->x2; a.normw = ly.ffn_norm; a.eps = m->eps; a.K = m->E;
+        seg_of(a.seg[0], ly.wg, c->h); seg_of(a.seg[1], ly.wu, c->h); a.nseg = 2; a.x = c->x2; a.normw = ly.ffn_norm; a.eps = m->eps; a.K = m->E; a.tl = tl_next(c);
         if (tm) tm->begin(s, 0, (double) (ly.wg.bytes + ly.wu.bytes));
         bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_SILU_MUL, m->n_cu, s);
         if (tm) tm->end(s);
         // 5. x = x2 + Wd . Q8_K(h)                                          (llama.cpp:8885, :8902)
         memset(&a, 0, sizeof a);
-        seg_of(a.seg[0], ly.wd, c->x); a.nseg = 1; a.x = c->h; a.K = m->F; a.res = c->x2;
+        seg_of(a.seg[0], ly.wd, c->x); a.nseg = 1; a.x = c->h; a.K = m->F; a.res = c->x2; a.tl = tl_next(c);
         if (tm) tm->begin(s, 0, (double) ly.wd.bytes);
         bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
         if (tm) tm->end(s);
@@ -420,7 +426,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
 static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
     bamd_model * m = c->m;
     bamd_mv_args a; memset(&a, 0, sizeof a);
-    seg_of(a.seg[0], m->output, c->logits); a.nseg = 1; a.x = c->x; a.normw = m->out_norm; a.eps = m->eps; a.K = m->E; a.best_key = &c->st->best_key;
+    seg_of(a.seg[0], m->output, c->logits); a.nseg = 1; a.x = c->x; a.normw = m->out_norm; a.eps = m->eps; a.K = m->E; a.best_key = &c->st->best_key; a.tl = tl_next(c);
     if (tm) tm->begin(s, 0, (double) m->output.bytes);
     bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_ARGMAX, m->n_cu, s);
     if (tm) tm->end(s);
@@ -818,6 +824,47 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
         std::sort(ov.begin(), ov.end());
         launches[3] = 9; ms[3] = ov[4]; bytes[3] = 0;
     }
+    return 0;
+}
+
+// Phase stamps of one decode step at position `pos` (BAMD_TIMING builds only): the step is captured into a hipGraph whose launches
+// carry their stamp blocks, replayed `replays` times back to back (each replay overwrites the stamps: the last one is read), and the
+// blocks are copied to `out` ([n_launches][BAMD_TL_SLOT_WORDS] u64, launch order: per layer qkv, attention, wo, gate/up, down; then
+// lm_head).  100 MHz device wall clock.  *n_launches receives the number of stamped launches.
+extern "C" __attribute__((visibility("default"))) int bamd_timeline_step(bamd_context * c, int pos, int replays, unsigned long long * out, int cap_launches, int * n_launches) {
+    bamd_model * m = c->m;
+    if (!bamd_timing_enabled()) return fail("bamd_timeline_step: library built without -DBAMD_TIMING (use booster_amd/lib/libbooster_amd_timing.so)");
+    if (!m->with_embd || !m->with_output) return fail("timeline needs a full single-stage model");
+    HIPC(hipSetDevice(m->device));
+    hipStream_t s = c->stream;
+    const int cap = (int) m->layers.size() * 5 + 1;
+    if (cap > cap_launches) return fail("bamd_timeline_step: output buffer too small");
+    const size_t bytes = (size_t) cap * BAMD_TL_SLOT_WORDS * 8;
+    unsigned long long * buf = nullptr;
+    HIPC(hipMalloc((void **) &buf, bytes));
+    HIPC(hipMemsetAsync(buf, 0, bytes, s));
+    int32_t tok = 1;
+    HIPC(hipMemcpyAsync(c->forced, &tok, 4, hipMemcpyHostToDevice, s));
+    c->tl_base = buf; c->tl_slot = 0; c->tl_cap = cap;
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue_begin(c, 1, 1, s);
+    int rc = enqueue_layers(c, 0, s, nullptr, pos);
+    enqueue_lm_head(c, s, nullptr);
+    hipError_t e = hipStreamEndCapture(s, &g);
+    *n_launches = c->tl_slot;
+    c->tl_base = nullptr; c->tl_slot = 0; c->tl_cap = 0;
+    if (rc || e != hipSuccess) { if (g) hipGraphDestroy(g); hipFree(buf); return rc ? rc : fail("timeline capture failed"); }
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { hipFree(buf); return fail("timeline graph instantiate failed"); }
+    for (int r = 0; r < replays; ++r) {
+        if (set_state(c, pos, s, false)) { hipGraphExecDestroy(ge); hipFree(buf); return 1; }
+        HIPC(hipGraphLaunch(ge, s));
+    }
+    HIPC(hipStreamSynchronize(s));
+    HIPC(hipMemcpy(out, buf, (size_t) *n_launches * BAMD_TL_SLOT_WORDS * 8, hipMemcpyDeviceToHost));
+    hipGraphExecDestroy(ge); hipFree(buf);
     return 0;
 }
 

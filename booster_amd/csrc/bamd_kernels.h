@@ -26,7 +26,9 @@ struct bamd_mv_args {
     float eps; int K;
     const float * res;             // residual (BAMD_EPI_ADD), indexed like seg[0].out
     unsigned long long * best_key; // BAMD_EPI_ARGMAX
-    int mode;                      // 0 auto, 1 force one-wave-per-row-group, 2 force split-K (tests)
+    int mode;                      // 0 auto, 1 force one-wave-per-row-group, 2 force split-K (tests); + 16: force the generic kernels
+    int cnt_q, cnt_r;              // fast kernels: row-groups per wave slot (mode A) / per workgroup (mode B), quotient and remainder (set by the launcher)
+    unsigned long long * tl;       // phase-stamp block of this launch (BAMD_TIMING builds; null = off)
 };
 
 struct bamd_attn_args {
@@ -43,6 +45,7 @@ struct bamd_attn_args {
     int batch, ld_qkv, ld_out;     // batched prefill: q/k/v and out are [T][ld_*] f32, token = blockIdx.y, position st->pos + token
     int lds_ld;                    // single-launch / batched kernels: floats per score / probability row in LDS — a multiple of 64 that bounds the padded
                                    // sequence length of this launch (or of every replay of the graph it is captured in); 0 = n_ctx
+    unsigned long long * tl;       // phase-stamp block of this launch (BAMD_TIMING builds; null = off)
 };
 
 // batched prefill mat-mul: Y[t][row] = W[row,:] . Q8_K(a_t), T tokens
@@ -53,6 +56,9 @@ struct bamd_mm_args {
     const float * res;             // BAMD_EPI_ADD: residual, indexed like seg[0].out
 };
 
+#define BAMD_TL_WG 512                 /* workgroups recorded per launch (phase stamps, BAMD_TIMING builds) */
+#define BAMD_TL_SLOT_WORDS (BAMD_TL_WG * 16)
+int  bamd_timing_enabled(void);   // 1 when the kernels were compiled with -DBAMD_TIMING
 void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K, hipStream_t s);
 void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s);
 void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipStream_t s);

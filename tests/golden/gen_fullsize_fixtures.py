@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Full-size fixtures from the GENUINE reference (build container only; needs /root/reference and oracle/_ref/ref_run).
+
+For every BASELINE.json configuration the deterministic synthetic GGUF of that shape (booster_amd.gguf.write_synthetic_llama,
+numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture carries the file's size and a digest of its first
+64 MiB) is evaluated by the reference CPU path (oracle/_ref/ref_run -> llama_decode, cpp/src/llama.cpp:14537) on the synthetic
+prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
+logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
+
+    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from booster_amd import gguf  # noqa: E402
+
+Q6 = gguf.Q6_K
+CONFIGS = {
+    # name: (model kwargs, n_prompt, n_decode, n_ctx, threads)
+    "8b": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, theta=500000.0), 128, 128, 512),
+    "8b_prefill2048": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, theta=500000.0), 2048, 8, 4096),
+    # one pipeline stage of Llama-3-70B Q4_K_M (the last: 10 layers + output layer), 70B widths, Q5_K attn_v outside the "more bits" layers
+    "70b_stage": (dict(E=8192, H=64, Hkv=8, L=10, F=28672, V=128256, theta=500000.0, type_fn="70b"), 8, 16, 256),
+    "m7q6k_8k": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=32000, theta=10000.0, type_fn="q6k", embd_type=Q6), 8064, 16, 8192),
+}
+
+
+def type_fn_of(tag, L):
+    if tag == "q6k":
+        return lambda name, il: gguf.Q6_K
+    if tag == "70b":
+        # Q4_K_M recipe of an 80-layer model seen from its LAST stage (layers 70..79): attn_v Q6_K in the "more bits" layers, else Q5_K
+        def f(name, il):
+            t = gguf.q4_k_m_type(name, 70 + il, 80)
+            if name == "attn_v" and t == gguf.Q4_K:
+                return gguf.Q5_K
+            return t
+        return f
+    return None
+
+
+def model_path(cfg):
+    return "/dev/shm/bamd_fx_%s.gguf" % cfg.replace("_prefill2048", "")
+
+
+def ensure_model(cfg):
+    kw = dict(CONFIGS[cfg][0])
+    p = model_path(cfg)
+    if not os.path.exists(p + ".done"):
+        tf = kw.pop("type_fn", None)
+        gguf.write_synthetic_llama(p, seed=7, reuse_layers=True, type_fn=type_fn_of(tf, kw["L"]), **kw)
+        open(p + ".done", "w").write("ok")
+    return p
+
+
+def file_digest(p):
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        h.update(f.read(64 << 20))
+    return h.hexdigest(), os.path.getsize(p)
+
+
+def main():
+    cfgs = sys.argv[1:] or list(CONFIGS)
+    threads = int(os.environ.get("REF_THREADS", str(os.cpu_count() or 8)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_run")
+    for cfg in cfgs:
+        _, n_prompt, n_decode, n_ctx = CONFIGS[cfg]
+        p = ensure_model(cfg)
+        out = os.path.join(ROOT, "tests", "golden", "fullsize_%s.bgld" % cfg)
+        t0 = time.time()
+        r = subprocess.run([exe, p, str(threads), str(n_prompt), str(n_decode), str(n_ctx), out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+        dg, sz = file_digest(p)
+        line = r.stdout.decode().strip().splitlines()[-1]
+        with open(out + ".txt", "w") as f:
+            f.write("%s\ngguf_bytes=%d gguf_sha256_first64MiB=%s\n" % (line, sz, dg))
+        print(cfg, line, "(%.0f s)" % (time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()
