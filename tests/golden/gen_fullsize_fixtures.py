@@ -44,8 +44,10 @@ def type_fn_of(tag, L):
     return None
 
 
-def model_path(cfg):
-    return "/dev/shm/bamd_fx_%s.gguf" % cfg.replace("_prefill2048", "")
+def model_path(cfg, d="/dev/shm"):
+    if cfg.startswith("8b"):
+        return os.path.join(d, "bamd_llama3_8b_q4_k_m_synth.gguf")      # the file bench.py and tests/test_gpu_fullsize.py use
+    return os.path.join(d, "bamd_fx_%s.gguf" % cfg)
 
 
 def ensure_model(cfg):

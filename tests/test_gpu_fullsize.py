@@ -16,9 +16,10 @@ CFG = dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256)
 @pytest.fixture(scope="module")
 def model_path():
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    p = os.path.join(d, "bamd_test_8b.gguf")
-    if not os.path.exists(p):
-        gguf.write_synthetic_llama(p, seed=7, reuse_layers=True, **CFG)
+    p = os.path.join(d, "bamd_llama3_8b_q4_k_m_synth.gguf")       # shared with bench.py and test_gpu_fullsize_ref.py (same bytes)
+    if not os.path.exists(p + ".done"):
+        gguf.write_synthetic_llama(p, seed=7, reuse_layers=True, theta=500000.0, eps=1e-5, n_ctx_train=8192, **CFG)
+        open(p + ".done", "w").write("ok")
     return p
 
 
