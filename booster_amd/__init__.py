@@ -140,9 +140,10 @@ class Context:
         return launches, ms, nbytes
 
     def timeline_step(self, pos, replays=3):
-        """phase stamps of one decode step (BAMD_LIB=.../libbooster_amd_timing.so): u64 [launches][512 workgroups][2 waves][8 phases], 100 MHz"""
+        """phase stamps of one decode step (BAMD_LIB=.../libbooster_amd_timing.so): u64 [launches][512 workgroups][24], 100 MHz;
+        per workgroup: 8 phases of wave 0, 8 phases of wave 7, the exit stamp of each of the 8 waves"""
         cap = 5 * self.model.n_layer + 1
-        out = np.zeros((cap, 512, 2, 8), np.uint64)
+        out = np.zeros((cap, 512, 24), np.uint64)
         n = C.c_int(0)
         _chk(lib().bamd_timeline_step(self.h, pos, replays, _p(out), cap, C.byref(n)))
         return out[:n.value]

@@ -45,7 +45,8 @@
 // into the stamp block of its launch — [workgroup][wave 0 | wave 7][8 phases] u64, handed over in the kernel arguments (`tl`, null = off).
 #ifdef BAMD_TIMING
 #define TL_STAMP(tl, k) do { if ((tl) && (threadIdx.x & 63) == 0 && blockIdx.x < BAMD_TL_WG && blockIdx.y == 0) { const int w_ = (int) (threadIdx.x >> 6); \
-        if (w_ == 0 || w_ == 7) (tl)[(size_t) blockIdx.x * 16 + (w_ ? 8 : 0) + (k)] = wall_clock64(); } } while (0)
+        if (w_ == 0 || w_ == 7) (tl)[(size_t) blockIdx.x * BAMD_TL_WG_WORDS + (w_ ? 8 : 0) + (k)] = wall_clock64(); \
+        if ((k) == 7 && w_ < 8) (tl)[(size_t) blockIdx.x * BAMD_TL_WG_WORDS + 16 + w_] = wall_clock64(); } } while (0)
 #else
 #define TL_STAMP(tl, k) do { } while (0)
 #endif

@@ -57,7 +57,8 @@ struct bamd_mm_args {
 };
 
 #define BAMD_TL_WG 512                 /* workgroups recorded per launch (phase stamps, BAMD_TIMING builds) */
-#define BAMD_TL_SLOT_WORDS (BAMD_TL_WG * 16)
+#define BAMD_TL_WG_WORDS 24            /* per workgroup: [wave 0: 8 phases][wave 7: 8 phases][exit stamp of each of 8 waves] */
+#define BAMD_TL_SLOT_WORDS (BAMD_TL_WG * BAMD_TL_WG_WORDS)
 int  bamd_timing_enabled(void);   // 1 when the kernels were compiled with -DBAMD_TIMING
 void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K, hipStream_t s);
 void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s);

@@ -1,0 +1,215 @@
+// bamd_matvec_core.h — device code shared by the mat-vec translation units (bamd_matvec.hip: generic kernels and launchers;
+// bamd_matvec_fast_a.hip / bamd_matvec_fast_b.hip: the host-dispatched fast kernels): the mode-A streaming loop and the mode-B
+// split-K loop.  Numerics contract and reference citations: bamd_device.h.
+#pragma once
+#include "bamd_device.h"
+
+template <int TYPE> struct RecOf;
+template <> struct RecOf<BAMD_Q4_K> { typedef RecQ4K type; };
+template <> struct RecOf<BAMD_Q5_K> { typedef RecQ5K type; };
+template <> struct RecOf<BAMD_Q6_K> { typedef RecQ6K type; };
+
+__device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned char * smem) {
+    const int nb = a.K >> 8;
+    ProArgs pa;
+    pa.x = a.x; pa.nw = a.normw; pa.eps = a.eps; pa.K = a.K;
+    pa.q8 = (uint32_t *) smem; pa.S = (int *) (pa.q8 + nb * 64); pa.yd = (float *) (pa.S + nb * 8);
+    pa.tl = a.tl;
+    pa.red = (double *) (smem + BAMD_ACT_RED_OFF(nb));     // byte offsets, never a pointer->integer->pointer round trip: that loses
+                                                           // the LDS address space and turns every access into a FLAT instruction
+    return pa;
+}
+
+
+// ---- MODE A: one wave per row-group --------------------------------------------------------------------------
+// The wave walks row-groups rg = first, first+stride, ... (count of them).  A register ring of D records is kept
+// in flight by a LOADER cursor that runs D records ahead of the consumer and crosses row-group boundaries by
+// pure (branch-free, scalar) arithmetic, so the prefetch never drains and the compiler can keep counted
+// s_waitcnt vmcnt(N) waits.  The ring is filled BEFORE the activation prologue (weights do not depend on it), so
+// the first HBM round trip overlaps the RMSNorm/Q8_K work.  With PAIR each row-group is streamed twice back to
+// back — gate (wA) then up (wB) — and the epilogue fuses silu(gate)*up.
+template <int TYPE, typename REC, int D, int EPI, int PRO, bool SMALLK = false>
+__device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb,
+                                               int first, int count, int stride, float * __restrict__ out,
+                                               const float * __restrict__ res, const ProArgs & pa, ActPro<PRO == BAMD_PRO_NORM> & ap,
+                                               bool issue_here, bool do_pro, unsigned long long & best, int nvalid) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    constexpr int NPARTS = PAIR ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const long rgb = (long) nb * RECB;                   // D divides nb (chosen by the dispatcher below)
+    const long rg_step = (long) stride * rgb;
+    const int chunks = nb / D;
+    if (issue_here) BAMD_PRO_ISSUE(ap, pa);              // activation loads go out FIRST (see ActPro::issue); the fast kernels issue them at entry
+    REC ring[D];
+    // The loader runs exactly one CHUNK (D records = the whole ring) ahead of the consumer: slot s is refilled, right after it
+    // is consumed, with record s of the chunk that follows in this wave's sequence (next chunk of the row, else the other half
+    // of a gate/up pair, else the next row-group).  One wave-uniform base address per chunk: the per-record cost of the cursor
+    // is a constant offset, and the loads stay unconditional so the compiler keeps counted s_waitcnt vmcnt(N) waits.
+    // (a wave without work — count == 0, fast kernels only — requests record 0 of the matrix D times: L1 hits, and its code path stays
+    // the one of the busy waves: one copy of the prologue, no join in front of the counted waits)
+    const uint8_t * rowA = wA + (count > 0 ? (long) first * rgb : 0l);
+    const int fill_step = count > 0 ? RECB : 0;
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * fill_step, lane);
+    TL_STAMP(pa.tl, 1);
+    if (do_pro) { if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa); else BAMD_PRO_FINISH(ap, pa); }
+    TL_STAMP(pa.tl, 2);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    for (int r = 0; r < count; ++r) {
+        const int rg = first + r * stride;
+        const int row = rg * 8 + (lane >> 3);
+        const long rowoff = (long) rg * rgb;
+        float gate_val = 0.f;
+#pragma unroll
+        for (int part = 0; part < NPARTS; ++part) {
+            const uint8_t * pbase = (part ? wB : wA) + rowoff;
+            // after the last chunk of this row-part: the other half of the pair, the next row-group, or — at the very end of the
+            // wave's stream — its own last record again, D times (step 0: one record of redundant traffic, never consumed; the
+            // requests stay unconditional so that the waits stay counted)
+            const bool last = !(PAIR && part == 0) && r + 1 >= count;
+            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
+            // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
+            float resv = 0.f;
+            if (EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
+            RowAcc A = { 0.f, 0.f };
+            for (int c = 0; c < chunks; ++c) {
+                const bool inrow = c + 1 < chunks;
+                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const int step = (inrow || !last) ? RECB : 0;
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    pin_rec(ring[s]);
+                    const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
+                    chain_step<TYPE>(A, T.d, T.fs, T.dmin, T.pm);
+                    load_rec(ring[s], nxt + s * step, lane);
+                    if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1)
+                        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from clustering the refills at the loop tail
+                }
+                if (r == 0 && part == 0 && c == 0) TL_STAMP(pa.tl, 3);
+            }
+            if (r + 1 == count && part == NPARTS - 1) TL_STAMP(pa.tl, 4);
+            const float val = finish_row<TYPE>(A);
+            if (PAIR) {
+                if (part == 0) gate_val = val;
+                else if ((lane & 7) == 0 && row < nvalid) out[row] = v_silu(gate_val) * val;
+            } else if ((lane & 7) == 0 && row < nvalid) {
+                float o = val;
+                if (EPI == BAMD_EPI_ADD) o = val + resv;
+                out[row] = o;
+                if (EPI == BAMD_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, row); best = k > best ? k : best; }
+            }
+        }
+    }
+}
+
+
+// ---- MODE B: split-K, one 8-wave workgroup per row-group ------------------------------------------------------
+// For matrices with few row-groups (wq/wk/wv/wo, ffn_down: 512..768 of them) one wave per row-group leaves the chip
+// short of bytes in flight.  Here the 8 waves of a workgroup share a row-group: wave w streams super-blocks
+// [w*nb/8, (w+1)*nb/8) and writes the per-block TERMS (d, fs, dmin, pm — exact integers already converted) to LDS;
+// after a workgroup barrier ONE wave replays the reference's sequential f32 chain over all nb blocks in order.
+// Same arithmetic, same order, 8x the parallelism.  Term buffers are double-buffered so the chain of row-group n
+// overlaps the streaming of row-group n+1; the prefetch ring spans row-group boundaries (M row-groups per body).
+// LDS term buffers: 2 (double buffer) x M (row-groups per batch) x nb x 64 lanes x float4 {d, fs, dmin, pm}
+#define BAMD_TERM_FLOATS(nb) ((size_t) (nb) * 256)      /* one float4 {d, fs, dmin, pm} per lane per super-block */
+
+// ONEB (fast kernels): every workgroup has exactly M row-groups — one batch, no refills, no loop: the waits for the ring stay counted
+// (record by record) instead of one full wait at the loop head
+template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false>
+__device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
+                                             float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
+                                             ActPro<PRO == BAMD_PRO_NORM> & ap, ActPro<PRO == BAMD_PRO_NORM> & ap2, bool issue_here, bool do_pro,
+                                             float * part0, int & batchctr, int nvalid) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int r8 = lane >> 3, l4 = lane & 3;
+    const long rgb = (long) nb * RECB;
+    const long rg_step = (long) stride * rgb;
+    const int i0 = wave * NBW;                               // this wave's first super-block inside a row
+    const size_t rg_floats = BAMD_TERM_FLOATS(nb);
+    // PLAIN prologue: wave w consumes only the activations of its own K-slice (blocks i0 .. i0+NBW-1), so it quantises exactly
+    // those — no workgroup barrier, and a wave starts on its records as soon as ITS blocks are done.  (NORM needs the sum of
+    // squares of the whole vector: shared prologue as in mode A.)
+    constexpr bool OWN = PRO == BAMD_PRO_PLAIN;
+    if (issue_here) {                                        // (the fast kernels issue these at entry)
+        if (OWN) { ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + NBW); if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + NBW); }
+        else BAMD_PRO_ISSUE(ap, pa);                         // activation loads go out FIRST
+    }
+    // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
+    // r0+M+m, i.e. a constant M*rg_step further on: the loader needs one wave-uniform base per batch and nothing per record
+    const uint8_t * bbase = w + (long) first * rgb + (long) i0 * RECB;
+    REC ring[D];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        // generic kernels: no redundant requests when the stream is short.  Fast kernels (SMALLK): the launcher picks M <= the row-groups of
+        // every workgroup, so the requests are unconditional — a branch around them costs a full s_waitcnt at the join, i.e. the
+        // activation prologue would wait for the whole ring to land before it starts
+        if (SMALLK || m < count) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], bbase + (long) m * rg_step + j * RECB, lane);
+        }
+    }
+    TL_STAMP(pa.tl, 1);
+    if (do_pro) {
+        if (OWN) {
+            static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");
+            ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
+            if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
+        } else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
+        else BAMD_PRO_FINISH(ap, pa);
+    }
+    TL_STAMP(pa.tl, 2);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    for (int r0 = 0; r0 < (ONEB ? 1 : count); r0 += M) {
+        const int nbatch = ONEB ? M : (count - r0 < M ? count - r0 : M);  // workgroup-uniform
+        float * B0 = part0 + (NBUF == 2 ? (size_t) (batchctr & 1) * M * rg_floats : (size_t) 0);
+        // the wave that will run the chain of row-group r0+wave fetches its residual now (old by chain time)
+        const int crow = (first + (r0 + (wave < nbatch ? wave : 0)) * stride) * 8 + r8;
+        float resv = 0.f;
+        if (EPI == BAMD_EPI_ADD && crow < nvalid) resv = res[crow];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            if (m < nbatch) {
+                float4 * P = (float4 *) (B0 + (size_t) m * rg_floats);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const int s = m * NBW + j;
+                    const int ci = i0 + j;
+                    pin_rec(ring[s]);
+                    const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
+                    P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
+                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], bbase + (long) (M + m) * rg_step + j * RECB, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (r0 == 0) TL_STAMP(pa.tl, 3);
+        __syncthreads();
+        if (r0 == 0) TL_STAMP(pa.tl, 4);
+        if (wave < nbatch) {
+            // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
+            const float4 * P = (const float4 *) (B0 + (size_t) wave * rg_floats);
+            RowAcc A = { 0.f, 0.f };
+            for (int i = 0; i < nb; i += 8) {                // nb % 8 == 0 here; the 16-byte LDS reads of 8 blocks issued together
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+            }
+            const float val = finish_row<TYPE>(A);
+            if ((lane & 7) == 0 && crow < nvalid) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
+            if (r0 == 0) TL_STAMP(pa.tl, 5);
+        }
+        batchctr += 1;
+        bbase += (long) M * rg_step;
+        if (NBUF == 1 && r0 + M < count) __syncthreads();    // single term buffer: the chains must be done before the next batch writes
+    }
+}
+
+
+// host-side dispatch of the fast kernels (bamd_matvec_fast_a.hip / _b.hip); false = no instance for this shape: generic kernel
+bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);
+bool bamd_launch_fast_b(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);

@@ -1,0 +1,107 @@
+// bamd_matvec_fast_a.hip — fast mode-A mat-vec kernels (one wave per row-group) and their host-side dispatch.
+#include "bamd_matvec_core.h"
+// ===========================================================================================================
+// FAST KERNELS — one kernel per (weight type, launch shape): straight-line code from the first instruction to the streaming loop.
+// The generic kernels above pick the weight type, the ring depth and the segment at run time inside ONE kernel; hipcc then has to
+// merge register states at every join, which (a) put a full s_waitcnt behind each conditional activation load and held the weight
+// ring back until the activations had arrived, (b) spilled scalar registers to vector lanes, and (c) made every launch walk through
+// a 200 KB code object.  Here the dispatch happens on the host (bamd_launch_matvec): activation requests at entry, ring requests
+// right behind them, counted waits all the way.  Same device functions (block_terms / chain_step / finish_row), same bits.
+// Shapes outside the table (K/256 not a multiple of 8, three differently typed segments, ...) keep using the generic kernels.
+// ===========================================================================================================
+
+// mode A.  TYPE1 == 0: one segment (or the gate/up pair: seg[0] and seg[1] of TYPE0, EPI_SILU_MUL), any number of row-groups per wave
+// (a.cnt_q / a.cnt_r = row-groups / wave slots, quotient and remainder).  TYPE1 != 0: two segments of different types with at most one
+// row-group per wave (fused QKV with a Q6_K / Q5_K attn_v): the wave's row-group picks the branch, each branch is straight-line.
+template <int TYPE0, int TYPE1, int PRO, int EPI>
+__global__ void __launch_bounds__(512) matvec_fast_kernel(bamd_mv_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TL_STAMP(a.tl, 0);
+    const int nb = a.K >> 8;
+    const ProArgs pa = carve_lds(a, smem);
+    ActPro<PRO == BAMD_PRO_NORM> ap;
+    BAMD_PRO_ISSUE(ap, pa);                                  // activation requests: the first memory instructions of the kernel
+    const int wave = wave_id(), nwaves = blockDim.x >> 6;
+    const int slot = blockIdx.x + gridDim.x * wave;          // consecutive row-groups land on different CUs
+    const int stride = gridDim.x * nwaves;
+    unsigned long long best = 0ull;
+    constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
+    typedef typename RecOf<TYPE0>::type REC0;
+    const int nrg0 = a.seg[0].nrows >> 3;
+    const int nv0 = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
+    if (TYPE1 == 0) {
+        const int count = a.cnt_q + (slot < a.cnt_r ? 1 : 0);
+        const uint8_t * wA = (const uint8_t *) a.seg[0].w;
+        const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
+        stream_segment<TYPE0, REC0, 8, EPI, PRO, true>(wA, wB, nb, slot, count, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);   // count == 0: prologue only
+    } else {
+        typedef typename RecOf<TYPE1 == 0 ? TYPE0 : TYPE1>::type REC1;
+        constexpr int T1 = TYPE1 == 0 ? TYPE0 : TYPE1;
+        const int nrg1 = a.seg[1].nrows >> 3;
+        const int nv1 = a.seg[1].nvalid > 0 ? a.seg[1].nvalid : a.seg[1].nrows;
+        if (slot >= nrg0 && slot < nrg0 + nrg1) {
+            const uint8_t * w1 = (const uint8_t *) a.seg[1].w;
+            stream_segment<T1, REC1, 8, EPI, PRO, true>(w1, w1, nb, slot - nrg0, 1, stride, a.seg[1].out, a.res, pa, ap, false, true, best, nv1);
+        } else {                                             // segment 0, or no work (count 0: prologue only)
+            const uint8_t * w0 = (const uint8_t *) a.seg[0].w;
+            stream_segment<TYPE0, REC0, 8, EPI, PRO, true>(w0, w0, nb, slot, slot < nrg0 ? 1 : 0, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);
+        }
+    }
+    if (EPI == BAMD_EPI_ARGMAX) {
+        // wave max -> block max -> one atomic per workgroup
+        for (int o = 32; o; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob > best ? ob : best; }
+        __syncthreads();
+        unsigned long long * wb = (unsigned long long *) smem;
+        if ((threadIdx.x & 63) == 0) wb[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = 0ull;
+            for (int w = 0; w < nwaves; ++w) b = wb[w] > b ? wb[w] : b;
+            if (b) atomicMax(a.best_key, b);
+        }
+    }
+    TL_STAMP(a.tl, 7);
+}
+
+// mode B (split-K), one segment of one type, NBW = K / 2048 records per wave and row-group, M row-groups per batch
+
+// ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
+template <int PRO, int EPI, int T0, int T1>
+static void launch_fast_a_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, a);
+}
+template <int PRO, int EPI>
+static bool launch_fast_a_types(const bamd_mv_args & a, int t0, int t1, int grid, hipStream_t s) {
+    constexpr bool MIX = PRO == BAMD_PRO_NORM && EPI == BAMD_EPI_STORE;      // two differently typed segments: the fused QKV launch only
+#define BAMD_A_CASE(T0_, T1_) if (t0 == T0_ && t1 == T1_) { launch_fast_a_inst<PRO, EPI, T0_, T1_>(a, grid, s); return true; }
+    BAMD_A_CASE(BAMD_Q4_K, 0) BAMD_A_CASE(BAMD_Q5_K, 0) BAMD_A_CASE(BAMD_Q6_K, 0)
+    if (MIX) {
+        BAMD_A_CASE(BAMD_Q4_K, BAMD_Q5_K) BAMD_A_CASE(BAMD_Q4_K, BAMD_Q6_K) BAMD_A_CASE(BAMD_Q5_K, BAMD_Q4_K)
+        BAMD_A_CASE(BAMD_Q5_K, BAMD_Q6_K) BAMD_A_CASE(BAMD_Q6_K, BAMD_Q4_K) BAMD_A_CASE(BAMD_Q6_K, BAMD_Q5_K)
+    }
+#undef BAMD_A_CASE
+    return false;
+}
+bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s) {
+    const int nb = a.K >> 8;
+    if ((nb & 7) != 0 || nb < 8 || nb > 8 * BAMD_ACT_BATCH) return false;      // SMALLK prologue: K <= 8192
+    const int slots = grid * 8;
+    int t0 = a.seg[0].type, t1 = 0;
+    const int nrg0 = a.seg[0].nrows >> 3;
+    if (epi == BAMD_EPI_SILU_MUL) { if (a.nseg != 2 || a.seg[1].type != t0 || a.seg[1].nrows != a.seg[0].nrows) return false; }
+    else if (a.nseg == 2) {
+        t1 = a.seg[1].type;
+        if (t1 == t0 || nrg0 + (a.seg[1].nrows >> 3) > slots) return false;
+    } else if (a.nseg != 1) return false;
+    a.cnt_q = nrg0 / slots; a.cnt_r = nrg0 % slots;
+    if (pro == BAMD_PRO_NORM) {
+        if (epi == BAMD_EPI_STORE)    return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_STORE>(a, t0, t1, grid, s);
+        if (epi == BAMD_EPI_SILU_MUL) return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_SILU_MUL>(a, t0, 0, grid, s);
+        if (epi == BAMD_EPI_ARGMAX)   return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_ARGMAX>(a, t0, t1, grid, s);
+        return false;
+    }
+    if (t1 != 0) return false;
+    if (epi == BAMD_EPI_STORE) return launch_fast_a_types<BAMD_PRO_PLAIN, BAMD_EPI_STORE>(a, t0, 0, grid, s);
+    if (epi == BAMD_EPI_ADD)   return launch_fast_a_types<BAMD_PRO_PLAIN, BAMD_EPI_ADD>(a, t0, 0, grid, s);
+    return false;
+}

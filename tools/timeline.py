@@ -21,12 +21,14 @@ sys.path.insert(0, ROOT)
 
 
 def reduce_timeline(tl, L):
-    """tl: u64 [launches][512][2][8] -> list of dicts per launch"""
+    """tl: u64 [launches][512][24] -> list of dicts per launch"""
     rows = []
     prev_end = None
     for i in range(tl.shape[0]):
-        a = tl[i].astype(np.float64)
-        a[a == 0] = np.nan
+        full = tl[i].astype(np.float64)
+        full[full == 0] = np.nan
+        a = full[:, :16].reshape(-1, 2, 8).copy()
+        a[:, 0, 7] = np.nanmax(full[:, 16:24], axis=1) if not np.all(np.isnan(full[:, 16:24])) else a[:, 0, 7]   # exit: the LAST wave of the workgroup
         if np.all(np.isnan(a[:, :, 0])):
             rows.append(None); continue
         t0 = np.nanmin(a[:, :, 0])
