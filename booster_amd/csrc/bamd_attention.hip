@@ -154,7 +154,11 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
 // scores and probabilities live in dynamic LDS (2 x ld floats, ld = the caller's bound on the padded sequence length, independent
 // of n_ctx).  Single-token decode uses this kernel for short sequences (beyond a few hundred positions one workgroup per head no
 // longer has the bandwidth: three-kernel path); batched prefill, with T x H workgroups, while the rows fit the LDS.
+// LG = head_dim / 64 (chain steps per lane / 8): compile-time, so that every request below is unconditional and the chains unroll.
+// Latency-bound (the K / V bytes of a few hundred positions are nothing): what matters is the ORDER of the requests and that none
+// of them sits behind a branch — a conditional load costs a full s_waitcnt at its join.
 #define BAMD_ATTN_LDS_MAX (144 * 1024)    /* score + probability rows of one workgroup */
+template <int LG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_fused_kernel(bamd_attn_args a, int gq) {
     __shared__ __attribute__((aligned(16))) float qt[256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
@@ -172,60 +176,77 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     int n_kv = st->n_kv;
     if (a.batch) { n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx; }
     a.q += (size_t) tokb * a.ld_qkv; a.k += (size_t) tokb * a.ld_qkv; a.v += (size_t) tokb * a.ld_qkv; a.out += (size_t) tokb * a.ld_out;
-    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    constexpr int hd = LG * 64, L = LG * 8, hp = hd / 2;
+    const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int h = blockIdx.x, hk = h / gq;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
     const float * rope = a.rope + (size_t) pos * hd;
     TL_STAMP(a.tl, 0);
-    // requests that do not depend on RoPE go out first: this lane's K chunks of the first 4 x 64 positions and its V^T chunks
+    // 1. the small, latency-critical requests go out FIRST: this token's q / k pair and its cos / sin for the thread's RoPE role, and
+    //    the v elements the KV store and the P.V splice need.  Loads return in order: they land ~1 us before the K / V^T chunks
+    //    requested behind them, and RoPE runs while those stream in.
+    const int role = tid / hp, rp = tid - role * hp;              // role 0: q pair rp, role 1: k pair rp, others: (a redundant copy of role 0)
+    const float * rsrc = role == 1 ? a.k + (size_t) hk * hd : a.q + (size_t) h * hd;
+    const float2 xin = *(const float2 *) (rsrc + 2 * rp);
+    const float2 cs = *(const float2 *) (rope + 2 * rp);
+    const float vst = a.v[hk * hd + (tid < hd ? tid : 0)];        // KV store: element tid of this token's v
     const int r_pos = wave * 8 + (lane >> 3);                     // position inside a 64-tile (scores) / d inside a 64-block (P.V)
-    uint4 kreg[4][4];
+    float vcf[LG];
+#pragma unroll
+    for (int dd = 0; dd < LG; ++dd) vcf[dd] = a.v[hk * hd + r_pos + 64 * dd];
+    // 2. this lane's K chunks of the first 4 x 64 positions and its V^T chunks of the first 4 blocks (rows d = r_pos + 64 dd), all
+    //    unconditional: a tile past the end of the cache is clamped to the last one, positions >= pos hold zeros or stale finite
+    //    values whose scores are masked below and whose probabilities are exactly 0
+    uint4 kreg[4][LG];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int i = t * 64 + r_pos;
+        const int i = t * 64 + r_pos < n_ctx ? t * 64 + r_pos : n_ctx - 64 + r_pos;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) kreg[t][g] = (i < n_kv && i < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < LG; ++g) kreg[t][g] = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8);
     }
-    // ... and its V^T chunks: the first 4 blocks of 64 positions of rows d = r_pos and r_pos + 64 (consumed after the softmax)
-    uint4 vreg[4][2];
+    uint4 vreg[4][LG < 2 ? LG : 2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        const int tb = t * 64 < n_ctx ? t * 64 : n_ctx - 64;
 #pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const int d = r_pos + 64 * dd;
-            vreg[t][dd] = (t * 64 < n_kv && d < hd) ? *(const uint4 *) (a.vc + (size_t) (hk * hd + d) * n_ctx + t * 64 + e * 8) : make_uint4(0, 0, 0, 0);
-        }
+        for (int dd = 0; dd < (LG < 2 ? LG : 2); ++dd) vreg[t][dd] = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + tb + e * 8);
     }
-    rope_heads(a.q + (size_t) h * hd, rope, hd, 1, qt, q16t, nullptr);
-    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
+    {   // RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143 — rope_heads' arithmetic) into the chain-major LDS copies
+        const float t0 = xin.x * cs.x, t1 = xin.y * cs.y, t2 = xin.x * cs.y, t3 = xin.y * cs.x;
+        const float r0 = t0 - t1, r1 = t2 + t3;
+        const int i0 = kperm(2 * rp, L), i1 = kperm(2 * rp + 1, L);
+        if (role == 0) { qt[i0] = r0; qt[i1] = r1; q16t[i0] = f2h(r0); q16t[i1] = f2h(r1); }
+        else if (role == 1) { k16t[i0] = f2h(r0); k16t[i1] = f2h(r1); }
+    }
     __syncthreads();
     // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
-    if (h == hk * gq && !a.batch) {
-        for (int i = tid; i < hd; i += blockDim.x) {
-            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
-            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
-        }
+    if (h == hk * gq && !a.batch && tid < hd) {
+        a.kc[(size_t) pos * Ekv + hk * hd + tid] = k16t[tid];
+        a.vc[(size_t) (hk * hd + tid) * n_ctx + vperm(pos)] = f2h(vst);
     }
     TL_STAMP(a.tl, 1);
-    // ---- scores ----
+    // ---- scores: every chain runs unconditionally (independent chains interleave), the mask is a select at the end ----
+    uint4 kself[4];                                                // this token's K row is not visible in the cache yet
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kself[g] = g < LG ? *(const uint4 *) (k16t + e * L + g * 8) : make_uint4(0, 0, 0, 0);
 #define BAMD_SCORE_TILE(t0_, KL_) do { \
         const int i = (t0_) + r_pos; \
-        float v = -INFINITY;                                       /* masked (KQ_mask, llama.cpp:14152-14200) */ \
-        if (i < n_kv && i <= pos) { \
-            if (i == pos) {                                        /* this token's K row is not visible in the cache yet */ \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) if (g * 8 < L) KL_[g] = *(const uint4 *) (k16t + e * L + g * 8); \
-            } \
-            v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(KL_, L, nullptr, q16t + e * L)) : hsum8_tinyblas(kq_chain<false>(KL_, L, qt + e * L, nullptr)); \
+        uint4 kk[4]; \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) { \
+            const uint4 kc_ = g < LG ? KL_[g < LG ? g : 0] : make_uint4(0, 0, 0, 0); \
+            kk[g].x = i == pos ? kself[g].x : kc_.x; kk[g].y = i == pos ? kself[g].y : kc_.y; kk[g].z = i == pos ? kself[g].z : kc_.z; kk[g].w = i == pos ? kself[g].w : kc_.w; \
         } \
+        float v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(kk, L, nullptr, q16t + e * L)) : hsum8_tinyblas(kq_chain<false>(kk, L, qt + e * L, nullptr)); \
+        v = (i < n_kv && i <= pos) ? v : -INFINITY;               /* masked (KQ_mask, llama.cpp:14152-14200) */ \
         if (e == 0 && i < n_kv) sc[i] = v; \
     } while (0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) { if (t * 64 < n_kv) BAMD_SCORE_TILE(t * 64, kreg[t]); }
     for (int t0 = 256; t0 < n_kv; t0 += 64) {
         const int i2 = t0 + r_pos;
-        uint4 kl[4];
+        uint4 kl[LG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) kl[g] = (i2 < n_kv && i2 < pos && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i2 * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < LG; ++g) kl[g] = *(const uint4 *) (a.kc + (size_t) i2 * Ekv + hk * hd + e * L + g * 8);    // n_kv <= n_ctx: in bounds
         BAMD_SCORE_TILE(t0, kl);
     }
 #undef BAMD_SCORE_TILE
@@ -263,8 +284,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     TL_STAMP(a.tl, 3);
     // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (A = V^T row, B = p), up to 4 rows d per lane ----
-    const unsigned short vcur[4] = { f2h(a.v[hk * hd + (r_pos < hd ? r_pos : 0)]), f2h(a.v[hk * hd + (r_pos + 64 < hd ? r_pos + 64 : 0)]),
-                                     f2h(a.v[hk * hd + (r_pos + 128 < hd ? r_pos + 128 : 0)]), f2h(a.v[hk * hd + (r_pos + 192 < hd ? r_pos + 192 : 0)]) };
+    unsigned short vcur[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int dd = 0; dd < LG; ++dd) vcur[dd] = f2h(vcf[dd]);       // requested at entry
     float acc4[4] = { 0.f, 0.f, 0.f, 0.f };
     const int pblk = pos & ~63, pe = pos & 7, pl = (pos & 63) >> 3;   // where this token's own V element sits
 #define BAMD_PV_BLOCK(b0_, dd_, VV_) do { \
@@ -283,9 +305,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int t = 0; t < 4; ++t) {                                  // blocks whose V chunks were requested at kernel entry
         if (t * 64 < n_kv) {
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd) if (r_pos + 64 * dd < hd) BAMD_PV_BLOCK(t * 64, dd, vreg[t][dd]);
+            for (int dd = 0; dd < (LG < 2 ? LG : 2); ++dd) BAMD_PV_BLOCK(t * 64, dd, vreg[t][dd]);
 #pragma unroll
-            for (int dd = 2; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {  // hd > 128
+            for (int dd = 2; dd < LG; ++dd) {                      // hd > 128
                 const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + t * 64 + e * 8);
                 BAMD_PV_BLOCK(t * 64, dd, vv);
             }
@@ -293,16 +315,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     for (int b0 = 256; b0 < n_kv; b0 += 64) {
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) if (r_pos + 64 * dd < hd) {
+        for (int dd = 0; dd < LG; ++dd) {
             const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
             BAMD_PV_BLOCK(b0, dd, vv);
         }
     }
 #undef BAMD_PV_BLOCK
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-        const int d = r_pos + 64 * dd;
-        if (d < hd) { const float v = hsum8_tinyblas(acc4[dd]); if (e == 0) a.out[(size_t) h * hd + d] = v; }
+    for (int dd = 0; dd < LG; ++dd) {
+        const float v = hsum8_tinyblas(acc4[dd]);
+        if (e == 0) a.out[(size_t) h * hd + r_pos + 64 * dd] = v;
     }
     TL_STAMP(a.tl, 7);
 }
@@ -450,6 +472,15 @@ __global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
 // ===========================================================================================================
 // launchers
 // ===========================================================================================================
+static void launch_attn_fused(const bamd_attn_args & a, int gq, dim3 grid, size_t lds, hipStream_t s) {
+    switch (a.hd >> 6) {                                       // head_dim 64 / 128 / 192 / 256 (checked by the callers)
+        case 1: hipLaunchKernelGGL((attn_fused_kernel<1>), grid, dim3(512), lds, s, a, gq); break;
+        case 2: hipLaunchKernelGGL((attn_fused_kernel<2>), grid, dim3(512), lds, s, a, gq); break;
+        case 3: hipLaunchKernelGGL((attn_fused_kernel<3>), grid, dim3(512), lds, s, a, gq); break;
+        default: hipLaunchKernelGGL((attn_fused_kernel<4>), grid, dim3(512), lds, s, a, gq); break;
+    }
+}
+
 // attention of a micro-batch of T tokens (a.batch = 1, a.ld_qkv / a.ld_out set): KV store for all tokens, then (head, token) workgroups
 int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
@@ -465,7 +496,7 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     if (gqh == 8)      hipLaunchKernelGGL((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
     else if (gqh == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
     else if (gqh == 2) hipLaunchKernelGGL((attn_batch_kernel<2>), grid, dim3(512), lds_g, s, a, gq);
-    else hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq, T), dim3(512), (size_t) ld * 8, s, a, gq);
+    else launch_attn_fused(a, gq, dim3(a.Hkv * gq, T), (size_t) ld * 8, s);
     return 0;
 }
 
@@ -475,7 +506,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
     if (max_tiles >= 0 && !(ld & 63) && (size_t) ld * 8 <= BAMD_ATTN_LDS_MAX) {
         // the caller knows the sequence is short enough for one workgroup per query head and that ld bounds its padded length
-        hipLaunchKernelGGL(attn_fused_kernel, dim3(a.Hkv * gq), dim3(512), (size_t) ld * 8, s, a, gq);
+        launch_attn_fused(a, gq, dim3(a.Hkv * gq), (size_t) ld * 8, s);
         return 0;
     }
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;
