@@ -28,12 +28,15 @@ def _stale(lib=LIB):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, timing=False):
+def build(force=False, verbose=False, timing=False, variant=None, extra=()):
+    """variant / extra: experiment builds — lib/libbooster_amd_<variant>.so compiled with the extra flags (select with BAMD_LIB)"""
     lib = LIB_TIMING if timing else LIB
+    if variant:
+        lib = os.path.join(HERE, "lib", "libbooster_amd_%s.so" % variant)
     if not force and not _stale(lib):
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "lib", "timing") if timing else os.path.join(HERE, "lib")
+    objdir = os.path.join(HERE, "lib", variant) if variant else os.path.join(HERE, "lib", "timing") if timing else os.path.join(HERE, "lib")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -43,7 +46,7 @@ def build(force=False, verbose=False, timing=False):
             continue
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + (["-DBAMD_TIMING"] if timing else []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-DBAMD_TIMING"] if timing else []) + list(extra) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -58,4 +61,5 @@ def build(force=False, verbose=False, timing=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))
+    _v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, timing="--timing" in sys.argv, variant=_v, extra=[a for a in sys.argv[1:] if a.startswith("-D")]))

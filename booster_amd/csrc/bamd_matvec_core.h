@@ -181,7 +181,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                     const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
                     P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
                     if (!ONEB && r0 + M + m < count) load_rec(ring[s], bbase + (long) (M + m) * rg_step + j * RECB, lane);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1 || s == D - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
