@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,8 @@ static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool kee
                       void * stream_dst = nullptr) {
     if (t->ne.size() != 2) return fail("tensor " + t->name + ": expected 2 dims");
     d.type = t->type; d.K = (int) t->ne[0]; d.nrows = (int) t->ne[1]; d.bytes = t->nbytes;
+    if (d.type != BAMD_F32 && d.type != BAMD_F16 && !bamd_is_kquant(d.type)) return fail("tensor " + t->name + ": type " + std::to_string(d.type) + " not supported (F32, F16, Q4_K, Q5_K, Q6_K)");
+    if (bamd_is_kquant(d.type) && d.K % 256) return fail("tensor " + t->name + ": row length not a multiple of 256");
     if (want_stream) {
         if (!bamd_is_kquant(d.type)) return fail("tensor " + t->name + ": only Q4_K/Q5_K/Q6_K matrices are supported on the matmul path");
         if (d.K % 256) return fail("tensor " + t->name + ": row length not a multiple of 256");
@@ -201,22 +204,28 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     m->n_rot = m->hd; if (g.get_u32("llama.rope.dimension_count", u)) m->n_rot = (int) u;
     if (m->n_rot != m->hd) return fail("llama.rope.dimension_count != n_embd/n_head is not supported");
     g.get_f32("llama.rope.freq_base", m->rope_theta);
-    {   // linear RoPE scaling (llama.cpp:4600-4640): freq_scale = 1/factor; YaRN is out of scope
-        std::string st; float factor = 0.f;
-        if (g.get_str("llama.rope.scaling.type", st) && st != "none" && st != "linear") return fail("rope scaling type \"" + st + "\" not supported");
-        if (g.get_f32("llama.rope.scaling.factor", factor) && factor != 0.f && st == "linear") m->rope_freq_scale = 1.0f / factor;
+    {   // RoPE scaling as llm_load_hparams reads it (llama.cpp:4636-4648): the type defaults to "linear" when the key is absent, the
+        // factor comes from rope.scaling.factor or the legacy rope.scale_linear, freq_scale = 1 / factor; a "none" type never scales
+        // (llama_new_context_with_model, llama.cpp:16682-16684).  YaRN is out of scope: rejected.
+        std::string st = "linear"; float factor = 0.f;
+        g.get_str("llama.rope.scaling.type", st);
+        if (st != "none" && st != "linear") return fail("rope scaling type \"" + st + "\" not supported");
+        if (!g.get_f32("llama.rope.scaling.factor", factor)) g.get_f32("llama.rope.scale_linear", factor);
+        m->rope_freq_scale = (factor == 0.f || st == "none") ? 1.0f : 1.0f / factor;
     }
     if (m->H % m->Hkv) return fail("n_head % n_head_kv != 0");
     const int gq = m->H / m->Hkv;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return fail("GQA ratio must be 1, 2, 4 or 8");
     if (m->hd % 64 || m->hd > 256) return fail("head dim must be 64, 128, 192 or 256");
     if (m->E % 256 || m->F % 256) return fail("n_embd and n_ff must be multiples of 256");
+    if (m->E > 32768 || m->F > 131072) return fail("n_embd / n_ff beyond what the kernels' LDS budgets were sized for");
     if (ll < 0 || ll > m->L) ll = m->L;
     if (lf < 0 || lf > ll) return fail("bad layer range");
     m->layer_first = lf; m->layer_last = ll; m->with_embd = with_embd != 0; m->with_output = with_output != 0;
 
     const GgufTensor * te = g.tensor("token_embd.weight");
     if (!te) return fail("missing token_embd.weight");
+    if (te->ne.size() != 2 || (int) te->ne[0] != m->E) return fail("token_embd.weight: row length != llama.embedding_length");
     m->V = (int) te->ne[1];
     if (const GgufTensor * rf = g.tensor("rope_freqs.weight")) {
         if (rf->type != BAMD_F32 || (int) rf->ne[0] < m->hd / 2) return fail("bad rope_freqs.weight");
@@ -234,6 +243,7 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
             const GgufTensor * to = g.tensor("output.weight");
             if (!to) to = te;                                              // tied embeddings, llama.cpp:6070-6076
             if ((rc = upload_mat(m, to, m->output, false, true, staging, s))) break;
+            if (m->output.K != m->E) { rc = fail("output.weight: row length != llama.embedding_length"); break; }
         }
         m->layers.resize((size_t) (ll - lf));
         for (int il = lf; il < ll && !rc; ++il) {
@@ -260,8 +270,9 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
                 ++mi;
             }
             if (rc) break;
-            if (ly.wq.nrows != m->E || ly.wq.K != m->E || ly.wk.nrows != m->Hkv * m->hd || ly.wv.nrows != m->Hkv * m->hd || ly.wo.nrows != m->E ||
-                ly.wg.nrows != m->F || ly.wu.nrows != m->F || ly.wd.nrows != m->E || ly.wd.K != m->F) { rc = fail("layer " + std::to_string(il) + ": unexpected tensor shapes"); break; }
+            if (ly.wq.nrows != m->E || ly.wq.K != m->E || ly.wk.nrows != m->Hkv * m->hd || ly.wk.K != m->E || ly.wv.nrows != m->Hkv * m->hd || ly.wv.K != m->E ||
+                ly.wo.nrows != m->E || ly.wo.K != m->E || ly.wg.nrows != m->F || ly.wg.K != m->E || ly.wu.nrows != m->F || ly.wu.K != m->E ||
+                ly.wd.nrows != m->E || ly.wd.K != m->F) { rc = fail("layer " + std::to_string(il) + ": unexpected tensor shapes"); break; }
             if (ly.wg.type != ly.wu.type) { rc = fail("ffn_gate and ffn_up must share one quantisation type"); break; }
         }
     } while (0);
@@ -273,7 +284,10 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
 
 extern "C" __attribute__((visibility("default"))) bamd_model * bamd_model_load(const char * path, int device, int layer_first, int layer_last, int with_embd, int with_output) {
     bamd_model * m = new bamd_model();
-    if (model_load_impl(m, path, device, layer_first, layer_last, with_embd, with_output)) { bamd_model_free(m); return nullptr; }
+    int rc = 1;
+    try { rc = model_load_impl(m, path, device, layer_first, layer_last, with_embd, with_output); }
+    catch (const std::exception & e) { g_err = std::string("model load: ") + e.what(); rc = 1; }     // nothing may unwind through the C boundary
+    if (rc) { bamd_model_free(m); return nullptr; }
     return m;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_model_free(bamd_model * m) {
@@ -583,6 +597,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
             if (t == n_tokens - 1) enqueue_lm_head(c, s, nullptr);
         }
     }
+    {   // a launch that the runtime rejected (LDS / grid beyond the device's limits, wrong architecture) leaves no other trace
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { fail(std::string("kernel launch failed: ") + hipGetErrorString(le)); return 1; }
+    }
     c->logits_host_valid = c->logits_readback;
     if (c->logits_readback && hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
     hipError_t e = hipStreamSynchronize(s);
@@ -738,7 +756,12 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
         else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         return 0;
     };
-    if (!g_stage_graph || s == nullptr) return enqueue(s);           // the legacy default stream cannot be captured
+    if (!g_stage_graph || s == nullptr) {                            // the legacy default stream cannot be captured
+        if (enqueue(s)) return 1;
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+        return 0;
+    }
     bamd_context::StageGraph & sg = c->sgraph[want_logits ? 1 : 0][prefill_mode ? 1 : 0];
     const int fused = attn_fused_for(c, pos) ? 1 : 0;
     if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev || sg.fused != fused)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }

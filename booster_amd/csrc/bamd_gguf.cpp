@@ -18,9 +18,10 @@ struct Cursor {
         if (p + sizeof(T) > end) { ok = false; return v; }
         memcpy(&v, p, sizeof(T)); p += sizeof(T); return v;
     }
+    size_t left() const { return (size_t) (end - p); }
     std::string str() {
         uint64_t n = rd<uint64_t>();
-        if (!ok || p + n > end) { ok = false; return std::string(); }
+        if (!ok || n > left()) { ok = false; return std::string(); }
         std::string s((const char *) p, (size_t) n); p += n; return s;
     }
 };
@@ -74,6 +75,9 @@ bool GgufFile::open_one(const std::string & path, std::string & err) {
     version = c.rd<uint32_t>();
     if (version < 2 || version > 3) { err = "unsupported GGUF version"; return false; }
     const uint64_t n_tensors = c.rd<uint64_t>(), n_kv = c.rd<uint64_t>();
+    // a corrupt header must come back as an error, not as a bad_alloc / length_error thrown across the C boundary: every count is
+    // bounded by the bytes that are left (a KV pair takes >= 12 bytes, a tensor entry >= 24, a string >= 8)
+    if (n_kv > c.left() / 12 || n_tensors > c.left() / 24) { err = "corrupt GGUF header (counts exceed the file size)"; return false; }
     for (uint64_t k = 0; k < n_kv && c.ok; ++k) {
         std::string key = c.str();
         GgufValue v; v.type = c.rd<uint32_t>();
@@ -81,11 +85,12 @@ bool GgufFile::open_one(const std::string & path, std::string & err) {
         else if (v.type == T_ARR) {
             v.arr_type = c.rd<uint32_t>(); v.arr_n = c.rd<uint64_t>();
             if (v.arr_type == T_STR) {
+                if (v.arr_n > c.left() / 8) { err = "bad array length in KV " + key; return false; }
                 v.arr_s.reserve((size_t) v.arr_n);
                 for (uint64_t i = 0; i < v.arr_n && c.ok; ++i) v.arr_s.push_back(c.str());
             } else {
                 const size_t sz = scalar_size(v.arr_type);
-                if (!sz || c.p + sz * v.arr_n > c.end) { err = "bad array in KV " + key; return false; }
+                if (!sz || v.arr_n > c.left() / sz) { err = "bad array in KV " + key; return false; }
                 v.arr_data = c.p; c.p += sz * v.arr_n;
             }
         } else if (!read_scalar(c, v.type, v)) { err = "bad KV type for " + key; return false; }
@@ -98,7 +103,11 @@ bool GgufFile::open_one(const std::string & path, std::string & err) {
         t.name = c.str();
         const uint32_t nd = c.rd<uint32_t>();
         if (nd > 4) { err = "bad n_dims"; return false; }
-        for (uint32_t d = 0; d < nd; ++d) t.ne.push_back((int64_t) c.rd<uint64_t>());
+        for (uint32_t d = 0; d < nd; ++d) {
+            const uint64_t n = c.rd<uint64_t>();
+            if (n == 0 || n > (uint64_t) 1 << 40) { err = "tensor " + t.name + ": bad dimension"; return false; }
+            t.ne.push_back((int64_t) n);
+        }
         t.type = (int) c.rd<uint32_t>();
         t.offset = c.rd<uint64_t>();
     }
@@ -107,10 +116,11 @@ bool GgufFile::open_one(const std::string & path, std::string & err) {
     const size_t data_off = (meta + alignment - 1) / alignment * alignment;
     for (size_t i = 0; i < tensors.size(); ++i) {
         auto & t = tensors[i];
-        int64_t rows = 1; for (size_t d = 1; d < t.ne.size(); ++d) rows *= t.ne[d];
+        unsigned __int128 rows = 1; for (size_t d = 1; d < t.ne.size(); ++d) rows *= (unsigned __int128) t.ne[d];
         const bool known = t.type == BAMD_F32 || t.type == BAMD_F16 || bamd_is_kquant(t.type);
-        t.nbytes = known ? bamd_row_bytes(t.type, t.ne.empty() ? 0 : t.ne[0]) * (size_t) rows : 0;
-        if (data_off + t.offset + t.nbytes > size_) { err = "tensor " + t.name + " out of file bounds"; return false; }
+        const unsigned __int128 nbytes = known ? (unsigned __int128) bamd_row_bytes(t.type, t.ne.empty() ? 0 : t.ne[0]) * rows : 0;
+        if (data_off > size_ || t.offset > size_ - data_off || nbytes > (unsigned __int128) (size_ - data_off - t.offset)) { err = "tensor " + t.name + " out of file bounds"; return false; }
+        t.nbytes = (size_t) nbytes;
         t.data = map_ + data_off + t.offset;
         index_[t.name] = i;
     }

@@ -1,11 +1,13 @@
-// bamd_vocab.cpp — see bamd_vocab.h.  Written from the behaviour of the reference's tokenizer, not from its code.
+// bamd_vocab.cpp — see bamd_vocab.h.  The tokenizer side of the bridge (llama_tokenize / llama_token_to_piece of the reference,
+// cpp/src/llama-vocab.cpp), reproduced on its own data structures: flat piece tables + one candidate heap for the merges
+// (join_greedily), hand-written splitters for the two pre-tokeniser regexes, code-point classes from the reference's own table
+// (bamd_unicode_tables.h <- tests/golden/unicode_classes.json).  Pinned token for token by tests/test_tokenizer.py.
 #include "bamd_vocab.h"
 #include "bamd_gguf.h"
 #include "bamd_unicode_tables.h"
 
 #include <string.h>
 #include <algorithm>
-#include <queue>
 
 // ---- UTF-8 helpers --------------------------------------------------------------------------------------------------
 static size_t utf8_len(unsigned char c) {              // unicode_len_utf8 (unicode.cpp): by the high nibble
@@ -84,8 +86,16 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
                 bpe_ranks[std::make_pair(w.substr(0, p), w.substr(p + 1))] = (int) i;
             }
         }
+        // pre-tokeniser (llm_load_vocab, llama.cpp:5375-5472): the llama-3 regex and the GPT-2 regex have hand-written splitters here;
+        // every other value — including a missing key or "default", whose four-regex chain is not implemented — FAILS the load
+        // instead of silently producing a different token stream
         std::string pre;
-        if (g.get_str("tokenizer.ggml.pre", pre) && (pre == "llama3" || pre == "llama-v3" || pre == "llama-bpe")) { pre_llama3 = true; ignore_merges = true; }
+        g.get_str("tokenizer.ggml.pre", pre);
+        if (pre == "llama3" || pre == "llama-v3" || pre == "llama-bpe") { pre_llama3 = true; ignore_merges = true; add_bos = true; }
+        else if (pre == "dbrx" || pre == "smaug-bpe" || pre == "chatglm-bpe") pre_llama3 = true;              // same regex, no flags
+        else if (pre == "gpt-2" || pre == "phi-2" || pre == "jina-es" || pre == "jina-de" || pre == "jina-v2-es" || pre == "jina-v2-de" ||
+                 pre == "jina-v2-code" || pre == "mpt" || pre == "olmo" || pre == "jais") pre_llama3 = false;
+        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 and GPT-2 family pre-tokenisers only)"; return false; }
     }
     uint32_t u;
     if (g.get_u32("tokenizer.ggml.bos_token_id", u)) bos = (int) u;
@@ -129,67 +139,109 @@ const std::string & BamdVocab::token_to_piece(int id) const {
     return id >= 0 && (size_t) id < piece.size() ? piece[(size_t) id] : empty;
 }
 
-// ---- SPM (llm_tokenizer_spm) ------------------------------------------------------------------------------------------
+// ---- greedy pair merging, shared by the SentencePiece and the byte-level BPE tokenizers ------------------------------------------
+// Behaviour to reproduce (llm_tokenizer_spm / llm_tokenizer_bpe, llama-vocab.cpp:190-300, :488-590): start from the UTF-8 characters
+// of the text; repeatedly join the adjacent pair with the best key — SPM: the highest score among pairs whose concatenation is a
+// token; BPE: the lowest merge rank — ties going to the leftmost pair; a join creates up to two new candidate pairs with its
+// neighbours.  Own data structures: the pieces are runs of characters described by three flat arrays (no linked list of symbols),
+// candidates sit in one binary min-heap keyed by (key, position) and carry the extents they were made for, so a candidate that
+// has been overtaken by another join is recognised by comparing extents.
 namespace {
-struct Sym { int prev, next; const char * text; size_t n; };
+struct PieceTable {
+    std::vector<uint32_t> off;       // off[c] .. off[c+1]: the bytes of character c
+    std::vector<int32_t> last;       // last[h]: last character of the piece that starts at character h   (valid while starts[h])
+    std::vector<int32_t> first;      // first[t]: first character of the piece that ends at character t   (valid at piece ends)
+    std::vector<uint8_t> starts;     // starts[c]: a piece begins at character c
+    int n = 0;
+    void init(const char * s, size_t len, size_t (*char_len)(unsigned char)) {
+        off.clear(); size_t o = 0;
+        while (o < len) { off.push_back((uint32_t) o); o += std::min(len - o, char_len((unsigned char) s[o])); }
+        n = (int) off.size(); off.push_back((uint32_t) len);
+        last.resize((size_t) n); first.resize((size_t) n); starts.assign((size_t) n, 1);
+        for (int c = 0; c < n; ++c) { last[(size_t) c] = c; first[(size_t) c] = c; }
+    }
+    void whole(size_t len) {                                    // one piece covering everything (BPE ignore_merges)
+        off.assign({ 0u, (uint32_t) len }); n = 1; last.assign(1, 0); first.assign(1, 0); starts.assign(1, 1);
+    }
+    int before(int h) const { return h == 0 ? -1 : first[(size_t) h - 1]; }
+    int after(int h) const { const int r = last[(size_t) h] + 1; return r < n ? r : -1; }
+    uint32_t lo(int h) const { return off[(size_t) h]; }
+    uint32_t hi(int h) const { return off[(size_t) last[(size_t) h] + 1]; }
+    void join(int l, int r) { const int t = last[(size_t) r]; last[(size_t) l] = t; first[(size_t) t] = l; starts[(size_t) r] = 0; }
+};
 
-struct SpmBigram { int left, right; float score; size_t size; };
-struct SpmCmp { bool operator()(const SpmBigram & l, const SpmBigram & r) const { return (l.score < r.score) || (l.score == r.score && l.left > r.left); } };
-
-struct SpmSession {
-    const BamdVocab & v; std::vector<Sym> syms; std::priority_queue<SpmBigram, std::vector<SpmBigram>, SpmCmp> q;
-    std::map<std::string, std::pair<int, int>> rev;
-    explicit SpmSession(const BamdVocab & vv) : v(vv) {}
-    void try_add(int l, int r) {
-        if (l == -1 || r == -1) return;
-        const std::string t(syms[(size_t) l].text, syms[(size_t) l].n + syms[(size_t) r].n);
-        auto it = v.token_to_id.find(t);
-        if (it == v.token_to_id.end() || (size_t) it->second >= v.text.size()) return;
-        q.push(SpmBigram{ l, r, v.score[(size_t) it->second], t.size() });
-        rev[t] = std::make_pair(l, r);
+struct Cand { double key; int32_t l, r, l_last, r_last; };      // a candidate join of the pieces starting at l and r, as they were when it was made
+struct CandHeap {                                                // binary min-heap on (key, l)
+    std::vector<Cand> a;
+    static bool less(const Cand & x, const Cand & y) { return x.key < y.key || (x.key == y.key && x.l < y.l); }
+    bool empty() const { return a.empty(); }
+    void push(const Cand & c) {
+        a.push_back(c); size_t i = a.size() - 1;
+        while (i > 0) { const size_t p = (i - 1) / 2; if (!less(a[i], a[p])) break; std::swap(a[i], a[p]); i = p; }
     }
-    int byte_token(unsigned char ch) const {              // llama_byte_to_token_impl: "<0xXX>", else the raw byte as a token
-        static const char * hex = "0123456789ABCDEF";
-        const char buf[7] = { '<', '0', 'x', hex[ch >> 4], hex[ch & 15], '>', 0 };
-        auto it = v.token_to_id.find(buf);
-        if (it != v.token_to_id.end()) return it->second;
-        auto it2 = v.token_to_id.find(std::string(1, (char) ch));
-        return it2 != v.token_to_id.end() ? it2->second : (v.unk >= 0 ? v.unk : 0);
-    }
-    void resegment(const Sym & s, std::vector<int> & out) {
-        const std::string t(s.text, s.n);
-        auto it = v.token_to_id.find(t);
-        if (it != v.token_to_id.end()) { out.push_back(it->second); return; }
-        auto p = rev.find(t);
-        if (p == rev.end()) { for (size_t j = 0; j < s.n; ++j) out.push_back(byte_token((unsigned char) s.text[j])); return; }
-        resegment(syms[(size_t) p->second.first], out); resegment(syms[(size_t) p->second.second], out);
-    }
-    void tokenize(const std::string & text, std::vector<int> & out) {
-        int index = 0; size_t offs = 0;
-        while (offs < text.size()) {
-            Sym s; const size_t len = utf8_len((unsigned char) text[offs]);
-            s.text = text.c_str() + offs; s.n = std::min(len, text.size() - offs); offs += s.n;
-            s.prev = index - 1; s.next = offs == text.size() ? -1 : index + 1; ++index;
-            syms.push_back(s);
+    Cand pop() {
+        const Cand top = a[0]; a[0] = a.back(); a.pop_back();
+        size_t i = 0; const size_t m = a.size();
+        for (;;) {
+            size_t b = i; const size_t l = 2 * i + 1, r = l + 1;
+            if (l < m && less(a[l], a[b])) b = l;
+            if (r < m && less(a[r], a[b])) b = r;
+            if (b == i) break;
+            std::swap(a[i], a[b]); i = b;
         }
-        for (size_t i = 1; i < syms.size(); ++i) try_add((int) i - 1, (int) i);
-        while (!q.empty()) {
-            const SpmBigram b = q.top(); q.pop();
-            Sym & L = syms[(size_t) b.left]; Sym & R = syms[(size_t) b.right];
-            if (L.n == 0 || R.n == 0 || L.n + R.n != b.size) continue;
-            L.n += R.n; R.n = 0; L.next = R.next;
-            if (R.next >= 0) syms[(size_t) R.next].prev = b.left;
-            try_add(L.prev, b.left); try_add(b.left, L.next);
-        }
-        if (syms.empty()) return;
-        for (int i = 0; i != -1; i = syms[(size_t) i].next) resegment(syms[(size_t) i], out);
+        return top;
     }
 };
 
-// ---- BPE (llm_tokenizer_bpe) --------------------------------------------------------------------------------------------
-struct BpeBigram { int left, right; std::string text; int rank; size_t size; };
-struct BpeCmp { bool operator()(const BpeBigram & l, const BpeBigram & r) const { return l.rank > r.rank || (l.rank == r.rank && l.left > r.left); } };
+// KEY(l, r, &key) -> is the pair of pieces (l, r) joinable, and with which key (smaller joins first)
+template <typename KEY>
+static void join_greedily(PieceTable & pt, KEY && key_of) {
+    CandHeap heap;
+    auto offer = [&](int l, int r) {
+        if (l < 0 || r < 0) return;
+        double k;
+        if (key_of(l, r, k)) heap.push(Cand{ k, l, r, pt.last[(size_t) l], pt.last[(size_t) r] });
+    };
+    for (int c = 0; c + 1 < pt.n; ++c) offer(c, c + 1);
+    while (!heap.empty()) {
+        const Cand c = heap.pop();
+        // still the two pieces this candidate was made for?  (either may have been swallowed, or have grown, since)
+        if (!pt.starts[(size_t) c.l] || !pt.starts[(size_t) c.r] || pt.last[(size_t) c.l] != c.l_last || pt.last[(size_t) c.r] != c.r_last) continue;
+        pt.join(c.l, c.r);
+        offer(pt.before(c.l), c.l);
+        offer(c.l, pt.after(c.l));
+    }
+}
 
+// ---- SentencePiece (llama-vocab.cpp:190-300) ---------------------------------------------------------------------------------
+static int spm_byte_token(const BamdVocab & v, unsigned char ch) {      // llama_byte_to_token_impl: "<0xXX>", else the raw byte as a token
+    static const char * hex = "0123456789ABCDEF";
+    const char buf[7] = { '<', '0', 'x', hex[ch >> 4], hex[ch & 15], '>', 0 };
+    auto it = v.token_to_id.find(buf);
+    if (it != v.token_to_id.end()) return it->second;
+    auto it2 = v.token_to_id.find(std::string(1, (char) ch));
+    return it2 != v.token_to_id.end() ? it2->second : (v.unk >= 0 ? v.unk : 0);
+}
+static void spm_tokenize(const BamdVocab & v, const std::string & text, std::vector<int> & out) {
+    if (text.empty()) return;
+    PieceTable pt; pt.init(text.data(), text.size(), utf8_len);
+    std::string tmp;
+    join_greedily(pt, [&](int l, int r, double & key) {
+        tmp.assign(text, pt.lo(l), pt.hi(r) - pt.lo(l));
+        auto it = v.token_to_id.find(tmp);
+        if (it == v.token_to_id.end() || (size_t) it->second >= v.text.size()) return false;
+        key = -(double) v.score[(size_t) it->second];            // highest score first (exact: float -> double -> negation)
+        return true;
+    });
+    for (int h = 0; h != -1; h = pt.after(h)) {                  // pieces left to right; a piece that is no token falls back to its bytes
+        tmp.assign(text, pt.lo(h), pt.hi(h) - pt.lo(h));
+        auto it = v.token_to_id.find(tmp);
+        if (it != v.token_to_id.end()) out.push_back(it->second);
+        else for (unsigned char ch : tmp) out.push_back(spm_byte_token(v, ch));
+    }
+}
+
+// ---- byte-level BPE (llama-vocab.cpp:488-590) ----------------------------------------------------------------------------------
 // split of the llama-3 pre-tokeniser regex (llama-vocab.cpp:345-349):
 // (?:'[sS]|'[tT]|'[rR][eE]|'[vV][eE]|'[mM]|'[lL][lL]|'[dD])|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
 static std::vector<std::pair<size_t, size_t>> split_llama3(const std::vector<uint32_t> & c) {
@@ -256,64 +308,40 @@ static std::vector<std::pair<size_t, size_t>> split_gpt2(const std::vector<uint3
     return out;
 }
 
-struct BpeSession {
-    const BamdVocab & v; std::vector<Sym> syms, fin;
-    std::priority_queue<BpeBigram, std::vector<BpeBigram>, BpeCmp> q;
-    explicit BpeSession(const BamdVocab & vv) : v(vv) {}
-    void add(int l, int r) {
-        if (l == -1 || r == -1) return;
-        const std::string a(syms[(size_t) l].text, syms[(size_t) l].n), b(syms[(size_t) r].text, syms[(size_t) r].n);
-        auto it = v.bpe_ranks.find(std::make_pair(a, b));
-        if (it == v.bpe_ranks.end() || it->second < 0) return;
-        q.push(BpeBigram{ l, r, a + b, it->second, a.size() + b.size() });
-    }
-    void tokenize(const std::string & text, std::vector<int> & out) {
-        uint32_t b2u[256]; std::unordered_map<uint32_t, uint8_t> u2b; byte_maps(b2u, u2b);
-        const std::vector<uint32_t> cps = utf8_to_cpts(text);
-        const auto spans = v.pre_llama3 ? split_llama3(cps) : split_gpt2(cps);
-        std::vector<std::string> words;
-        for (auto & sp : spans) {                                             // word -> UTF-8 -> byte-level unicode text
-            std::string raw; for (size_t k = sp.first; k < sp.second; ++k) append_utf8(raw, cps[k]);
-            std::string enc; for (unsigned char ch : raw) append_utf8(enc, b2u[ch]);
-            words.push_back(enc);
+static void bpe_tokenize(const BamdVocab & v, const std::string & text, std::vector<int> & out) {
+    uint32_t b2u[256]; std::unordered_map<uint32_t, uint8_t> u2b; byte_maps(b2u, u2b);
+    const std::vector<uint32_t> cps = utf8_to_cpts(text);
+    const auto spans = v.pre_llama3 ? split_llama3(cps) : split_gpt2(cps);
+    std::string raw, word, lt, rt;
+    PieceTable pt;
+    for (const auto & sp : spans) {
+        raw.clear(); for (size_t k = sp.first; k < sp.second; ++k) append_utf8(raw, cps[k]);                   // the word as UTF-8 ...
+        word.clear(); for (unsigned char ch : raw) append_utf8(word, b2u[ch]);                                 // ... then as byte-level unicode text
+        if (v.ignore_merges && v.token_to_id.find(word) != v.token_to_id.end()) pt.whole(word.size());       // llama-3: a word that is a token stays whole
+        else {
+            pt.init(word.data(), word.size(), utf8_len);
+            join_greedily(pt, [&](int l, int r, double & key) {
+                lt.assign(word, pt.lo(l), pt.hi(l) - pt.lo(l)); rt.assign(word, pt.lo(r), pt.hi(r) - pt.lo(r));
+                auto it = v.bpe_ranks.find(std::make_pair(lt, rt));
+                if (it == v.bpe_ranks.end() || it->second < 0) return false;
+                key = (double) it->second;                       // lowest merge rank first
+                return true;
+            });
         }
-        int final_prev = -1;
-        for (const std::string & word : words) {
-            q = decltype(q)(); syms.clear();
-            int index = 0; size_t offset = 0;
-            if (v.ignore_merges && v.token_to_id.find(word) != v.token_to_id.end()) { syms.push_back(Sym{ -1, -1, word.c_str(), word.size() }); offset = word.size(); }
-            while (offset < word.size()) {
-                Sym s; const size_t cl = std::min(word.size() - offset, utf8_len((unsigned char) word[offset]));
-                s.text = word.c_str() + offset; s.n = cl; offset += cl;
-                s.prev = index - 1; s.next = offset == word.size() ? -1 : index + 1; ++index;
-                syms.push_back(s);
+        if (pt.n == 0) continue;
+        for (int h = 0; h != -1; h = pt.after(h)) {
+            lt.assign(word, pt.lo(h), pt.hi(h) - pt.lo(h));
+            auto it = v.token_to_id.find(lt);
+            if (it != v.token_to_id.end()) { out.push_back(it->second); continue; }
+            for (size_t k = 0; k < lt.size(); ) {                // unknown piece: character by character, dropping what has no token
+                const size_t cl = std::min(lt.size() - k, utf8_len((unsigned char) lt[k]));
+                auto bt = v.token_to_id.find(lt.substr(k, cl));
+                if (bt != v.token_to_id.end()) out.push_back(bt->second);
+                k += cl;
             }
-            for (size_t i = 1; i < syms.size(); ++i) add((int) i - 1, (int) i);
-            while (!q.empty()) {
-                const BpeBigram b = q.top(); q.pop();
-                Sym & L = syms[(size_t) b.left]; Sym & R = syms[(size_t) b.right];
-                if (L.n == 0 || R.n == 0) continue;
-                if (std::string(L.text, L.n) + std::string(R.text, R.n) != b.text) continue;
-                L.n += R.n; R.n = 0; L.next = R.next;
-                if (R.next >= 0) syms[(size_t) R.next].prev = b.left;
-                add(L.prev, b.left); add(b.left, L.next);
-            }
-            for (const Sym & s : syms) {
-                if (s.n == 0) continue;
-                const std::string str(s.text, s.n);
-                auto it = v.token_to_id.find(str);
-                if (it != v.token_to_id.end()) out.push_back(it->second);
-                else for (size_t k = 0; k < str.size(); ) {                   // unknown piece: byte by byte (llama-vocab.cpp:575-590)
-                    const size_t cl = std::min(str.size() - k, utf8_len((unsigned char) str[k]));
-                    auto bt = v.token_to_id.find(str.substr(k, cl));
-                    if (bt != v.token_to_id.end()) out.push_back(bt->second);
-                    k += cl;
-                }
-            }
-            (void) final_prev;
         }
     }
-};
+}
 }  // namespace
 
 // ---- llama_tokenize_internal ------------------------------------------------------------------------------------------
@@ -351,7 +379,7 @@ std::vector<int> BamdVocab::tokenize(const std::string & raw, bool add_special, 
             std::string t = raw.substr(f.off, f.len);
             if (add_space_prefix && prev_special) t = " " + t;
             size_t p = 0; while ((p = t.find(' ', p)) != std::string::npos) { t.replace(p, 1, "\xe2\x96\x81"); p += 3; }   // llama_escape_whitespace
-            SpmSession s(*this); s.tokenize(t, out);
+            spm_tokenize(*this, t, out);
             prev_special = false;
         }
         if (add_special && add_eos && eos != -1) out.push_back(eos);
@@ -359,7 +387,7 @@ std::vector<int> BamdVocab::tokenize(const std::string & raw, bool add_special, 
         if (add_special && add_bos && bos != -1) out.push_back(bos);
         for (const Frag & f : frags) {
             if (f.is_token) { out.push_back(f.token); continue; }
-            BpeSession s(*this); s.tokenize(raw.substr(f.off, f.len), out);
+            bpe_tokenize(*this, raw.substr(f.off, f.len), out);
         }
         if (add_special && add_eos && eos != -1) out.push_back(eos);
     }
