@@ -49,14 +49,31 @@ struct Pod {
     double t_p_eval_ms = 0, t_eval_ms = 0; int64_t n_p_eval = 0, n_eval = 0;
 };
 
-struct Job {                                     // status() hands out c_str() of the newest version; older versions are retired late
-    std::vector<std::unique_ptr<std::string>> versions;
+// The text of a job (prompt echo + generated pieces), append-only.  status() hands out a pointer into the current buffer; a poller may
+// hold it for as long as the job exists (Go copies it at once, but the contract must not depend on that): a buffer is never freed or
+// moved — when the text outgrows it, a buffer of twice the capacity takes over and the old one stays behind (retired memory <= the
+// final text).  Appending inside a buffer keeps every reader's view NUL-terminated: the new terminator is written first, then the
+// piece from its last byte to its first, which overwrites the old terminator last.
+struct Job {
+    std::vector<std::unique_ptr<char[]>> bufs;
+    char * cur_buf = nullptr; size_t cap = 0, len = 0;
     int64_t prompt_eval = 0, timing = 0, prompt_tokens = 0; uint32_t seed = 0;
-    const std::string & cur() { if (versions.empty()) versions.emplace_back(new std::string()); return *versions.back(); }
+    const char * c_str() { if (!cur_buf) grow(64); return cur_buf; }
+    void grow(size_t need) {
+        size_t ncap = cap ? cap : 64; while (ncap < need) ncap *= 2;
+        std::unique_ptr<char[]> nb(new char[ncap]);
+        if (cur_buf) memcpy(nb.get(), cur_buf, len);
+        nb[len] = 0;
+        cur_buf = nb.get(); cap = ncap; bufs.push_back(std::move(nb));
+    }
     void append(const std::string & piece) {
-        std::unique_ptr<std::string> n(new std::string(cur())); n->append(piece);
-        versions.push_back(std::move(n));
-        if (versions.size() > 16) versions.erase(versions.begin());
+        if (piece.empty()) return;
+        if (!cur_buf || len + piece.size() + 1 > cap) grow(len + piece.size() + 1);
+        volatile char * b = cur_buf;
+        b[len + piece.size()] = 0;
+        for (size_t i = piece.size(); i-- > 0; ) b[len + i] = piece[i];
+        std::atomic_thread_fence(std::memory_order_release);
+        len += piece.size();
     }
 };
 
@@ -507,7 +524,7 @@ BAMD_API void stopInference(int idx) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (idx >= 0 && idx < 8 && g_pods[idx]) g_pods[idx]->stop.store(true);
 }
-BAMD_API const char * status(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].cur().c_str(); }
+BAMD_API const char * status(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].c_str(); }
 BAMD_API int64_t promptEval(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_eval; }
 BAMD_API int64_t getPromptTokenCount(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_tokens; }
 BAMD_API int64_t timing(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].timing; }

@@ -36,8 +36,10 @@ int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID, char * 
 
 /* cpp/bridge.cpp:802-804 */
 void stopInference(int idx);
-/* cpp/bridge.cpp:662-667, :806-809: prompt text + generated text so far.  Borrowed pointer, valid until the job's text
- * grows past its current capacity twice more (retired buffers are kept; Go copies it immediately with C.GoString). */
+/* cpp/bridge.cpp:662-667, :806-809: prompt text + generated text so far.  Borrowed pointer, NUL-terminated at every instant and
+ * valid for the lifetime of the process: the job's text lives in append-only buffers that are never freed or moved (a full buffer
+ * is succeeded by one of twice the capacity; a pointer into the old one keeps reading the text as it was).  Go copies it at once
+ * with C.GoString, the reference's own buffer (a std::string c_str()) is racy. */
 const char * status(char * jobID);
 /* cpp/bridge.cpp:669-674, :811-814: integer-truncated ms per prompt token (t_p_eval_ms / n_p_eval) */
 int64_t promptEval(char * jobID);

@@ -157,3 +157,45 @@ def test_device_sampler_fallbacks(lib, bamd, tmp_path):
         assert res[0][0] == res[1][0] >= 0, "case %d" % case
         assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32)), "case %d: logits after the penalties" % case
     assert counts[1] >= 3 and counts[0] >= 3            # the crowded cases went through the host path, the others stayed on the device
+
+
+def test_reference_abi_transcript(lib, bamd, tmp_path):
+    """the nine cgo symbols replayed against the transcript recorded from the GENUINE reference bridge
+    (tests/golden/abi_transcript.json <- tests/golden/gen_abi_transcript.py: cpp/bridge.cpp + cpp/janus.cpp compiled in place, CPU
+    path): every doInference return value (n_p_eval + n_eval, 0 for a prompt beyond n_ctx - 4), every status() text byte for byte
+    (prompt echo + generated pieces; a reused job id; a job that never ran), every getPromptTokenCount, on two pods.  The model is
+    the same deterministic synthetic GGUF; here it runs on the GPU (gpu1 = 100)."""
+    import json
+    import os
+    t = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "abi_transcript.json")))
+    vocab = gguf.synthetic_janus_vocab(t["n_vocab"])
+    path = str(tmp_path / "abi.gguf")
+    gguf.write_synthetic_llama(path, V=len(vocab["tokens"]), vocab=vocab, **t["model"])
+    ctxs = {}
+    pod_of = {0: 5, 1: 7}                               # the other tests of this module use pods 0..4 and 6
+    for line, want in zip(t["script"], t["results"]):
+        p = line.split()
+        op = p[0]
+        if op == "ctx":
+            idx, n_ctx, n_predict, hi, lo = int(p[1]), int(p[2]), int(p[3]), float(p[4]), float(p[5])
+            ctxs[idx] = lib.initContext(*ctx_args(pod_of[idx], path, (100, 0, 0, 0), n_ctx, n_predict, hi, lo))
+            assert bool(ctxs[idx]) == bool(want["ok"]), line
+        elif op == "init":
+            lib.init(b"", b"")
+        elif op == "infer":
+            idx = int(p[1]); pod = pod_of[idx]
+            got = lib.doInference(pod, ctxs[idx], ("abi-" + p[2]).encode(), b"sess", bytes.fromhex(p[3]))
+            assert got == want["ret"], "%s: doInference returned %d, the reference %d" % (line[:40], got, want["ret"])
+        elif op == "status":
+            got = lib.status(("abi-" + p[1]).encode())
+            assert got == bytes.fromhex(want["hex"]), "%s: status() differs\n ours %r\n ref  %r" % (line, got, bytes.fromhex(want["hex"]))
+        elif op == "count":
+            assert lib.getPromptTokenCount(("abi-" + p[1]).encode()) == want["ret"], line
+        elif op == "stop":
+            lib.stopInference(pod_of[int(p[1])])
+        elif op == "seed":
+            assert (lib.getSeed(("abi-" + p[1]).encode()) != 0) == bool(want["nonzero"])
+        elif op == "evalms":
+            assert (lib.promptEval(("abi-" + p[1]).encode()) >= 0) == bool(want["nonneg"])
+        elif op == "genms":
+            assert (lib.timing(("abi-" + p[1]).encode()) >= 0) == bool(want["nonneg"])
