@@ -31,7 +31,12 @@ enum { LANG_ZERO = 0, LANG_EN = 2, SPACE_EN = 20, LANG_RU = 3, SPACE_RU = 30, LA
 
 struct JanusParams { int32_t janus = 1, depth = 200; float scale = 0.96f, hi = 0.99f, lo = 0.96f; };
 
-struct Stage { bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in = nullptr; };
+// one layer-split stage: its slice of the model on one device, the context's own (non-blocking) stream as the stage stream, the
+// hand-off buffer the previous stage writes over xGMI, and the event that orders the neighbours behind this stage's work
+struct Stage {
+    bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in = nullptr; hipEvent_t done = nullptr;
+    void * stream() const { return bamd_context_stream(ctx); }
+};
 
 struct Pod {
     std::vector<Stage> stages;
@@ -292,7 +297,7 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
     if (!host_path) {
         bamd_shortlist_head head;
         std::vector<int32_t> ids((size_t) BAMD_SHORTLIST_CAP); std::vector<float> vals((size_t) BAMD_SHORTLIST_CAP);
-        void * stream = p.stages.size() == 1 ? bamd_context_stream(st.ctx) : nullptr;
+        void * stream = st.stream();
         if (bamd_logits_shortlist(st.ctx, pen.data(), (int) pen.size(), ru_context ? 1 : 0, &head, ids.data(), vals.data(), stream)) return -1;
         host_path = head.nan || !(head.top_logit > 0.0f) || head.ntop != 1 || head.count < 1 || head.count > BAMD_SHORTLIST_CAP;
         if (!host_path) {
@@ -302,12 +307,12 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
             for (size_t i = 1; i < cand.size() && !host_path; i++) host_path = !(cand[i].logit < cand[i - 1].logit);
         }
         if (host_path) {                          // the device logits already carry the penalties: shortlist them on the host
-            const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, nullptr);
+            const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, st.stream());
             if (!lg) return -1;
             janus_shortlist(lg, V, [&](int topToken) { return janus_cutoff(p, topToken); }, true, cand);
         }
     } else {                                      // more distinct penalised tokens than the device list holds: the host sampler
-        const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, nullptr);
+        const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, st.stream());
         if (!lg) return -1;
         memcpy(p.logits.data(), lg, V * 4);
         p.n_sample_host++;
@@ -321,16 +326,20 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
 // llm_load_tensors (llama.cpp:5932-5969) with the bridge's settings (bridge.cpp:745-750: n_gpu_layers = gpu1+..+gpu4, tensor_split = gpuN):
 // only the first `device_count` entries of the split count; if those are all zero the reference splits by free device memory (equal
 // here: identical GPUs); layer i lives on upper_bound(cumulative normalised splits, i / act), the output layer with fraction (act-1)/act.
-bool plan_stages(int n_layer, const int gpu[4], int device_count, std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
-    const int n_gpu_layers = gpu[0] + gpu[1] + gpu[2] + gpu[3];
-    if (n_gpu_layers <= 0) { err = "gpu1..gpu4 are all zero: this build has no CPU path"; return false; }
+// BAMD_MAX_GPUS = 8: the nine symbols carry four weights (gpu1..gpu4, cpp/bridge.cpp:745-750 -> tensor_split[0..3]); the environment
+// variable BOOSTER_GPUS="w0,w1,...,w7"  replaces them with up to eight — same rule, more devices.
+#define BAMD_MAX_GPUS 8
+bool plan_stages(int n_layer, const int * gpu, int n_gpu, int device_count, std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
+    int n_gpu_layers = 0;
+    for (int i = 0; i < n_gpu; ++i) n_gpu_layers += gpu[i];
+    if (n_gpu_layers <= 0) { err = "the gpu weights are all zero: this build has no CPU path"; return false; }
     if (n_gpu_layers <= n_layer) { err = "sum(gpuN) must exceed the layer count (partial CPU offload is not supported: no CPU path)"; return false; }
-    const int dc = std::min(device_count, 4);
+    const int dc = std::min(device_count, n_gpu);
     if (dc < 1) { err = "no HIP device"; return false; }
     const int act = std::min(n_gpu_layers, n_layer + 1);
     bool all_zero = true;
     for (int i = 0; i < dc; ++i) all_zero = all_zero && gpu[i] == 0;
-    float splits[4], sum = 0.f;
+    float splits[BAMD_MAX_GPUS], sum = 0.f;
     for (int i = 0; i < dc; ++i) { sum += all_zero ? 1.0f : (float) gpu[i]; splits[i] = sum; }
     for (int i = 0; i < dc; ++i) splits[i] /= sum;
     auto dev_of = [&](int i) { const float f = (float) i / (float) act; int d = 0; while (d < dc - 1 && !(f < splits[d])) ++d; return d; };   // std::upper_bound
@@ -344,6 +353,21 @@ bool plan_stages(int n_layer, const int gpu[4], int device_count, std::vector<st
     if (dout != out.back().first) out.push_back({ dout, { n_layer, n_layer } });
     return true;
 }
+// gpu1..gpu4, or BOOSTER_GPUS (comma-separated non-negative integers, up to eight); returns the number of weights
+int gpu_weights(int gpu1, int gpu2, int gpu3, int gpu4, int * w) {
+    w[0] = gpu1; w[1] = gpu2; w[2] = gpu3; w[3] = gpu4;
+    const char * e = getenv("BOOSTER_GPUS");
+    if (!e || !*e) return 4;
+    int n = 0;
+    while (*e && n < BAMD_MAX_GPUS) {
+        char * end; const long v = strtol(e, &end, 10);
+        if (end == e) break;
+        w[n++] = (int) std::max(0l, v);
+        e = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    return n > 0 ? n : 4;
+}
 
 int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // llama_decode for one micro-batch (<= 512 tokens)
     const auto t0 = std::chrono::steady_clock::now();
@@ -353,15 +377,30 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
     } else {
         // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
         // and shapes without batched kernels, step token by token
+        // Stream-ordered hand-off, no host synchronisation per hop: stage s works on its own stream, behind the event of stage s-1 (whose
+        // work ends with the peer write of the hidden state into this stage's hand-off buffer) and behind the previous event of stage
+        // s+1 (which must be done with ITS hand-off buffer before this stage overwrites it).  A single decoded token therefore crosses
+        // the devices as one chain of device-side dependencies — each stage replaying its captured graph — and the host waits once, at
+        // the end (llama_decode's own synchronisation point).
+        auto ordered = [&](size_t s) -> int {
+            Stage & st = p.stages[s];
+            if (hipSetDevice(st.device) != hipSuccess) return 1;
+            if (s > 0 && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s - 1].done, 0) != hipSuccess) return 1;
+            if (s + 1 < p.stages.size() && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s + 1].done, 0) != hipSuccess) return 1;   // never recorded yet: no-op
+            return 0;
+        };
+        auto stamp = [&](size_t s) -> int { return hipEventRecord(p.stages[s].done, (hipStream_t) p.stages[s].stream()) != hipSuccess; };
+        // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
+        // and shapes without batched kernels, step token by token
         bool batched = n > 1 && n <= 512;
         for (size_t s = 0; s < p.stages.size() && batched; ++s) {
             Stage & st = p.stages[s];
             const bool last = s + 1 == p.stages.size();
             void * hout = last ? nullptr : p.stages[s + 1].hidden_in;
-            const int rc = bamd_stage_prefill(st.ctx, s == 0 ? tokens : nullptr, n, n_past, st.hidden_in, hout, last ? 1 : 0, nullptr);
+            if (ordered(s)) return 1;
+            const int rc = bamd_stage_prefill(st.ctx, s == 0 ? tokens : nullptr, n, n_past, st.hidden_in, hout, last ? 1 : 0, st.stream());
             if (rc == 2 && s == 0) { batched = false; break; }            // no batched kernels for this model: per-token path below
-            if (rc) return 1;
-            if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }
+            if (rc || stamp(s)) return 1;
         }
         const int prefill = n > 1;
         for (int t = 0; t < n && !batched; ++t) {
@@ -369,17 +408,19 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
                 Stage & st = p.stages[s];
                 const bool last = s + 1 == p.stages.size();
                 void * hout = last ? nullptr : p.stages[s + 1].hidden_in;       // lives on the NEXT device; peer write
-                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, hout, last && t == n - 1, prefill, nullptr)) return 1;
-                if (!last) { hipSetDevice(st.device); if (hipStreamSynchronize(nullptr) != hipSuccess) return 1; }   // hand-off: producer done before consumer starts
+                if (ordered(s)) return 1;
+                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, hout, last && t == n - 1, prefill, st.stream())) return 1;
+                if (stamp(s)) return 1;
             }
         }
+        Stage & lst = p.stages.back();
         if (!p.gpu_sampler) {
-            const float * lg = bamd_stage_get_logits(p.stages.back().ctx, nullptr);
+            const float * lg = bamd_stage_get_logits(lst.ctx, lst.stream());      // synchronises the last stage's stream: everything before it is done
             if (!lg) return 1;
             memcpy(p.logits.data(), lg, (size_t) p.n_vocab * 4);
         } else {                                  // the logits stay on the last device; llama_decode's synchronisation still applies
-            hipSetDevice(p.stages.back().device);
-            if (hipStreamSynchronize(nullptr) != hipSuccess) return 1;
+            hipSetDevice(lst.device);
+            if (hipStreamSynchronize((hipStream_t) lst.stream()) != hipSuccess) return 1;
         }
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -389,7 +430,13 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
 
 void pod_free(Pod * p) {
     if (!p) return;
-    for (auto & s : p->stages) { if (s.hidden_in) { hipSetDevice(s.device); hipFree(s.hidden_in); } if (s.ctx) bamd_context_free(s.ctx); if (s.model) bamd_model_free(s.model); }
+    for (auto & s : p->stages) {
+        hipSetDevice(s.device);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.hidden_in) hipFree(s.hidden_in);
+        if (s.ctx) bamd_context_free(s.ctx);
+        if (s.model) bamd_model_free(s.model);
+    }
     delete p;
 }
 }  // namespace
@@ -423,16 +470,21 @@ BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_si
     pod->n_vocab = bamd_model_n_vocab(probe); pod->n_embd = bamd_model_n_embd(probe);
     const int n_ctx_train = bamd_model_n_ctx_train(probe);
     bamd_model_free(probe);
-    const int gpu[4] = { gpu1, gpu2, gpu3, gpu4 };
+    int gpu[BAMD_MAX_GPUS] = { 0 };
+    const int n_gpu = gpu_weights(gpu1, gpu2, gpu3, gpu4, gpu);
+    // BAMD_VIRTUAL_DEVICES=N (tests): plan the split as if N devices were present and place device d on physical device d mod ndev —
+    // the whole multi-stage path (stage streams, events, hand-off copies, stage graphs) then runs on a box with fewer GPUs
+    int ndev_plan = ndev;
+    if (const char * e = getenv("BAMD_VIRTUAL_DEVICES")) { const int v = atoi(e); if (v >= 1 && v <= BAMD_MAX_GPUS) ndev_plan = v; }
     std::vector<std::pair<int, std::pair<int, int>>> plan;
-    if (!plan_stages(n_layer, gpu, ndev, plan, err)) { fprintf(stderr, "initContext: %s\n", err.c_str()); return nullptr; }
+    if (!plan_stages(n_layer, gpu, n_gpu, ndev_plan, plan, err)) { fprintf(stderr, "initContext: %s\n", err.c_str()); return nullptr; }
     int n_ctx = context > 0 ? context : n_ctx_train;          // n_ctx 0 = from model (llama.cpp:16640)
     n_ctx = (n_ctx + 31) / 32 * 32;
     pod->n_ctx = n_ctx; pod->n_predict = predict;
     pod->n_batch = (batch_size > 0 && batch_size <= n_ctx) ? batch_size : 512;          // cpp/bridge.cpp:152-160 (GPU branch)
     pod->jp.janus = janus; pod->jp.depth = depth; pod->jp.scale = scale; pod->jp.hi = hi; pod->jp.lo = lo;
     for (size_t s = 0; s < plan.size(); ++s) {
-        Stage st; st.device = plan[s].first;
+        Stage st; st.device = ndev_plan != ndev ? plan[s].first % ndev : plan[s].first;
         if (st.device >= ndev) { fprintf(stderr, "initContext: gpu%d requested but only %d HIP device(s) present\n", st.device + 1, ndev); return nullptr; }
         const bool first = s == 0, last = s + 1 == plan.size();
         st.model = bamd_model_load(path.c_str(), st.device, plan[s].second.first, plan[s].second.second, first, last);
@@ -441,6 +493,8 @@ BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_si
         Stage & ref = pod->stages.back();
         ref.ctx = bamd_context_new(ref.model, n_ctx);
         if (!ref.ctx) { fprintf(stderr, "initContext: error: failed to create context: %s\n", bamd_last_error()); return nullptr; }
+        hipSetDevice(ref.device);
+        if (hipEventCreateWithFlags(&ref.done, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (!first) {
             hipSetDevice(ref.device);
             if (hipMalloc(&ref.hidden_in, (size_t) 512 * pod->n_embd * 4) != hipSuccess) return nullptr;     // one prompt micro-batch of hidden states
@@ -553,7 +607,7 @@ BAMD_API int bamd_bridge_sample_test(void * ctx, const float * logits, const int
         if (!p.gpu_sampler || bamd_set_logits_test(p.stages.back().ctx, logits)) return -1;
         id = sample_janus_device(p, last_tokens, (size_t) prompt_len, (size_t) pos, (size_t) max);
         if (logits_after) {
-            const float * lg = p.stages.size() == 1 ? bamd_get_logits(p.stages.back().ctx) : bamd_stage_get_logits(p.stages.back().ctx, nullptr);
+            const float * lg = p.stages.size() == 1 ? bamd_get_logits(p.stages.back().ctx) : bamd_stage_get_logits(p.stages.back().ctx, p.stages.back().stream());
             if (!lg) return -1;
             memcpy(logits_after, lg, (size_t) p.n_vocab * 4);
         }
@@ -588,9 +642,10 @@ BAMD_API void bamd_vocab_free(bamd_vocab * h) { delete h; }
 // test hook, CPU only: the device of every layer and of the output layer (index n_layer) for a gpu1..gpu4 setting on a box with
 // `device_count` GPUs; returns 0, or 1 when the setting is refused (no CPU path)
 BAMD_API int bamd_plan_stages_test(int n_layer, int g1, int g2, int g3, int g4, int device_count, int32_t * device_of) {
-    const int gpu[4] = { g1, g2, g3, g4 };
+    int gpu[BAMD_MAX_GPUS] = { 0 };
+    const int n_gpu = gpu_weights(g1, g2, g3, g4, gpu);       // honours BOOSTER_GPUS like initContext
     std::vector<std::pair<int, std::pair<int, int>>> plan; std::string err;
-    if (!plan_stages(n_layer, gpu, device_count, plan, err)) return 1;
+    if (!plan_stages(n_layer, gpu, n_gpu, device_count, plan, err)) return 1;
     for (const auto & st : plan) for (int il = st.second.first; il < st.second.second; ++il) device_of[il] = st.first;
     device_of[n_layer] = plan.back().first;
     return 0;

@@ -60,6 +60,7 @@ def test_gpus_split_rule():
     rng = np.random.default_rng(3)
 
     def ref(n_layer, gpu, dc):
+        dc = min(dc, len(gpu))
         n_gpu_layers = sum(gpu)
         if n_gpu_layers <= n_layer:
             return None                                   # layers would stay on the CPU: refused here
@@ -90,3 +91,22 @@ def test_gpus_split_rule():
             assert rc == 0 and out.tolist() == want, (n_layer, gpu, dc, out.tolist(), want)
             n_ok += 1
     assert n_ok > 50
+    # BOOSTER_GPUS: up to eight weights through the unchanged nine symbols.  The reference's own layer -> device map
+    # cannot be dumped here (llm_load_tensors needs CUDA devices), so the pin stays the rule at cpp/src/llama.cpp:5932-5969,
+    # restated above, applied to eight entries.
+    import os
+    try:
+        for n_layer, gpu8, dc in [(80, (11, 10, 10, 10, 10, 10, 10, 10), 8), (32, (5, 4, 4, 4, 4, 4, 4, 4), 8), (80, (20, 20, 20, 21, 0, 0, 0, 0), 8),
+                                  (80, (11, 10, 10, 10, 10, 10, 10, 10), 5), (40, (0, 0, 0, 0, 0, 0, 0, 50), 8)]:
+            os.environ["BOOSTER_GPUS"] = ",".join(str(x) for x in gpu8)
+            out = np.full(n_layer + 1, -1, np.int32)
+            rc = L.bamd_plan_stages_test(n_layer, 100, 0, 0, 0, dc, out.ctypes.data_as(C.c_void_p))      # the four arguments are overridden
+            want = ref(n_layer, list(gpu8), dc)
+            assert rc == 0 and out.tolist() == want, (n_layer, gpu8, dc, out.tolist(), want)
+        assert out.tolist() == [7] * 41                   # everything on the eighth device
+        os.environ["BOOSTER_GPUS"] = "11,10,10,10,10,10,10,10"
+        out = np.full(81, -1, np.int32)
+        assert L.bamd_plan_stages_test(80, 0, 0, 0, 0, 8, out.ctypes.data_as(C.c_void_p)) == 0
+        assert [out.tolist().count(d) for d in range(8)] == [11, 10, 10, 10, 10, 10, 10, 10]          # Llama-3-70B on 8 GPUs: 11 layers on the first, 9 + the output layer on the last
+    finally:
+        os.environ.pop("BOOSTER_GPUS", None)

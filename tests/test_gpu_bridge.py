@@ -159,14 +159,22 @@ def test_device_sampler_fallbacks(lib, bamd, tmp_path):
     assert counts[1] >= 3 and counts[0] >= 3            # the crowded cases went through the host path, the others stayed on the device
 
 
-def test_reference_abi_transcript(lib, bamd, tmp_path):
+@pytest.mark.parametrize("split", ["one stage", "three stages"])
+def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
     """the nine cgo symbols replayed against the transcript recorded from the GENUINE reference bridge
     (tests/golden/abi_transcript.json <- tests/golden/gen_abi_transcript.py: cpp/bridge.cpp + cpp/janus.cpp compiled in place, CPU
     path): every doInference return value (n_p_eval + n_eval, 0 for a prompt beyond n_ctx - 4), every status() text byte for byte
     (prompt echo + generated pieces; a reused job id; a job that never ran), every getPromptTokenCount, on two pods.  The model is
-    the same deterministic synthetic GGUF; here it runs on the GPU (gpu1 = 100)."""
+    the same deterministic synthetic GGUF; here it runs on the GPU (gpu1 = 100).
+    "three stages": the same session through Booster's layer split — BOOSTER_GPUS=2,1,1 over three devices (virtual ones on a box
+    with fewer GPUs: BAMD_VIRTUAL_DEVICES), i.e. the event-ordered multi-stage path with its hand-off copies and stage graphs —
+    must give the reference's results unchanged."""
     import json
     import os
+    if split == "three stages":
+        monkeypatch.setenv("BOOSTER_GPUS", "2,1,1")
+        if bamd.device_count() < 3:
+            monkeypatch.setenv("BAMD_VIRTUAL_DEVICES", "3")
     t = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "abi_transcript.json")))
     vocab = gguf.synthetic_janus_vocab(t["n_vocab"])
     path = str(tmp_path / "abi.gguf")
@@ -184,18 +192,18 @@ def test_reference_abi_transcript(lib, bamd, tmp_path):
             lib.init(b"", b"")
         elif op == "infer":
             idx = int(p[1]); pod = pod_of[idx]
-            got = lib.doInference(pod, ctxs[idx], ("abi-" + p[2]).encode(), b"sess", bytes.fromhex(p[3]))
+            got = lib.doInference(pod, ctxs[idx], ("abi-%s-" % split[:3] + p[2]).encode(), b"sess", bytes.fromhex(p[3]))
             assert got == want["ret"], "%s: doInference returned %d, the reference %d" % (line[:40], got, want["ret"])
         elif op == "status":
-            got = lib.status(("abi-" + p[1]).encode())
+            got = lib.status(("abi-%s-" % split[:3] + p[1]).encode())
             assert got == bytes.fromhex(want["hex"]), "%s: status() differs\n ours %r\n ref  %r" % (line, got, bytes.fromhex(want["hex"]))
         elif op == "count":
-            assert lib.getPromptTokenCount(("abi-" + p[1]).encode()) == want["ret"], line
+            assert lib.getPromptTokenCount(("abi-%s-" % split[:3] + p[1]).encode()) == want["ret"], line
         elif op == "stop":
             lib.stopInference(pod_of[int(p[1])])
         elif op == "seed":
-            assert (lib.getSeed(("abi-" + p[1]).encode()) != 0) == bool(want["nonzero"])
+            assert (lib.getSeed(("abi-%s-" % split[:3] + p[1]).encode()) != 0) == bool(want["nonzero"])
         elif op == "evalms":
-            assert (lib.promptEval(("abi-" + p[1]).encode()) >= 0) == bool(want["nonneg"])
+            assert (lib.promptEval(("abi-%s-" % split[:3] + p[1]).encode()) >= 0) == bool(want["nonneg"])
         elif op == "genms":
-            assert (lib.timing(("abi-" + p[1]).encode()) >= 0) == bool(want["nonneg"])
+            assert (lib.timing(("abi-%s-" % split[:3] + p[1]).encode()) >= 0) == bool(want["nonneg"])
