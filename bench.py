@@ -11,14 +11,17 @@ N = 1: the whole model on one GPU, K steps replayed from one hipGraph per step.
 N > 1: Booster's `gpus:` layer split (llama.cpp:5932-5969), one process per GPU: rank r owns a contiguous layer
        range, its KV slice, (rank 0) the embedding, (last rank) output_norm + lm_head.  The f32 hidden state
        [n_embd] moves with ONE RCCL send/recv per boundary (torch.distributed, backend nccl = RCCL over xGMI); the
-       arg-max token returns from the last rank to rank 0 with one more send/recv.  N sequences are kept in flight
-       (pipeline over independent requests — Booster's pods), so every GPU streams its weight slice continuously:
-       per-GPU work is fixed as N grows ("weak").  The single-sequence (latency-bound) rate is reported beside it.
+       arg-max token returns from the last rank to rank 0 with one more send/recv.  `value` stays the BASELINE
+       metric — batch-1 decode of ONE sequence, now through N stages that work one after another (total work fixed:
+       "strong"); the throughput with N independent sequences in flight (Booster's pods) is reported beside it.
+--model 70b: the same with Llama-3-70B Q4_K_M shapes (80 layers; BASELINE config 4 at --gpus 8); m7q6k: Mistral-7B, all Q6_K.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the quantised mat-vec, all weight streaming):
-achieved = algorithmic weight bytes per launch / mean launch duration, measured here with HIP events around every
-launch of an eager step.  `cpu_baseline` times the oracle (a port of the reference CPU path) on this box's host
-cores on a bounded sample (2 of 32 layers + lm_head, extrapolated), rank 0, N = 1 only.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the quantised mat-vec launches, all weight
+streaming): achieved = algorithmic weight bytes per launch / mean launch duration, measured here with HIP events around
+every launch of an eager step; `traffic` is NOT measured in this run: it is the per-launch HBM read bytes of the committed
+rocprofv3 PMC pass (profiles/), quoted for comparison.  `cpu_baseline` times the GENUINE reference CPU path
+(oracle/_ref/ref_bench, built in the build container and shipped prebuilt) on this box's host cores on the same GGUF:
+a 16-token prefill and 32 single-token decode steps, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -32,32 +35,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG_8B = dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, theta=500000.0, eps=1e-5, n_ctx_train=8192)
+CFG_70B = dict(E=8192, H=64, Hkv=8, L=80, F=28672, V=128256, theta=500000.0, eps=1e-5, n_ctx_train=8192)
+CFG_M7 = dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=32000, theta=10000.0, eps=1e-5, n_ctx_train=8192)
+MODELS = {"8b": ("Llama-3-8B Q4_K_M", CFG_8B, "bamd_llama3_8b_q4_k_m_synth.gguf"),
+          "70b": ("Llama-3-70B Q4_K_M", CFG_70B, "bamd_llama3_70b_q4_k_m_synth.gguf"),
+          "m7q6k": ("Mistral-7B Q6_K", CFG_M7, "bamd_mistral7b_q6_k_synth.gguf")}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 N_PROMPT, N_CTX = 128, 512
 KV_BYTES_PER_POS = 2 * 32 * 8 * 128 * 2
 
 
-def model_path():
+def model_path(model="8b"):
+    name = MODELS[model][2]
+    need = (48 << 30) if model == "70b" else (7 << 30)
     for d in ("/dev/shm", "/tmp"):
         if os.path.isdir(d) and os.access(d, os.W_OK):
             try:
+                if os.path.exists(os.path.join(d, name + ".done")):
+                    return os.path.join(d, name)
                 st = os.statvfs(d)
-                if st.f_bavail * st.f_frsize > 7 << 30:
-                    return os.path.join(d, "bamd_llama3_8b_q4_k_m_synth.gguf")
+                if st.f_bavail * st.f_frsize > need:
+                    return os.path.join(d, name)
             except OSError:
                 pass
-    return "/tmp/bamd_llama3_8b_q4_k_m_synth.gguf"
+    return os.path.join("/tmp", name)
 
 
-def ensure_model(path, rank):
+def ensure_model(path, rank, model="8b"):
     from booster_amd import gguf
     done = path + ".done"
     if rank == 0 and not os.path.exists(done):
         t0 = time.time()
-        gguf.write_synthetic_llama(path, seed=7, reuse_layers=True, **CFG_8B)
+        kw = dict(MODELS[model][1])
+        if model == "70b":
+            kw["type_fn"] = lambda name, il: gguf.q4_k_m_type_70b(name, il, 80)
+        elif model == "m7q6k":
+            kw["type_fn"] = lambda name, il: gguf.Q6_K
+            kw["embd_type"] = gguf.Q6_K
+        gguf.write_synthetic_llama(path, seed=7, reuse_layers=True, **kw)
         open(done, "w").write("ok")
         sys.stderr.write("[bench] wrote %s (%.1f GB) in %.1f s\n" % (path, os.path.getsize(path) / 1e9, time.time() - t0))
     return path
+
+
+def cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def split_layers(L, n):
@@ -76,15 +104,16 @@ def cpu_baseline_reference(path, nthreads):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     if not os.path.exists(exe):
         return None
-    n_prompt, n_decode = 16, 12
+    n_prompt, n_decode = 16, 32
     env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
     out = subprocess.run([exe, path, str(nthreads), str(n_prompt), str(n_decode), "512"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                          timeout=600, env=env, check=True).stdout.decode()
     m = re.search(r"tokens_per_s=([0-9.]+) ms_per_token=([0-9.]+) prompt_tokens_per_s=([0-9.]+)", out)
     return dict(value=round(float(m.group(1)), 4), unit="tokens/s", cores=nthreads, kind="reference",
-                sample="genuine reference CPU path (gotzmann/booster's ggml + llama.cpp built by oracle/Makefile, `make cpu` flags with -march=x86-64-v3, "
-                       "%d threads) on the same GGUF, all 32 layers: %d-token prefill (%.1f tok/s) + %d greedy single-token llama_decode steps, %.1f ms per token"
-                       % (nthreads, n_prompt, float(m.group(3)), n_decode, float(m.group(2))))
+                sample="genuine reference CPU path (gotzmann/booster's ggml + llama.cpp built by oracle/Makefile, `make cpu` flags with -march=x86-64-v3) "
+                       "on %d threads of this box's host (%s, %d logical CPUs) on the same GGUF, all layers: %d-token prefill (%.1f tok/s) + %d greedy "
+                       "single-token llama_decode steps, %.1f ms per token.  Build-container figures for config 1 (128 + 128 tokens, threads = 1 and 8): BASELINE.md section 3"
+                       % (nthreads, cpu_name(), os.cpu_count() or 0, n_prompt, float(m.group(3)), n_decode, float(m.group(2))))
 
 
 def cpu_baseline(path, nthreads):
@@ -119,6 +148,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="8b", choices=sorted(MODELS), help="8b = the BASELINE metric (default); 70b = BASELINE config 4 shapes; m7q6k = config 5 shapes")
     ap.add_argument("--pipeline-smoke", action="store_true", help="run the N > 1 code path (layer-split pipeline, RCCL group) with a single rank")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,14 +166,15 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    path = model_path()
-    ensure_model(path, rank)
+    model_name, CFG, _ = MODELS[args.model]
+    path = model_path(args.model)
+    ensure_model(path, rank, args.model)
     if dist is not None:
         dist.barrier()
     steps, warmup = args.steps, args.warmup
     # the default K / W fit the 512-position context the metric is quoted on; a longer request grows the context instead of failing
     n_ctx = max(N_CTX, (N_PROMPT + warmup + steps + 2 + 255) // 256 * 256)
-    prompt = [(7919 * i + 13) % CFG_8B["V"] for i in range(N_PROMPT)]
+    prompt = [(7919 * i + 13) % CFG["V"] for i in range(N_PROMPT)]
     result = {}
 
     if N == 1 and not args.pipeline_smoke:
@@ -184,23 +215,26 @@ def main():
         achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
         traffic = None                                                   # HBM bytes per launch from the committed PMC pass, if any
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_summary.json")))
-            traffic = int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
+            if args.model == "8b":                                           # quoted from the committed PMC pass of this workload, not measured in this run
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_summary.json")))
+                traffic = int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
         except Exception:
             pass
         n_kv_avg = N_PROMPT + warmup + steps / 2.0
-        bytes_per_token = m.weight_bytes + KV_BYTES_PER_POS * n_kv_avg
+        kv_bytes_per_pos = 2 * CFG["L"] * CFG["Hkv"] * (CFG["E"] // CFG["H"]) * 2
+        bytes_per_token = m.weight_bytes + kv_bytes_per_pos * n_kv_avg
         result = dict(
             value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
-            config=dict(workload="Llama-3-8B Q4_K_M shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
-                                 "128-token prompt, n_ctx %d, n_kv %d..%d" % (n_ctx, N_PROMPT + warmup, n_past),
+            config=dict(workload="%s shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
+                                 "128-token prompt, n_ctx %d, n_kv %d..%d" % (model_name, n_ctx, N_PROMPT + warmup, n_past),
                         parallelism="single GPU", graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
                         prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3), empty_event_pair_us=round(ev_empty_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                          traffic=traffic, kernel="matvec_kernel (Q4_K/Q6_K x Q8_K, fused prologue/epilogue)",
+                          traffic=traffic, traffic_source="profiles/r02_pmc_fetch_summary.json (committed rocprofv3 PMC pass of this workload; not measured in this run)",
+                          kernel="quantised mat-vec launches (matvec_fast_kernel / matvec_split_fast_kernel: Q4_K/Q5_K/Q6_K weights x Q8_K activations, fused prologue/epilogue)",
                           bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
         )
         if not args.no_cpu_baseline:
@@ -221,10 +255,10 @@ def main():
         ctx.close(); m.close()
     else:
         from booster_amd import pipeline
-        result = pipeline.run_layer_split_bench(path, CFG_8B, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch)
+        result = pipeline.run_layer_split_bench(path, CFG, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch, model_name)
 
     if rank == 0:
-        out = dict(metric="decode tokens/sec Llama-3-8B Q4_K_M", value=result.pop("value"), unit="tokens/s", n_gpus=N, steps=steps,
+        out = dict(metric="decode tokens/sec " + model_name, value=result.pop("value"), unit="tokens/s", n_gpus=N, steps=steps,
                    warmup=warmup, ms_per_step=result.pop("ms_per_step"), higher_is_better=True, scaling=result.pop("scaling"),
                    vs_baseline=None, dtype="int8xint4/6 dot -> f32 (Q4_K/Q6_K weights x Q8_K activations), f16 KV", data="synthetic")
         out.update(result)

@@ -205,6 +205,13 @@ def q4_k_m_type(name, il, n_layer):
     return Q4_K
 
 
+def q4_k_m_type_70b(name, il, n_layer=80):
+    """The Q4_K_M recipe for the 70B shape: as q4_k_m_type, but attn_v (8 heads share it) is Q5_K where the recipe leaves it at
+    Q4_K (llama.cpp:15552-15555)."""
+    t = q4_k_m_type(name, il, n_layer)
+    return Q5_K if (name == "attn_v" and t == Q4_K) else t
+
+
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
                           type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0):
     """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.

@@ -48,6 +48,7 @@ class HipStage:
         self.device = torch.device("cuda", device)
         # a side stream: stage steps replay captured hipGraphs, and the legacy default stream cannot be captured
         self.stream = torch.cuda.Stream(device=self.device)
+        self.time_steps = None                              # a list: step() brackets every stage step with a HIP event pair (bench roofline)
 
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
@@ -60,8 +61,13 @@ class HipStage:
 
     def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
         stream = self.torch.cuda.current_stream().cuda_stream
+        if self.time_steps is not None:
+            a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            a.record()
         self.ctx[seq].stage_step(token_host, pos, None if hin is None else hin.data_ptr(), None if hout is None else hout.data_ptr(),
                                  want_logits, prefill_mode, stream, None if token_dev is None else token_dev.data_ptr())
+        if self.time_steps is not None:
+            b.record(); self.time_steps.append((a, b))
 
     def token_to(self, seq, token_dev):
         self.ctx[seq].stage_token_to(token_dev.data_ptr(), self.torch.cuda.current_stream().cuda_stream)
@@ -154,44 +160,64 @@ def _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset)
     return [[int(t.item()) for t in f] for f in fed]
 
 
-def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch):
-    """bench.py's N > 1 leg.  Returns the dict bench.py prints (value = whole-job tokens/s with N sequences in flight)."""
+def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch, model_name="Llama-3-8B Q4_K_M"):
+    """bench.py's N > 1 leg.  `value` = the BASELINE metric at N GPUs: greedy batch-1 decode of ONE sequence through the N layer-split
+    stages (the stages work one after another, so it does not grow with N — Booster's `gpus:` split buys capacity, not batch-1 speed);
+    the throughput with N independent sequences in flight (Booster's pods keeping every stage busy) is reported beside it."""
     import booster_amd
     ranges = split_layers_balanced(cfg["L"], N)
     stage = HipStage(booster_amd, torch, path, local, ranges[rank], rank == 0, rank == N - 1, n_ctx, N)
     dist.barrier()
     # untimed: every sequence through the prompt and `warmup` + 1 decode steps.  All sequences are identical, so the token fed at
-    # the last position is known on rank 0; the timed call re-feeds it at the same position (T = 1 semantics, identical KV row)
-    # and then runs EXACTLY `steps` decode steps per sequence on top of the warm caches.
+    # the last position is known on rank 0; the timed calls re-feed it at the same position (T = 1 semantics, identical KV row)
+    # and then run EXACTLY `steps` decode steps on top of the warm caches.
     fed = run_pipeline(stage, dist, rank, N, prompt, warmup + 1, N)
     pos0 = len(prompt) + warmup
     carry = [fed[0][-1] if rank == 0 else 0]
+    # ---- the metric: one sequence, K steps ----
+    dist.barrier(); stage.sync()
+    t0 = time.perf_counter()
+    run_pipeline(stage, dist, rank, N, carry, steps, 1, pos_offset=pos0)
+    stage.sync(); dist.barrier()
+    dt_single = time.perf_counter() - t0
+    # ---- side number: N sequences in flight ----
     dist.barrier(); stage.sync()
     t0 = time.perf_counter()
     run_pipeline(stage, dist, rank, N, carry, steps, N, pos_offset=pos0)
     stage.sync(); dist.barrier()
-    dt = time.perf_counter() - t0
-    # single sequence in flight (latency-bound, the reference's batch-1 layer-split behaviour)
-    k1 = min(steps, 32)
-    dist.barrier(); stage.sync()
-    t0 = time.perf_counter()
-    run_pipeline(stage, dist, rank, N, carry, k1, 1, pos_offset=pos0)
-    stage.sync(); dist.barrier()
-    dt_single = time.perf_counter() - t0
-    t = torch.tensor([dt, dt_single], dtype=torch.float64, device=stage.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, dt_single = [float(v) for v in t.tolist()]
-    value = N * steps / dt
+    dt_pods = time.perf_counter() - t0
+    # ---- roofline per stage: this rank's slice of the weights / the time its stage step takes (events around 16 steps of a
+    #      single sequence on the stage stream; an event pair's own cost, measured empty, is subtracted) ----
+    stage.time_steps = []
+    run_pipeline(stage, dist, rank, N, carry, 16, 1, pos_offset=pos0)
+    stage.sync()
+    ev = stage.time_steps; stage.time_steps = None
+    with stage.stream_ctx():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record(); stage.sync()
+        empty_ms = a.elapsed_time(b)
+    stage_ms = max(sum(x.elapsed_time(y) for x, y in ev) / max(len(ev), 1) - empty_ms, 1e-6)
     wbytes = float(getattr(stage.model, "weight_bytes", 0))         # this rank's slice of the mat-mul weights
-    t = torch.tensor([wbytes], dtype=torch.float64, device=stage.device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    per_gpu_gbs = float(t.item()) / N * value / 1e9                 # every token of every sequence streams each stage's slice once
+    t = torch.tensor([dt_single, dt_pods], dtype=torch.float64, device=stage.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_single, dt_pods = [float(v) for v in t.tolist()]
+    per = torch.zeros(N, 2, dtype=torch.float64, device=stage.device)
+    per[rank, 0] = wbytes; per[rank, 1] = stage_ms
+    dist.all_reduce(per, op=dist.ReduceOp.SUM)
+    per = per.tolist()
+    stages = [dict(rank=r, layers=list(ranges[r]), weight_bytes=int(per[r][0]), ms_per_token=round(per[r][1], 4),
+                   achieved_GBps=round(per[r][0] / (per[r][1] * 1e-3) / 1e9, 1)) for r in range(N)]
+    slow = max(stages, key=lambda d: d["ms_per_token"])
+    value = steps / dt_single
     stage.close()
-    return dict(value=round(value, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
-                config=dict(workload="Llama-3-8B Q4_K_M shapes (synthetic GGUF), greedy decode, layer-split over %d MI355X, %d sequences in flight, "
-                                     "128-token prompt, n_ctx %d" % (N, N, n_ctx),
-                            parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state per boundary per token" % N,
-                            layer_ranges=ranges, single_sequence_tokens_per_s=round(k1 / max(dt_single, 1e-9), 2),
-                            note="single_sequence = one request through all stages (stages idle in turn, the reference's batch-1 behaviour)"),
-                roofline=dict(bound="hbm", achieved=round(per_gpu_gbs, 1), peak=8000.0, unit="GB/s", frac=round(per_gpu_gbs / 8000.0, 4), traffic=None,
-                              kernel="per-GPU average over the timed region: (weight bytes of a stage) x (tokens/s through it); per-launch figures are the N=1 line's"))
+    return dict(value=round(value, 2), ms_per_step=round(dt_single / steps * 1e3, 4), scaling="strong",
+                config=dict(workload="%s shapes (synthetic GGUF), greedy batch-1 decode of ONE sequence, layer-split over %d MI355X "
+                                     "(Booster's gpus: split), 128-token prompt, n_ctx %d" % (model_name, N, n_ctx),
+                            parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state [n_embd] per boundary per token" % N,
+                            layer_ranges=ranges, sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
+                            pods_tokens_per_s=round(N * steps / dt_pods, 2),
+                            note="value = one request through all stages (stages idle in turn: the reference's batch-1 behaviour); "
+                                 "pods_tokens_per_s = N independent sequences in flight, every stage busy"),
+                roofline=dict(bound="hbm", achieved=slow["achieved_GBps"], peak=8000.0, unit="GB/s", frac=round(slow["achieved_GBps"] / 8000.0, 4), traffic=None,
+                              kernel="slowest stage: weight bytes of its layer slice / its stage time per token (HIP events on the stage stream)",
+                              stages=stages))
