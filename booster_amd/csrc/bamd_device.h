@@ -89,6 +89,11 @@ __device__ __forceinline__ int dotscale8(const uint32_t (&a)[8], const uint32_t 
 }
 // scale (<= 8 bits) x block dot (<= 15 bits): full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ const uint8_t * uniform_ptr(const uint8_t * p) {      // a pointer the caller knows to be wave-uniform -> SGPR pair
+    const uint64_t u = (uint64_t) p;
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) u), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (u >> 32));
+    return (const uint8_t *) (((uint64_t) hi << 32) | lo);
+}
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
 
 // ggml-quants.c:1632-1637
@@ -294,8 +299,8 @@ struct ActPro {
 struct RowAcc { float acc, accm; };
 
 // ---- per-record arithmetic -----------------------------------------------------------------------------
-struct RecQ4K { uint4 qs, hd; };
-struct RecQ5K { uint4 qs, hd; uint32_t qh; };
+struct RecQ4K { uint4 qs, hd; uint32_t mn47; };              // mn47: BAMD_XSCALES = 1 only (bamd_formats.h); dead otherwise
+struct RecQ5K { uint4 qs, hd; uint32_t qh, mn47; };
 struct RecQ6K { uint4 ql; uint2 qh, sc; uint32_t d; };
 
 // Pin a loaded register at its point of use: without this, LLVM folds the first ALU op on a ring register into
@@ -304,15 +309,25 @@ struct RecQ6K { uint4 ql; uint2 qh, sc; uint32_t d; };
 __device__ __forceinline__ void pin(uint32_t & x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(uint2 & x) { pin(x.x); pin(x.y); }
 __device__ __forceinline__ void pin(uint4 & x) { pin(x.x); pin(x.y); pin(x.z); pin(x.w); }
+#if BAMD_XSCALES
+__device__ __forceinline__ void pin_rec(RecQ4K & R) { pin(R.qs); pin(R.hd); pin(R.mn47); }
+__device__ __forceinline__ void pin_rec(RecQ5K & R) { pin(R.qs); pin(R.hd); pin(R.qh); pin(R.mn47); }
+#else
 __device__ __forceinline__ void pin_rec(RecQ4K & R) { pin(R.qs); pin(R.hd); }
 __device__ __forceinline__ void pin_rec(RecQ5K & R) { pin(R.qs); pin(R.hd); pin(R.qh); }
+#endif
 __device__ __forceinline__ void pin_rec(RecQ6K & R) { pin(R.ql); pin(R.qh); pin(R.sc); pin(R.d); }
 
-// `rec` is wave-uniform (SGPR pair); the per-lane part is a 32-bit offset, so the loads take the saddr form and need no
-// 64-bit VALU address arithmetic.  Weights are read exactly once per token: non-temporal loads keep them out of the way
-// of the L2-resident activations (MI355X_MICROARCH.md, row nt-weights).
+// Weight records are fetched with BUFFER loads: the matrix is one 128-bit resource descriptor in scalar registers, the record a scalar
+// byte offset (soffset), the lane's share a constant 32-bit vector offset + an immediate — no vector instruction computes an address
+// (a global_load of base + per-lane offset took one 64-bit vector add per request: 2 of the 62 vector instructions of a Q4_K record).
+// Weights are read exactly once per token: non-temporal (MI355X_MICROARCH.md, row nt-weights).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#ifndef BAMD_BUFFER_LOADS
+#define BAMD_BUFFER_LOADS 1
+#endif
+#define BAMD_LOAD_NT 2                  /* aux bits of the raw buffer loads: nt */
 template <typename T> __device__ __forceinline__ T ldnt(const uint8_t * rec, uint32_t off) { return __builtin_nontemporal_load((const T *) (rec + off)); }
 template <> __device__ __forceinline__ uint4 ldnt<uint4>(const uint8_t * rec, uint32_t off) {
     const u32x4_t v = __builtin_nontemporal_load((const u32x4_t *) (rec + off)); return make_uint4(v.x, v.y, v.z, v.w);
@@ -320,25 +335,52 @@ template <> __device__ __forceinline__ uint4 ldnt<uint4>(const uint8_t * rec, ui
 template <> __device__ __forceinline__ uint2 ldnt<uint2>(const uint8_t * rec, uint32_t off) {
     const u32x2_t v = __builtin_nontemporal_load((const u32x2_t *) (rec + off)); return make_uint2(v.x, v.y);
 }
-__device__ __forceinline__ void load_rec(RecQ4K & R, const uint8_t * rec, int lane) {
-    const uint32_t l = (uint32_t) lane;
-    R.qs = ldnt<uint4>(rec, l * 16u);
-    R.hd = ldnt<uint4>(rec, 1024u + (l >> 3) * 16u);
+#if BAMD_BUFFER_LOADS
+typedef __amdgpu_buffer_rsrc_t bamd_rsrc;
+__device__ __forceinline__ bamd_rsrc weight_rsrc(const void * base) {       // base must be wave-uniform; the window is 2 GiB - 1 (offsets are checked by the launcher's shapes)
+    return __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) base), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void load_rec(RecQ5K & R, const uint8_t * rec, int lane) {
+__device__ __forceinline__ uint4 bl128(bamd_rsrc r, uint32_t voff, int soff) { const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) voff, soff, BAMD_LOAD_NT); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 bl64(bamd_rsrc r, uint32_t voff, int soff) { const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int) voff, soff, BAMD_LOAD_NT); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint32_t bl32(bamd_rsrc r, uint32_t voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, soff, BAMD_LOAD_NT); }
+__device__ __forceinline__ uint32_t bl16(bamd_rsrc r, uint32_t voff, int soff) { return (uint32_t) __builtin_amdgcn_raw_buffer_load_b16(r, (int) voff, soff, BAMD_LOAD_NT); }
+#else
+struct bamd_rsrc { const uint8_t * base; };
+__device__ __forceinline__ bamd_rsrc weight_rsrc(const void * base) { bamd_rsrc r; r.base = uniform_ptr((const uint8_t *) base); return r; }
+__device__ __forceinline__ uint4 bl128(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint4>(r.base + soff, voff); }
+__device__ __forceinline__ uint2 bl64(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint2>(r.base + soff, voff); }
+__device__ __forceinline__ uint32_t bl32(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint32_t>(r.base + soff, voff); }
+__device__ __forceinline__ uint32_t bl16(bamd_rsrc r, uint32_t voff, int soff) { return (uint32_t) ldnt<unsigned short>(r.base + soff, voff); }
+#endif
+// soff: byte offset of the record inside the matrix (wave-uniform)
+__device__ __forceinline__ void load_rec(RecQ4K & R, bamd_rsrc rs, int soff, int lane) {
     const uint32_t l = (uint32_t) lane;
-    R.qs = ldnt<uint4>(rec, l * 16u);
-    R.qh = ldnt<uint32_t>(rec, 1024u + l * 4u);
-    R.hd = ldnt<uint4>(rec, 1280u + (l >> 3) * 16u);
+    R.qs = bl128(rs, l * 16u, soff);
+    R.hd = bl128(rs, 1024u + (l >> 3) * 16u, soff);
+#if BAMD_XSCALES
+    R.mn47 = bl32(rs, 1152u + (l >> 3) * 4u, soff);
+#else
+    R.mn47 = 0u;
+#endif
 }
-__device__ __forceinline__ void load_rec(RecQ6K & R, const uint8_t * rec, int lane) {
+__device__ __forceinline__ void load_rec(RecQ5K & R, bamd_rsrc rs, int soff, int lane) {
     const uint32_t l = (uint32_t) lane;
-    R.ql = ldnt<uint4>(rec, l * 16u);
-    R.qh = ldnt<uint2>(rec, 1024u + l * 8u);
-    R.sc = ldnt<uint2>(rec, 1536u + (l >> 3) * 16u + ((l >> 2) & 1u) * 8u);
-    R.d  = ldnt<unsigned short>(rec, 1664u + (l >> 3) * 2u);
+    R.qs = bl128(rs, l * 16u, soff);
+    R.qh = bl32(rs, 1024u + l * 4u, soff);
+    R.hd = bl128(rs, 1280u + (l >> 3) * 16u, soff);
+#if BAMD_XSCALES
+    R.mn47 = bl32(rs, 1408u + (l >> 3) * 4u, soff);
+#else
+    R.mn47 = 0u;
+#endif
 }
-
+__device__ __forceinline__ void load_rec(RecQ6K & R, bamd_rsrc rs, int soff, int lane) {
+    const uint32_t l = (uint32_t) lane;
+    R.ql = bl128(rs, l * 16u, soff);
+    R.qh = bl64(rs, 1024u + l * 8u, soff);
+    R.sc = bl64(rs, 1536u + (l >> 3) * 16u + ((l >> 2) & 1u) * 8u, soff);
+    R.d  = bl16(rs, 1664u + (l >> 3) * 2u, soff);
+}
 // 6-bit scale/min unpack, ggml-quants.c:6928-6933
 __device__ __forceinline__ void unpack_k4(const uint4 & hd, uint32_t & sc03, uint32_t & sc47, uint32_t & mn03, uint32_t & mn47) {
     const uint32_t u0 = hd.y, u1 = hd.z, u2 = hd.w;
@@ -359,7 +401,11 @@ __device__ __forceinline__ Terms block_terms(const RecQ4K & R, int ci, int lane,
     Terms T;
     T.d = ydv * h2f(R.hd.x & 0xffffu);
     T.dmin = (-ydv) * h2f(R.hd.x >> 16);
+#if BAMD_XSCALES
+    const uint32_t sc03 = R.hd.y, sc47 = R.hd.z, mn03 = R.hd.w, mn47 = R.mn47;      // unpacked at load time (repack_kernel)
+#else
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+#endif
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     const uint32_t wq[8] = { R.qs.x & 0x0f0f0f0fu, (R.qs.x >> 4) & 0x0f0f0f0fu, R.qs.y & 0x0f0f0f0fu, (R.qs.y >> 4) & 0x0f0f0f0fu,
                              R.qs.z & 0x0f0f0f0fu, (R.qs.z >> 4) & 0x0f0f0f0fu, R.qs.w & 0x0f0f0f0fu, (R.qs.w >> 4) & 0x0f0f0f0fu };
@@ -380,7 +426,11 @@ __device__ __forceinline__ Terms block_terms(const RecQ5K & R, int ci, int lane,
     Terms T;
     T.d = ydv * h2f(R.hd.x & 0xffffu);
     T.dmin = (-ydv) * h2f(R.hd.x >> 16);
+#if BAMD_XSCALES
+    const uint32_t sc03 = R.hd.y, sc47 = R.hd.z, mn03 = R.hd.w, mn47 = R.mn47;
+#else
     uint32_t sc03, sc47, mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+#endif
     const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
     const uint32_t qh = R.qh;
 #define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))

@@ -162,7 +162,8 @@ static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool kee
     if (keep_raw) { if (dev_alloc(m->allocs, &d.raw, t->nbytes)) return 1; rawdev = d.raw; }
     HIPC(hipMemcpyAsync(rawdev, t->data, t->nbytes, hipMemcpyHostToDevice, s));
     if (want_stream) {
-        const size_t stream_bytes = bamd_row_bytes(d.type, d.K) * (size_t) d.nrows_pad;
+        const size_t stream_bytes = bamd_stream_bytes(d.type, d.K, d.nrows_pad);
+        if (stream_bytes >= (size_t) 0x7fffffff) return fail("tensor " + t->name + ": wave-stream copy exceeds 2 GiB (32-bit record offsets)");
         if (stream_dst) d.stream = stream_dst;
         else { if (dev_alloc(m->allocs, &d.stream, stream_bytes)) return 1; if (d.nrows_pad != d.nrows) HIPC(hipMemsetAsync(d.stream, 0, stream_bytes, s)); }
         bamd_launch_repack(rawdev, d.stream, d.type, d.nrows, d.K, s);
@@ -257,7 +258,10 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
             char * qkv_base = nullptr; size_t qkv_off = 0;
             {
                 size_t tot = 0;
-                for (int j = 0; j < 3; ++j) { const GgufTensor * t = g.tensor(p + mats[j].n + ".weight"); if (t) tot += t->nbytes; }
+                for (int j = 0; j < 3; ++j) {
+                    const GgufTensor * t = g.tensor(p + mats[j].n + ".weight");
+                    if (t && t->ne.size() == 2 && bamd_is_kquant(t->type)) tot += bamd_stream_bytes(t->type, t->ne[0], ((int64_t) t->ne[1] + 7) / 8 * 8);
+                }
                 if (dev_alloc(m->allocs, (void **) &qkv_base, tot)) { rc = 1; break; }
             }
             int mi = 0;
@@ -265,7 +269,7 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
                 const GgufTensor * t = g.tensor(p + mm.n + ".weight");
                 if (!t) { rc = fail("missing tensor " + p + mm.n + ".weight"); break; }
                 void * dst = nullptr;
-                if (mi < 3) { dst = qkv_base + qkv_off; qkv_off += t->nbytes; }
+                if (mi < 3) { dst = qkv_base + qkv_off; if (t->ne.size() == 2 && bamd_is_kquant(t->type)) qkv_off += bamd_stream_bytes(t->type, t->ne[0], ((int64_t) t->ne[1] + 7) / 8 * 8); }
                 if ((rc = upload_mat(m, t, *mm.d, false, true, staging, s, dst))) break;
                 ++mi;
             }
@@ -924,7 +928,7 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
     if (need_device()) return 1;
     if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0) return fail("bad type/shape");
     const int nrows_pad = (nrows + 7) / 8 * 8;
-    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_row_bytes(type, k) * (size_t) nrows_pad;
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_stream_bytes(type, k, nrows_pad);
     void * rawA = t.up(wA, wb), * strA = t.up(nullptr, wbp), * rawB = nullptr, * strB = nullptr;
     if (wB) { rawB = t.up(wB, wb); strB = t.up(nullptr, wbp); }
     if (strA) HIPC(hipMemset(strA, 0, wbp));
@@ -955,7 +959,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     if (need_device()) return 1;
     if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0 || T <= 0) return fail("bad type/shape");
     const int nrows_pad = (nrows + 7) / 8 * 8;
-    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_row_bytes(type, k) * (size_t) nrows_pad;
+    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_stream_bytes(type, k, nrows_pad);
     void * raw = t.up(w_raw, wb), * str = t.up(nullptr, wbp);
     float * dx = (float *) t.up(x, (size_t) T * k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr;
     float * dres = residual ? (float *) t.up(residual, (size_t) T * nrows * 4) : nullptr; float * dy = (float *) t.up(nullptr, (size_t) T * nrows * 4);
@@ -1066,7 +1070,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_bench_matvec(int type
     }
     std::vector<float> hx((size_t) k); for (int i = 0; i < k; ++i) { sd = sd * 1664525u + 1013904223u; hx[i] = (float) (int) (sd >> 8) / 8388608.0f - 1.0f; }
     std::vector<float> hn((size_t) k, 1.0f);
-    void * raw = t.up(hw.data(), wb), * strA = t.up(nullptr, wb), * strB = epi == BAMD_EPI_SILU_MUL ? t.up(nullptr, wb) : nullptr;
+    const size_t wbs = bamd_stream_bytes(type, k, nrows);
+    void * raw = t.up(hw.data(), wb), * strA = t.up(nullptr, wbs), * strB = epi == BAMD_EPI_SILU_MUL ? t.up(nullptr, wbs) : nullptr;
     float * dx = (float *) t.up(hx.data(), (size_t) k * 4), * dw = (float *) t.up(hn.data(), (size_t) k * 4);
     float * dres = (float *) t.up(nullptr, (size_t) nrows * 4), * dy = (float *) t.up(nullptr, (size_t) nrows * 4);
     unsigned long long * key = (unsigned long long *) t.up(nullptr, 8);

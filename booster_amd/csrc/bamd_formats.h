@@ -15,6 +15,7 @@
 //   Q4_K record 1152 B: [qs   : lane*16 -> 4 dwords j=0..3 = file qs[32j+4e .. +3]      ] 1024 B
 //                       [hdr  : r*16    -> file bytes 0..15 (d, dmin, scales[12])       ]  128 B
 //   Q5_K record 1408 B: [qs 1024 B as Q4_K][qh: lane*4 -> file qh[4e..4e+3] 256 B][hdr 128 B]
+//   (BAMD_XSCALES = 1, an experiment kept behind the macro: hdr = {d | dmin<<16, sc[0..3], sc[4..7], mn[0..3]} + 32 B of mn[4..7])
 //   Q6_K record 1680 B: [ql   : lane*16 -> 4 dwords j=0..3 = file ql[32j+4e .. +3]      ] 1024 B
 //                       [qh   : lane*8  -> 2 dwords m=0,1 = file qh[32m+4e .. +3]      ]  512 B
 //                       [sc   : r*16    -> byte hi*8+c = file scales[2c+hi]             ]  128 B
@@ -37,7 +38,17 @@
 enum bamd_type { BAMD_F32 = 0, BAMD_F16 = 1, BAMD_Q4_K = 12, BAMD_Q5_K = 13, BAMD_Q6_K = 14 };
 
 BAMD_HD static inline int bamd_block_bytes(int t) { return t == BAMD_Q4_K ? 144 : t == BAMD_Q5_K ? 176 : t == BAMD_Q6_K ? 210 : 0; }
-BAMD_HD static inline int bamd_record_bytes(int t) { return 8 * bamd_block_bytes(t); }
+#ifndef BAMD_XSCALES
+#define BAMD_XSCALES 0          /* 0: the file's 12 packed scale bytes per row (records of 1152 / 1408 B = 8 x the GGUF block); 1: unpacked scales and
+                                   mins, a byte each (1184 / 1440 B) — measured SLOWER on the MI355X in round 2 (gate/up 14.8 vs 13.2 us, decode 649 vs
+                                   666 tok/s): 9 vector instructions saved per record do not pay for +2.8 % bytes, a third request per record and
+                                   records that no longer start on a 128-byte line */
+#endif
+#define BAMD_RECB_Q4K (BAMD_XSCALES ? 1184 : 1152)
+#define BAMD_RECB_Q5K (BAMD_XSCALES ? 1440 : 1408)
+BAMD_HD static inline int bamd_record_bytes(int t) { return t == BAMD_Q4_K ? BAMD_RECB_Q4K : t == BAMD_Q5_K ? BAMD_RECB_Q5K : t == BAMD_Q6_K ? 1680 : 0; }   // wave-stream record: 8 rows x 1 super-block
+// bytes of the wave-stream copy of a K-quant matrix [nrows_pad (multiple of 8)][K]
+BAMD_HD static inline size_t bamd_stream_bytes(int t, int64_t k, int64_t nrows_pad) { return (size_t) (nrows_pad / 8) * (size_t) (k / BAMD_QK_K) * (size_t) bamd_record_bytes(t); }
 BAMD_HD static inline int bamd_is_kquant(int t) { return t == BAMD_Q4_K || t == BAMD_Q5_K || t == BAMD_Q6_K; }
 BAMD_HD static inline size_t bamd_row_bytes(int t, int64_t k) {
     return t == BAMD_F32 ? (size_t) k * 4 : t == BAMD_F16 ? (size_t) k * 2 : (size_t) (k / BAMD_QK_K) * bamd_block_bytes(t);

@@ -12,7 +12,7 @@ __global__ void repack_kernel(const uint8_t * __restrict__ raw, uint8_t * __rest
     const int rg = row >> 3, r = row & 7;
     const int bb = type == BAMD_Q4_K ? 144 : type == BAMD_Q5_K ? 176 : 210;
     const uint8_t * src = raw + ((int64_t) row * nb + i) * bb;
-    uint8_t * rec = dst + ((int64_t) rg * nb + i) * (8 * bb);
+    uint8_t * rec = dst + ((int64_t) rg * nb + i) * bamd_record_bytes(type);
     if (type == BAMD_Q4_K || type == BAMD_Q5_K) {
         const uint8_t * qs = src + (type == BAMD_Q4_K ? 16 : 48);
         for (int e = 0; e < 8; ++e)
@@ -24,7 +24,18 @@ __global__ void repack_kernel(const uint8_t * __restrict__ raw, uint8_t * __rest
                 for (int t = 0; t < 4; ++t) rec[1024 + (r * 8 + e) * 4 + t] = src[16 + 4 * e + t];
             hdr_off = 1280;
         }
+        // header: d, dmin as in the file, then the eight scales and the eight mins of get_scale_min_k4 (ggml-quants.c:1891-1899), a byte each
+#if BAMD_XSCALES
+        uint8_t * h = rec + hdr_off + r * 16, * h2 = rec + hdr_off + 128 + r * 4;
+        for (int t = 0; t < 4; ++t) h[t] = src[t];
+        for (int j = 0; j < 8; ++j) {
+            int sc, mn; get_scale_min_k4(j, src + 4, sc, mn);
+            h[4 + j] = (uint8_t) sc;
+            if (j < 4) h[12 + j] = (uint8_t) mn; else h2[j - 4] = (uint8_t) mn;
+        }
+#else
         for (int t = 0; t < 16; ++t) rec[hdr_off + r * 16 + t] = src[t];
+#endif
     } else {
         const uint8_t * ql = src, * qh = src + 128, * sc = src + 192;
         for (int e = 0; e < 8; ++e) {

@@ -33,12 +33,14 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
                                                int first, int count, int stride, float * __restrict__ out,
                                                const float * __restrict__ res, const ProArgs & pa, ActPro<PRO == BAMD_PRO_NORM> & ap,
                                                bool issue_here, bool do_pro, unsigned long long & best, int nvalid) {
-    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;     // bamd_record_bytes
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
     constexpr int NPARTS = PAIR ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const long rgb = (long) nb * RECB;                   // D divides nb (chosen by the dispatcher below)
-    const long rg_step = (long) stride * rgb;
+    // records are addressed as (matrix descriptor, 32-bit byte offset): see load_rec.  A matrix stays below 2 GiB (launcher).
+    const bamd_rsrc rsA = weight_rsrc(wA), rsB = PAIR ? weight_rsrc(wB) : rsA;
+    const int rgb = nb * RECB;                           // D divides nb (chosen by the dispatcher below)
+    const int rg_step = stride * rgb;
     const int chunks = nb / D;
     if (issue_here) BAMD_PRO_ISSUE(ap, pa);              // activation loads go out FIRST (see ActPro::issue); the fast kernels issue them at entry
     REC ring[D];
@@ -48,10 +50,10 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
     // is a constant offset, and the loads stay unconditional so the compiler keeps counted s_waitcnt vmcnt(N) waits.
     // (a wave without work — count == 0, fast kernels only — requests record 0 of the matrix D times: L1 hits, and its code path stays
     // the one of the busy waves: one copy of the prologue, no join in front of the counted waits)
-    const uint8_t * rowA = wA + (count > 0 ? (long) first * rgb : 0l);
+    const int offA = count > 0 ? first * rgb : 0;
     const int fill_step = count > 0 ? RECB : 0;
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * fill_step, lane);
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
     TL_STAMP(pa.tl, 1);
     if (do_pro) { if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa); else BAMD_PRO_FINISH(ap, pa); }
     TL_STAMP(pa.tl, 2);
@@ -59,30 +61,31 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
     for (int r = 0; r < count; ++r) {
         const int rg = first + r * stride;
         const int row = rg * 8 + (lane >> 3);
-        const long rowoff = (long) rg * rgb;
+        const int rowoff = rg * rgb;
         float gate_val = 0.f;
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) {
-            const uint8_t * pbase = (part ? wB : wA) + rowoff;
             // after the last chunk of this row-part: the other half of the pair, the next row-group, or — at the very end of the
             // wave's stream — its own last record again, D times (step 0: one record of redundant traffic, never consumed; the
             // requests stay unconditional so that the waits stay counted)
             const bool last = !(PAIR && part == 0) && r + 1 >= count;
-            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
+            const bool after_b = (PAIR && part == 0) || (last && part == 1);
+            const int after_off = (PAIR && part == 0) ? rowoff : (last ? rowoff + (nb - 1) * RECB : rowoff + rg_step);
             // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
             float resv = 0.f;
             if (EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
             RowAcc A = { 0.f, 0.f };
             for (int c = 0; c < chunks; ++c) {
                 const bool inrow = c + 1 < chunks;
-                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const bamd_rsrc nrs = (inrow ? part == 1 : after_b) ? rsB : rsA;
+                const int nxt = inrow ? rowoff + (c + 1) * (D * RECB) : after_off;
                 const int step = (inrow || !last) ? RECB : 0;
 #pragma unroll
                 for (int s = 0; s < D; ++s) {
                     pin_rec(ring[s]);
                     const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
                     chain_step<TYPE>(A, T.d, T.fs, T.dmin, T.pm);
-                    load_rec(ring[s], nxt + s * step, lane);
+                    load_rec(ring[s], nrs, nxt + s * step, lane);
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1)
                         __builtin_amdgcn_sched_barrier(0);   // keep hipcc from clustering the refills at the loop tail
                 }
@@ -121,12 +124,13 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
                                              ActPro<PRO == BAMD_PRO_NORM> & ap, ActPro<PRO == BAMD_PRO_NORM> & ap2, bool issue_here, bool do_pro,
                                              float * part0, int & batchctr, int nvalid) {
-    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;     // bamd_record_bytes
     constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int r8 = lane >> 3, l4 = lane & 3;
-    const long rgb = (long) nb * RECB;
-    const long rg_step = (long) stride * rgb;
+    const bamd_rsrc rs = weight_rsrc(w);
+    const int rgb = nb * RECB;
+    const int rg_step = stride * rgb;
     const int i0 = wave * NBW;                               // this wave's first super-block inside a row
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
     // PLAIN prologue: wave w consumes only the activations of its own K-slice (blocks i0 .. i0+NBW-1), so it quantises exactly
@@ -139,7 +143,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     }
     // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
     // r0+M+m, i.e. a constant M*rg_step further on: the loader needs one wave-uniform base per batch and nothing per record
-    const uint8_t * bbase = w + (long) first * rgb + (long) i0 * RECB;
+    int bbase = first * rgb + i0 * RECB;
     REC ring[D];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -148,7 +152,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         // activation prologue would wait for the whole ring to land before it starts
         if (SMALLK || m < count) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], bbase + (long) m * rg_step + j * RECB, lane);
+            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs, bbase + m * rg_step + j * RECB, lane);
         }
     }
     TL_STAMP(pa.tl, 1);
@@ -180,7 +184,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                     pin_rec(ring[s]);
                     const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
                     P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
-                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], bbase + (long) (M + m) * rg_step + j * RECB, lane);
+                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + j * RECB, lane);
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1 || s == D - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -204,7 +208,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
             if (r0 == 0) TL_STAMP(pa.tl, 5);
         }
         batchctr += 1;
-        bbase += (long) M * rg_step;
+        bbase += M * rg_step;
         if (NBUF == 1 && r0 + M < count) __syncthreads();    // single term buffer: the chains must be done before the next batch writes
     }
 }

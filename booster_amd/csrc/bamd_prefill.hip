@@ -53,32 +53,33 @@ template <int TYPE, typename REC, int D, int EPI>
 __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb, int first, int count, int stride,
                                               float * __restrict__ out, const float * __restrict__ res, int ldo, int t0, int nt,
                                               const unsigned char * acts, size_t bb, int nvalid) {
-    constexpr int RECB = TYPE == BAMD_Q4_K ? 1152 : TYPE == BAMD_Q5_K ? 1408 : 1680;
+    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;     // bamd_record_bytes
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
     constexpr int NPARTS = PAIR ? 2 : 1;
     const int lane = threadIdx.x & 63;
-    const long rgb = (long) nb * RECB, rg_step = (long) stride * rgb;
+    const bamd_rsrc rsA = weight_rsrc(wA), rsB = PAIR ? weight_rsrc(wB) : rsA;
+    const int rgb = nb * RECB, rg_step = stride * rgb;
     const int chunks = nb / D;
     REC ring[D];
-    const uint8_t * rowA = wA + (long) first * rgb;
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_rec(ring[s], rowA + s * RECB, lane);
+    for (int s = 0; s < D; ++s) load_rec(ring[s], rsA, first * rgb + s * RECB, lane);
     for (int r = 0; r < count; ++r) {
         const int rg = first + r * stride;
         const int row = rg * 8 + (lane >> 3);
-        const long rowoff = (long) rg * rgb;
+        const int rowoff = rg * rgb;
         float gate_val[BAMD_TT];
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) {
-            const uint8_t * pbase = (part ? wB : wA) + rowoff;
             const bool last = !(PAIR && part == 0) && r + 1 >= count;
-            const uint8_t * after = (PAIR && part == 0) ? wB + rowoff : (last ? pbase + (long) (nb - 1) * RECB : wA + rowoff + rg_step);
+            const bool after_b = (PAIR && part == 0) || (last && part == 1);
+            const int after_off = (PAIR && part == 0) ? rowoff : (last ? rowoff + (nb - 1) * RECB : rowoff + rg_step);
             RowAcc A[BAMD_TT];
 #pragma unroll
             for (int u = 0; u < BAMD_TT; ++u) { A[u].acc = 0.f; A[u].accm = 0.f; }
             for (int c = 0; c < chunks; ++c) {
                 const bool inrow = c + 1 < chunks;
-                const uint8_t * nxt = inrow ? pbase + (long) (c + 1) * (D * RECB) : after;
+                const bamd_rsrc nrs = (inrow ? part == 1 : after_b) ? rsB : rsA;
+                const int nxt = inrow ? rowoff + (c + 1) * (D * RECB) : after_off;
                 const int step = (inrow || !last) ? RECB : 0;
 #pragma unroll
                 for (int s = 0; s < D; ++s) {
@@ -90,7 +91,7 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
                         const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
                         chain_step<TYPE>(A[u], T.d, T.fs, T.dmin, T.pm);
                     }
-                    load_rec(ring[s], nxt + s * step, lane);
+                    load_rec(ring[s], nrs, nxt + s * step, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -173,7 +174,7 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 // summs = summs + dmin * (float) sum_j m_j S_j (multiply, then add: ggml-quants.c:7515-7518), added after the hsum tree.
 template <int EPI, bool Q5>
 __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
-    constexpr uint32_t RECB = Q5 ? 1408u : 1152u, HDRO = Q5 ? 1280u : 1024u;
+    constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K, HDRO = Q5 ? 1280u : 1024u;      // bamd_record_bytes; header {d|dmin, sc[0..3], sc[4..7], mn[0..3]} + mn[4..7] at HDRO + 128
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef short s2_t __attribute__((ext_vector_type(2)));
@@ -209,7 +210,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
             lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
     const int rtc = live ? rt : 0;
-    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * RECB, * rec1 = rec0 + (size_t) nb * RECB;     // record groups of rows 0-7 / 8-15
+    // record groups of rows 0-7 / 8-15 of the tile; a last tile with only 8 (padded) rows reads its first group twice (rows 8-15 are never stored)
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * RECB, * rec1 = (rtc * 2 + 1) * 8 < a.nrows_pad ? rec0 + (size_t) nb * RECB : rec0;
     const uint8_t * hdrm = (m < 8 ? rec0 : rec1) + HDRO + (m & 7) * 16;                                    // header of row m (lanes g == 0)
     bamd_f4 acc[BAMD_MMA_NT][8], accm[BAMD_MMA_NT][4];
 #pragma unroll
@@ -221,7 +223,9 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     }
     // prologue: stage super-block 0, prefetch the weights of super-block 0
     BAMD_STAGE_ISSUE(0, 0);
+    const uint8_t * hdrm2 = (m < 8 ? rec0 : rec1) + HDRO + 128 + (m & 7) * 4;                              // its mins 4..7
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
+    uint32_t hd2 = BAMD_XSCALES ? *(const uint32_t *) hdrm2 : 0u;
     uint32_t qha = 0u, qhb = 0u;
     if (Q5) { qha = ldnt<uint32_t>(rec0, 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, 1024u + (uint32_t) lane * 4u); }
     lds_dma_wait();
@@ -236,7 +240,11 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
             *(uint4 *) (wl + 1 * 288 + r * 36 + e * 4) = wb;
             if (Q5) { qht[0 * 72 + r * 9 + e] = qha; qht[1 * 72 + r * 9 + e] = qhb; }
             if (g == 0) {                                    // lanes 0..15: row m
+#if BAMD_XSCALES
+                const uint32_t sc03 = hd.y, sc47 = hd.z, mn03 = hd.w, mn47 = hd2;     // unpacked by the load-time repack
+#else
                 uint32_t sc03, sc47, mn03, mn47; unpack_k4_(hd.y, hd.z, hd.w, sc03, sc47, mn03, mn47);
+#endif
                 uint4 h0, h1;
                 h0.x = hd.x; h0.y = sc03; h0.z = sc47; h0.w = 0u;
                 h1.x = __builtin_amdgcn_perm(0u, mn03, 0x0c010c00u); h1.y = __builtin_amdgcn_perm(0u, mn03, 0x0c030c02u);
@@ -250,7 +258,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
         {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * RECB;
-            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro);
+            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro); if (BAMD_XSCALES) hd2 = *(const uint32_t *) (hdrm2 + ro);
             if (Q5) { qha = ldnt<uint32_t>(rec0, ro + 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, ro + 1024u + (uint32_t) lane * 4u); }
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the math (the scheduler would sink it to the loop end)
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
         if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
             lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
     const int rtc = live ? rt : 0;
-    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = rec0 + (size_t) nb * 1680;
+    const uint8_t * rec0 = a.w + (size_t) (rtc * 2) * nb * 1680, * rec1 = (rtc * 2 + 1) * 8 < a.nrows_pad ? rec0 + (size_t) nb * 1680 : rec0;     // (a last tile of 8 rows: its first group twice)
     const uint8_t * recm = m < 8 ? rec0 : rec1;                                             // record group of row m (lanes g == 0)
     bamd_f4 acc[BAMD_MMA_NT][8];
 #pragma unroll
