@@ -12,9 +12,12 @@ LIB = os.path.join(HERE, "lib", "libbooster_amd.so")
 SOURCES = ["bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_prefill.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
 HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_device.h", "bamd_matvec_core.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
 # -ffp-contract=off: the numerics contract (bit-parity with the reference CPU path) forbids implicit FMA fusion.
-# -fno-slp-vectorize: SLP packs neighbouring f32 multiplies into v_pk_mul_f32, whose operands need even-aligned register pairs: the
-# copies it adds sit right behind the loads (a full s_waitcnt before the weight ring could be requested) and packed f32 is no faster here.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
+# -fno-slp-vectorize (decode kernels only, NO_SLP): SLP packs neighbouring f32 multiplies into v_pk_mul_f32, whose operands need
+# even-aligned register pairs: the copies it adds sit right behind the loads (a full s_waitcnt before the weight ring could be
+# requested) and packed f32 is no faster there.  The prefill kernels keep SLP: their f32 chains run on float4 accumulators, where
+# v_pk_fma_f32 halves the instruction count (same IEEE fma per element).
+NO_SLP = ("bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 LIB_TIMING = os.path.join(HERE, "lib", "libbooster_amd_timing.so")      # -DBAMD_TIMING: kernels write phase stamps (tools/timeline.py)
@@ -46,7 +49,7 @@ def build(force=False, verbose=False, timing=False, variant=None, extra=()):
             continue
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + (["-DBAMD_TIMING"] if timing else []) + list(extra) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-fno-slp-vectorize"] if s in NO_SLP else []) + (["-DBAMD_TIMING"] if timing else []) + list(extra) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

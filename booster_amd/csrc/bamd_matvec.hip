@@ -279,6 +279,7 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
     if (grid > nrg) grid = nrg;
     if (grid < 1) grid = 1;
     const bool generic = g_mv_generic || a.mode >= 16;       // mode bit 4: force the generic kernels (tests)
+    if (!generic && mixed && fmode == 0 && can_split && bamd_launch_fast_mixed(a, pro, epi, grid, s)) return;
     if (split) {
         if (!generic && bamd_launch_fast_b(a, pro, epi, grid, s)) return;
         if (pro == BAMD_PRO_NORM) launch_mv_split<BAMD_PRO_NORM>(a, epi, grid, s);

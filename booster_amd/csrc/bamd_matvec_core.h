@@ -217,3 +217,4 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
 // host-side dispatch of the fast kernels (bamd_matvec_fast_a.hip / _b.hip); false = no instance for this shape: generic kernel
 bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);
 bool bamd_launch_fast_b(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);
+bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s);

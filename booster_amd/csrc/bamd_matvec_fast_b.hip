@@ -26,6 +26,127 @@ __global__ void __launch_bounds__(512) matvec_split_fast_kernel(bamd_mv_args a) 
 }
 
 
+// ---- fused QKV with a differently typed attn_v (wq|wk Q4_K + wv Q6_K / Q5_K): split-K over BOTH segments in one pass -------------
+// Every workgroup takes MA row-groups of segment 0 (type TA) and ONE more row-group that is of type TA (still segment 0) or of
+// type TB (segment 1) depending on the workgroup: all MA + 1 rings are requested at entry, all terms are parked in one batch, waves
+// 0..MA replay one chain each.  The type of the last row-group is a template parameter and the kernel branches on it ONCE, right
+// after the activation requests, so that each side is straight-line code with counted waits.  (Through mode A this launch ran on 3
+// of 8 waves per CU, 16 records each: 10 us against 6.4 us for the all-Q4_K layers.)
+template <int TA, int TB, int NBW, int MA>
+__device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const ProArgs & pa, ActPro<true> & ap, float * part0, int g_last) {
+    typedef typename RecOf<TA>::type RECA;
+    typedef typename RecOf<TB>::type RECB_T;
+    constexpr int RA = TA == BAMD_Q4_K ? BAMD_RECB_Q4K : TA == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
+    constexpr int RB = TB == BAMD_Q4_K ? BAMD_RECB_Q4K : TB == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
+    constexpr bool SAME = TA == TB;                          // the last row-group still belongs to segment 0
+    const int nb = pa.K >> 8;
+    const int lane = threadIdx.x & 63, wave = wave_id(), r8 = lane >> 3;
+    const int i0 = wave * NBW, grid = (int) gridDim.x, b = (int) blockIdx.x;
+    const int nrg0 = a.seg[0].nrows >> 3;
+    const bamd_rsrc rs0 = weight_rsrc(a.seg[0].w), rs1 = weight_rsrc(SAME ? a.seg[0].w : a.seg[1].w);
+    const int rgbA = nb * RA, rgbB = nb * RB;
+    RECA ring[MA * NBW]; RECB_T ringL[NBW];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs0, (b + m * grid) * rgbA + (i0 + j) * RA, lane);
+    const int lastoff = SAME ? g_last * rgbA : (g_last - nrg0) * rgbB;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) load_rec(ringL[j], rs1, lastoff + (i0 + j) * RB, lane);
+    TL_STAMP(pa.tl, 1);
+    BAMD_PRO_FINISH_SMALLK(ap, pa);
+    TL_STAMP(pa.tl, 2);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    const size_t rg_floats = BAMD_TERM_FLOATS(nb);
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+        float4 * P = (float4 *) (part0 + (size_t) m * rg_floats);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            pin_rec(ring[m * NBW + j]);
+            const Terms T = block_terms(ring[m * NBW + j], i0 + j, lane, q8, S, yd);
+            P[(i0 + j) * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+        }
+    }
+    {
+        float4 * P = (float4 *) (part0 + (size_t) MA * rg_floats);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            pin_rec(ringL[j]);
+            const Terms T = block_terms(ringL[j], i0 + j, lane, q8, S, yd);
+            P[(i0 + j) * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+        }
+    }
+    TL_STAMP(pa.tl, 3);
+    __syncthreads();
+    TL_STAMP(pa.tl, 4);
+    if (wave <= MA) {                                        // one chain per wave, in the reference's order (split_stream)
+        const float4 * P = (const float4 *) (part0 + (size_t) wave * rg_floats);
+        const bool lastw = wave == MA;
+        RowAcc A = { 0.f, 0.f };
+        float val;
+        if (SAME || !lastw) {
+            for (int i = 0; i < nb; i += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) chain_step<TA>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+            }
+            val = finish_row<TA>(A);
+        } else {
+            for (int i = 0; i < nb; i += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) chain_step<TB>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+            }
+            val = finish_row<TB>(A);
+        }
+        const bool in1 = !SAME && lastw;
+        const int row = in1 ? (g_last - nrg0) * 8 + r8 : ((lastw ? g_last : b + wave * grid) * 8 + r8);
+        const bamd_mv_seg & sg = a.seg[in1 ? 1 : 0];
+        const int nv = sg.nvalid > 0 ? sg.nvalid : sg.nrows;
+        if ((lane & 7) == 0 && row < nv) sg.out[row] = val;
+        TL_STAMP(pa.tl, 5);
+    }
+}
+template <int TA, int TB, int NBW, int MA>
+__global__ void __launch_bounds__(512) matvec_split_mixed_kernel(bamd_mv_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TL_STAMP(a.tl, 0);
+    const int nb = a.K >> 8;
+    const ProArgs pa = carve_lds(a, smem);
+    ActPro<true> ap;
+    BAMD_PRO_ISSUE(ap, pa);
+    float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double));
+    const int g_last = MA * (int) gridDim.x + (int) blockIdx.x;       // index of this workgroup's last row-group in the concatenated segments
+    if (g_last < (a.seg[0].nrows >> 3)) split_mixed_body<TA, TA, NBW, MA>(a, pa, ap, part0, g_last);
+    else                                split_mixed_body<TA, TB, NBW, MA>(a, pa, ap, part0, g_last);
+    TL_STAMP(a.tl, 7);
+}
+template <int TA, int TB, int NBW, int MA>
+static void launch_mixed_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
+    const int nb = a.K >> 8;
+    const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (MA + 1) * nb * 256 * 4;
+    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA>), dim3(grid), dim3(512), lds, s, a);
+}
+// fused QKV launch with two differently typed segments; false: shape not covered (mode A takes it)
+bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s) {
+    static const bool on = [] { const char * e = getenv("BAMD_MIXED_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on || pro != BAMD_PRO_NORM || epi != BAMD_EPI_STORE || a.nseg != 2) return false;
+    const int nb = a.K >> 8, t0 = a.seg[0].type, t1 = a.seg[1].type;
+    const int nrg0 = a.seg[0].nrows >> 3, nrg1 = a.seg[1].nrows >> 3;
+    if ((nb & 7) != 0 || nb > 8 * BAMD_ACT_BATCH || t0 == t1 || grid < 1 || (nrg0 + nrg1) % grid) return false;
+    const int cnt = (nrg0 + nrg1) / grid, nbw = nb >> 3;
+    if (cnt != 3 || nrg0 < 2 * grid || nbw != 2) return false;                  // the Llama-3-8B / Mistral-7B shape: K = 4096, three row-groups per workgroup
+#define BAMD_MX(TA_, TB_) if (t0 == TA_ && t1 == TB_) { launch_mixed_inst<TA_, TB_, 2, 2>(a, grid, s); return true; }
+    BAMD_MX(BAMD_Q4_K, BAMD_Q6_K) BAMD_MX(BAMD_Q4_K, BAMD_Q5_K) BAMD_MX(BAMD_Q5_K, BAMD_Q6_K)
+#undef BAMD_MX
+    return false;
+}
+
 template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false>
 static void launch_fast_b_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;

@@ -12,10 +12,10 @@
 // ===========================================================================================================
 
 // one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
-// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block 528 B: 8 (e) x 4 (g) groups of 8 halves — group (e, g) = the
-// int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane — followed by
-// the four i16 pairs (S_2l, S_2l+1) of the block sums; after the nb super-blocks, yd[nb] f32.  (528 B = 132 dwords: the MFMA
-// kernel stages these records in LDS, and 132 = 4 mod 64 makes its 16-byte reads bank-conflict free.)
+// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block BAMD_B16_REC = 560 B: 8 (e) x 4 (g) groups of 8 halves — group
+// (e, g) = the int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane —
+// then, per pair l of sub-blocks, the four halves {S_h(2l), S_h(2l+1), S_l(2l), S_l(2l+1)} of the block sums split as S = 2 S_h + S_l
+// (the B operand of the Q4_K min-term MFMA), then the four i16 pairs (S_2l, S_2l+1) (Q5_K); after the nb super-blocks, yd[nb] f32.
 template <bool NORM>
 __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
                                                              uint8_t * __restrict__ blob, uint8_t * __restrict__ blob16) {
@@ -39,9 +39,16 @@ __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __res
             uint2 v; v.x = (uint32_t) h0 | ((uint32_t) h1 << 16); v.y = (uint32_t) h2 | ((uint32_t) h3 << 16);
             *(uint2 *) (o + (size_t) ci * BAMD_B16_REC + (size_t) (e * 4 + (c >> 1)) * 16 + (c & 1) * 8) = v;
         }
-        for (int i = threadIdx.x; i < nb * 4; i += blockDim.x) {           // (S_2l, S_2l+1) as i16 pairs: |S| <= 32 * 127
+        for (int i = threadIdx.x; i < nb * 4; i += blockDim.x) {
             const int ci = i >> 2, l = i & 3;
-            *(uint32_t *) (o + (size_t) ci * BAMD_B16_REC + 512 + l * 4) = ((uint32_t) S[ci * 8 + 2 * l] & 0xffffu) | ((uint32_t) S[ci * 8 + 2 * l + 1] << 16);
+            const int sa = S[ci * 8 + 2 * l], sb = S[ci * 8 + 2 * l + 1];          // block sums of sub-blocks 2l, 2l+1: |S| <= 32 * 127
+            // operands of the min-term MFMA (Q4_K): S = 2 S_h + S_l with S_h = S >> 1 (|.| <= 2048) and S_l = S & 1 both exact in f16
+            uint2 mf;
+            mf.x = (uint32_t) f2h((float) (sa >> 1)) | ((uint32_t) f2h((float) (sb >> 1)) << 16);
+            mf.y = (uint32_t) f2h((float) (sa & 1)) | ((uint32_t) f2h((float) (sb & 1)) << 16);
+            *(uint2 *) (o + (size_t) ci * BAMD_B16_REC + 512 + l * 8) = mf;
+            // (S_2l, S_2l+1) as i16 pairs (Q5_K: v_dot2_i32_i16)
+            *(uint32_t *) (o + (size_t) ci * BAMD_B16_REC + 544 + l * 4) = ((uint32_t) sa & 0xffffu) | ((uint32_t) sb << 16);
         }
         float * oyd = (float *) (o + (size_t) nb * BAMD_B16_REC);
         for (int i = threadIdx.x; i < nb; i += blockDim.x) oyd[i] = yd[i];
@@ -120,6 +127,7 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
 // MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3);
 // C/D rows 4g + i, token m (cdna_hip_programming.md, fragment layout).  One wave = 16 rows x 16 tokens over the whole K.
 typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bamd_h4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void * bamd_lds_vp;
 typedef const __attribute__((address_space(1))) void * bamd_glb_vp;
 // global -> LDS copy without registers: each active lane moves 16 (4) bytes from ITS global address to LDS base + lane * 16 (4).
@@ -188,15 +196,15 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
     uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
     uint32_t * qht = hl + 16 * 8;                                            // Q5_K: high-bit dwords [2][8 rows][9] (row stride padded)
-    // staging plan: 33 uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
+    // staging plan: BAMD_B16_Q uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
     // Per-thread source offsets, fixed over the K loop.  The records go global -> LDS directly (global_load_lds_dwordx4: each wave's 64
     // lanes fill 1 KiB of consecutive LDS, the source address is per lane), so the stage costs no registers and no ds_write pass; the
     // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
     // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
     // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
-    const bool third = tid + 1024 < BAMD_MMA_TOK * 33;
+    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q;
     auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
-        const int tok = idx / 33, q = idx - tok * 33;
+        const int tok = idx / BAMD_B16_Q, q = idx - tok * BAMD_B16_Q;
         const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
         return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
@@ -234,6 +242,11 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
         // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
+        // Q4_K min terms on the matrix core: pm_l = m_2l S_2l + m_2l+1 S_2l+1 with S = 2 S_h + S_l is the 4-term dot product
+        // {2 m_2l, 2 m_2l+1, m_2l, m_2l+1} . {S_h(2l), S_h(2l+1), S_l(2l), S_l(2l+1)}: every factor and every partial sum an exact f16 /
+        // f32 integer.  A operand of v_mfma_f32_16x16x16f16: lanes g == 0 (k = 0..3) carry row m's four halves, the other k-groups zeros
+        // — and lane (m, 0) is the lane that unpacks row m's header anyway.  (Was 16 v_dot2_i32_i16 + 16 conversions per token tile.)
+        uint2 amin[4] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
         {
             const int r = lane >> 3, e = lane & 7;           // wave-stream lane' = (row r of its record group, chunk e)
             *(uint4 *) (wl + 0 * 288 + r * 36 + e * 4) = wa;
@@ -250,6 +263,17 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 h1.x = __builtin_amdgcn_perm(0u, mn03, 0x0c010c00u); h1.y = __builtin_amdgcn_perm(0u, mn03, 0x0c030c02u);
                 h1.z = __builtin_amdgcn_perm(0u, mn47, 0x0c010c00u); h1.w = __builtin_amdgcn_perm(0u, mn47, 0x0c030c02u);
                 *(uint4 *) (hl + m * 8) = h0; *(uint4 *) (hl + m * 8 + 4) = h1;
+                if (!Q5) {
+                    const h2_t k1024 = { (_Float16) 1024.f, (_Float16) 1024.f };
+                    const uint32_t sel[2] = { 0x04010400u, 0x04030402u };
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) {           // (1024 + m_a, 1024 + m_b) by byte permute, minus 1024: the pair as exact f16
+                        union { uint32_t u; h2_t h; } c, one, two;
+                        c.u = __builtin_amdgcn_perm(0x64646464u, l < 2 ? mn03 : mn47, sel[l & 1]);
+                        one.h = c.h - k1024; two.h = one.h + one.h;
+                        amin[l].x = two.u; amin[l].y = one.u;
+                    }
+                }
             }
         }
         // the next stage and the next weights in flight during the math (at the end: this super-block again, the stage into the idle
@@ -317,25 +341,31 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        // min terms: pm_l = m_2l S_2l + m_2l+1 S_2l+1 (one v_dot2_i32_i16); accm_l = fma(dmin, pm_l, accm_l)   (:6937-6941)
+        // min terms: pm_l = m_2l S_2l + m_2l+1 S_2l+1; accm_l = fma(dmin, pm_l, accm_l)   (:6937-6941)
 #pragma unroll
         for (int n = 0; n < BAMD_MMA_NT; ++n) {
-            const uint4 sp = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 512);
-            const uint32_t spl[4] = { sp.x, sp.y, sp.z, sp.w };
+            if (Q5) {
+                const uint4 sp = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 544);
+                const uint32_t spl[4] = { sp.x, sp.y, sp.z, sp.w };
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t mpl[4] = { mp[i].x, mp[i].y, mp[i].z, mp[i].w };
-                if (Q5) {
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t mpl[4] = { mp[i].x, mp[i].y, mp[i].z, mp[i].w };
                     int hs = 0;
 #pragma unroll
                     for (int l = 0; l < 4; ++l) { union { uint32_t u; s2_t v; } ma, sb; ma.u = mpl[l]; sb.u = spl[l]; hs = __builtin_amdgcn_sdot2(ma.v, sb.v, hs, false); }
                     const float t = Dm[n][i] * (float) hs;
                     accm[n][0][i] = accm[n][0][i] + t;
-                } else {
-                    float pm[4];
-                    dot2x4_f32(mpl, spl, pm);
+                }
+            } else {
+                const uint4 sfa = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 512), sfb = *(const uint4 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + 528);
+                const uint2 bl[4] = { { sfa.x, sfa.y }, { sfa.z, sfa.w }, { sfb.x, sfb.y }, { sfb.z, sfb.w } };
 #pragma unroll
-                    for (int l = 0; l < 4; ++l) accm[n][l][i] = fmaf(Dm[n][i], pm[l], accm[n][l][i]);
+                for (int l = 0; l < 4; ++l) {
+                    union { uint2 u; bamd_h4 h; } av4, bv4; av4.u = amin[l]; bv4.u = bl[l];
+                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                    const bamd_f4 pm = __builtin_amdgcn_mfma_f32_16x16x16f16(av4.h, bv4.h, z, 0, 0, 0);     // rows 4g + i, token m: exact integers
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accm[n][l][i] = fmaf(Dm[n][i], pm[i], accm[n][l][i]);
                 }
             }
         }
@@ -387,9 +417,9 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
     // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
     // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
     // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
-    const bool third = tid + 1024 < BAMD_MMA_TOK * 33;
+    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q;
     auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
-        const int tok = idx / 33, q = idx - tok * 33;
+        const int tok = idx / BAMD_B16_Q, q = idx - tok * BAMD_B16_Q;
         const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
         return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
