@@ -1,6 +1,7 @@
 // bamd_prefill.hip — batched prefill: per-token Q8_K quantisation into global blobs, the exact MFMA mat-mul kernels (Q4_K, Q6_K),
 // the integer-dot batched mat-mul (any K-quant), batched embedding, silu*up.  Helpers: bamd_device.h.
 #include "bamd_device.h"
+#include <type_traits>
 
 // ===========================================================================================================
 // Batched prefill (T > 1 tokens per call; reference: llama_decode with a micro-batch, ggml_compute_forward_mul_mat with
@@ -175,6 +176,7 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 #define BAMD_MMA_NT 2
 #define BAMD_MMA_TOK (16 * BAMD_MMA_NT)
 #define BAMD_MMA_STAGE (BAMD_MMA_TOK * BAMD_B16_REC + BAMD_MMA_TOK * 4)          /* B records + yd */
+#define BAMD_MMA_NSTAGE 4                                                        /* stage buffers of the Q4_K / Q5_K kernel (one barrier per two super-blocks) */
 #define BAMD_MMA_WAVE_LDS (2 * 288 * 4 + 16 * 32 + 2 * 72 * 4)                   /* transposed A tile + row headers + Q5_K high-bit tile */
 // Q5 = true: Q5_K records (1408 B: + one dword of high bits per lane).  The fifth bit joins the nibble before the f16 build
 // (values <= 31, scale x value <= 1953: exact); (1024 + n) * s would overflow f16 at s = 63, so the bias is subtracted first (exact)
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     const int t0 = blockIdx.x * BAMD_MMA_TOK;
     const size_t b16 = BAMD_BLOB16_BYTES(nb);
     unsigned char * stage = smem;                                            // [2][BAMD_MMA_STAGE]
-    uint32_t * wl = (uint32_t *) (smem + 2 * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
+    uint32_t * wl = (uint32_t *) (smem + BAMD_MMA_NSTAGE * BAMD_MMA_STAGE + wave * BAMD_MMA_WAVE_LDS);   // this wave's A tile [2][288] dwords
     uint32_t * hl = wl + 2 * 288;                                            // this wave's row headers [16][8] dwords
     uint32_t * qht = hl + 16 * 8;                                            // Q5_K: high-bit dwords [2][8 rows][9] (row stride padded)
     // staging plan: BAMD_B16_Q uint4 per token record, BAMD_MMA_TOK tokens; tokens past T repeat the last one (never stored)
@@ -229,8 +231,12 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
 #pragma unroll
         for (int l = 0; l < 4; ++l) accm[n][l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
     }
-    // prologue: stage super-block 0, prefetch the weights of super-block 0
+    // prologue: stage super-blocks 0 and 1, prefetch the weights of super-block 0.  FOUR stage buffers, one workgroup barrier per
+    // TWO super-blocks: at the top of an even iteration ci the records of ci + 2 and ci + 3 are requested into the two buffers every
+    // wave left at the last barrier; the barrier at the end of ci + 1 publishes them.  (The wave-private tiles wl / hl need no
+    // barrier: one wave's LDS operations execute in order.)
     BAMD_STAGE_ISSUE(0, 0);
+    BAMD_STAGE_ISSUE(nb > 1 ? 1 : 0, 1);
     const uint8_t * hdrm2 = (m < 8 ? rec0 : rec1) + HDRO + 128 + (m & 7) * 4;                              // its mins 4..7
     uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
     uint32_t hd2 = BAMD_XSCALES ? *(const uint32_t *) hdrm2 : 0u;
@@ -238,8 +244,9 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     if (Q5) { qha = ldnt<uint32_t>(rec0, 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, 1024u + (uint32_t) lane * 4u); }
     lds_dma_wait();
     __syncthreads();
-    for (int ci = 0; ci < nb; ++ci) {
-        const unsigned char * st = stage + (size_t) (ci & 1) * BAMD_MMA_STAGE;
+    auto step = [&](const int ci, auto even_tag) {
+        constexpr bool EVEN = decltype(even_tag)::value;      // compile-time: the even half issues the next two stages, the odd half ends with the barrier
+        const unsigned char * st = stage + (size_t) (ci & 3) * BAMD_MMA_STAGE;
         const bool more = ci + 1 < nb;
         // ---- weights of this super-block: transpose into the A layout, unpack the row headers once ----
         // Q4_K min terms on the matrix core: pm_l = m_2l S_2l + m_2l+1 S_2l+1 with S = 2 S_h + S_l is the 4-term dot product
@@ -279,7 +286,10 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         // the next stage and the next weights in flight during the math (at the end: this super-block again, the stage into the idle
         // buffer).  Issued AFTER the registers of the previous prefetch were consumed: with a global_load_lds in flight the compiler
         // waits vmcnt(0) at the next use of an ordinary load result, which would otherwise sit right behind the issue.
-        BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);
+        if (EVEN) {
+            BAMD_STAGE_ISSUE(ci + 2 < nb ? ci + 2 : nb - 1, (ci + 2) & 3);
+            BAMD_STAGE_ISSUE(ci + 3 < nb ? ci + 3 : nb - 1, (ci + 3) & 3);
+        }
         {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * RECB;
             wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro); if (BAMD_XSCALES) hd2 = *(const uint32_t *) (hdrm2 + ro);
@@ -369,8 +379,14 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                 }
             }
         }
-        lds_dma_wait();
-        __syncthreads();                                     // next stage visible; this stage and the wave tiles free again
+        if (!EVEN) {
+            lds_dma_wait();
+            __syncthreads();                                 // the next two stages visible; the two just read free again
+        }
+    };
+    for (int ci = 0; ci < nb; ci += 2) {
+        step(ci, std::true_type());
+        if (ci + 1 < nb) step(ci + 1, std::false_type());    // (an odd K / 256 ends on an even step: nothing reads the stages after it)
     }
     if (!live) return;
     // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
@@ -641,7 +657,7 @@ int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrow
         else     hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds6, s, a);
         return 0;
     }
-    const size_t lds = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
+    const size_t lds = BAMD_MMA_NSTAGE * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
     if (type == BAMD_Q5_K) {
         if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD, true>),   grid, dim3(512), lds, s, a);
         else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE, true>), grid, dim3(512), lds, s, a);
