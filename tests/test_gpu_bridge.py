@@ -12,8 +12,7 @@ from booster_amd import gguf
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def lib(bamd):
+def bind(bamd):
     L = bamd.lib()
     f, i, u = C.c_float, C.c_int, C.c_uint32
     L.init.argtypes = [C.c_char_p, C.c_char_p]; L.init.restype = None
@@ -27,6 +26,11 @@ def lib(bamd):
     L.getSeed.restype = C.c_uint32; L.getSeed.argtypes = [C.c_char_p]
     L.bamd_bridge_tokenize.argtypes = [C.c_void_p, C.c_char_p, i, i, C.c_void_p, i]
     return L
+
+
+@pytest.fixture(scope="module")
+def lib(bamd):
+    return bind(bamd)
 
 
 def make_model(tmp_path, name):
@@ -169,12 +173,16 @@ def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
     "three stages": the same session through Booster's layer split — BOOSTER_GPUS=2,1,1 over three devices (virtual ones on a box
     with fewer GPUs: BAMD_VIRTUAL_DEVICES), i.e. the event-ordered multi-stage path with its hand-off copies and stage graphs —
     must give the reference's results unchanged."""
-    import json
-    import os
     if split == "three stages":
         monkeypatch.setenv("BOOSTER_GPUS", "2,1,1")
         if bamd.device_count() < 3:
             monkeypatch.setenv("BAMD_VIRTUAL_DEVICES", "3")
+    replay_transcript(lib, bamd, tmp_path, split[:3])
+
+
+def replay_transcript(lib, bamd, tmp_path, tag):
+    import json
+    import os
     t = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "abi_transcript.json")))
     vocab = gguf.synthetic_janus_vocab(t["n_vocab"])
     path = str(tmp_path / "abi.gguf")
@@ -192,18 +200,18 @@ def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
             lib.init(b"", b"")
         elif op == "infer":
             idx = int(p[1]); pod = pod_of[idx]
-            got = lib.doInference(pod, ctxs[idx], ("abi-%s-" % split[:3] + p[2]).encode(), b"sess", bytes.fromhex(p[3]))
+            got = lib.doInference(pod, ctxs[idx], ("abi-%s-" % tag + p[2]).encode(), b"sess", bytes.fromhex(p[3]))
             assert got == want["ret"], "%s: doInference returned %d, the reference %d" % (line[:40], got, want["ret"])
         elif op == "status":
-            got = lib.status(("abi-%s-" % split[:3] + p[1]).encode())
+            got = lib.status(("abi-%s-" % tag + p[1]).encode())
             assert got == bytes.fromhex(want["hex"]), "%s: status() differs\n ours %r\n ref  %r" % (line, got, bytes.fromhex(want["hex"]))
         elif op == "count":
-            assert lib.getPromptTokenCount(("abi-%s-" % split[:3] + p[1]).encode()) == want["ret"], line
+            assert lib.getPromptTokenCount(("abi-%s-" % tag + p[1]).encode()) == want["ret"], line
         elif op == "stop":
             lib.stopInference(pod_of[int(p[1])])
         elif op == "seed":
-            assert (lib.getSeed(("abi-%s-" % split[:3] + p[1]).encode()) != 0) == bool(want["nonzero"])
+            assert (lib.getSeed(("abi-%s-" % tag + p[1]).encode()) != 0) == bool(want["nonzero"])
         elif op == "evalms":
-            assert (lib.promptEval(("abi-%s-" % split[:3] + p[1]).encode()) >= 0) == bool(want["nonneg"])
+            assert (lib.promptEval(("abi-%s-" % tag + p[1]).encode()) >= 0) == bool(want["nonneg"])
         elif op == "genms":
-            assert (lib.timing(("abi-%s-" % split[:3] + p[1]).encode()) >= 0) == bool(want["nonneg"])
+            assert (lib.timing(("abi-%s-" % tag + p[1]).encode()) >= 0) == bool(want["nonneg"])
