@@ -65,4 +65,4 @@ def build(force=False, verbose=False, timing=False, variant=None, extra=()):
 
 if __name__ == "__main__":
     _v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, timing="--timing" in sys.argv, variant=_v, extra=[a for a in sys.argv[1:] if a.startswith("-D")]))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, timing="--timing" in sys.argv, variant=_v, extra=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-f") or a.startswith("-m")]))

@@ -6,14 +6,15 @@
 // ===========================================================================================================
 // Batched prefill (T > 1 tokens per call; reference: llama_decode with a micro-batch, ggml_compute_forward_mul_mat with
 // ne11 = T, ggml.c:12277-12492).  Per (row, token) the arithmetic is EXACTLY the single-token chain above — the reference
-// quantises each activation row to Q8_K and runs the same vec_dot per (row, column) — so the batched kernels reuse
-// block_terms / chain_step / finish_row unchanged and differ only in data movement: the weights of a record are unpacked once
-// and used for BAMD_TT tokens whose Q8_K activations sit in LDS.  (An MFMA formulation that keeps the per-lane chains exact —
-// f16 A = scale x quant, one 32-deep MFMA per SIMD lane e — is the next step; see DESIGN.md.)
+// quantises each activation row to Q8_K and runs the same vec_dot per (row, column).  Two implementations, bit-identical:
+//   matmul_mfma_q4k_kernel / matmul_mfma_q6k_kernel (default): the integer sums of a super-block on the matrix cores, exactly — f16
+//     A = scale x quant, f16 B = the int8 activations, one 32-deep MFMA per SIMD lane e of the reference — and the f32 chains on the VALU;
+//   matmul_batch_kernel (BAMD_PREFILL_MFMA=0; the second implementation the first is tested against): block_terms / chain_step /
+//     finish_row of the decode path, the weights of a record unpacked once for BAMD_TT tokens whose Q8_K activations sit in LDS.
 // ===========================================================================================================
 
 // one workgroup per token: RMSNorm (optional) + Q8_K of row t of x[T][K] -> blob[t]
-// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block BAMD_B16_REC = 560 B: 8 (e) x 4 (g) groups of 8 halves — group
+// f16 copy of a token's Q8_K row for the MFMA path.  Per super-block BAMD_B16_REC = 608 B (560 used): 8 (e) x 4 (g) groups of 8 halves — group
 // (e, g) = the int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane —
 // then, per pair l of sub-blocks, the four halves {S_h(2l), S_h(2l+1), S_l(2l), S_l(2l+1)} of the block sums split as S = 2 S_h + S_l
 // (the B operand of the Q4_K min-term MFMA), then the four i16 pairs (S_2l, S_2l+1) (Q5_K); after the nb super-blocks, yd[nb] f32.
@@ -174,6 +175,17 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 //     16 row headers ONCE (d, dmin, scales, mins as i16 pairs) into LDS for the other lanes;
 //   - 8 (e) x 2 (token tiles) MFMAs; chains, min terms (v_dot2_i32_i16) and the final trees on the VALU.
 #define BAMD_MMA_NT 2
+#ifndef BAMD_MMA_NTLOADS
+#define BAMD_MMA_NTLOADS 0                                                       /* weight loads of the MFMA kernels: default cache policy — the 16 token tiles of a row block re-read
+                                                                                    the same records through L2 (nt: 246 vs 253 TFLOP/s at 512 tokens) */
+#endif
+template <typename T> __device__ __forceinline__ T ldw(const uint8_t * rec, uint32_t off) {
+#if BAMD_MMA_NTLOADS
+    return ldnt<T>(rec, off);
+#else
+    return *(const T *) (rec + off);
+#endif
+}
 #define BAMD_MMA_TOK (16 * BAMD_MMA_NT)
 #define BAMD_MMA_STAGE (BAMD_MMA_TOK * BAMD_B16_REC + BAMD_MMA_TOK * 4)          /* B records + yd */
 #define BAMD_MMA_NSTAGE 4                                                        /* stage buffers of the Q4_K / Q5_K kernel (one barrier per two super-blocks) */
@@ -238,10 +250,10 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     BAMD_STAGE_ISSUE(0, 0);
     BAMD_STAGE_ISSUE(nb > 1 ? 1 : 0, 1);
     const uint8_t * hdrm2 = (m < 8 ? rec0 : rec1) + HDRO + 128 + (m & 7) * 4;                              // its mins 4..7
-    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
+    uint4 wa = ldw<uint4>(rec0, (uint32_t) lane * 16u), wb = ldw<uint4>(rec1, (uint32_t) lane * 16u), hd = *(const uint4 *) hdrm;
     uint32_t hd2 = BAMD_XSCALES ? *(const uint32_t *) hdrm2 : 0u;
     uint32_t qha = 0u, qhb = 0u;
-    if (Q5) { qha = ldnt<uint32_t>(rec0, 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, 1024u + (uint32_t) lane * 4u); }
+    if (Q5) { qha = ldw<uint32_t>(rec0, 1024u + (uint32_t) lane * 4u); qhb = ldw<uint32_t>(rec1, 1024u + (uint32_t) lane * 4u); }
     lds_dma_wait();
     __syncthreads();
     auto step = [&](const int ci, auto even_tag) {
@@ -292,8 +304,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
         }
         {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * RECB;
-            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro); if (BAMD_XSCALES) hd2 = *(const uint32_t *) (hdrm2 + ro);
-            if (Q5) { qha = ldnt<uint32_t>(rec0, ro + 1024u + (uint32_t) lane * 4u); qhb = ldnt<uint32_t>(rec1, ro + 1024u + (uint32_t) lane * 4u); }
+            wa = ldw<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldw<uint4>(rec1, ro + (uint32_t) lane * 16u); hd = *(const uint4 *) (hdrm + ro); if (BAMD_XSCALES) hd2 = *(const uint32_t *) (hdrm2 + ro);
+            if (Q5) { qha = ldw<uint32_t>(rec0, ro + 1024u + (uint32_t) lane * 4u); qhb = ldw<uint32_t>(rec1, ro + 1024u + (uint32_t) lane * 4u); }
         }
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the math (the scheduler would sink it to the loop end)
         // headers of the four C rows 4g + i; d products per token tile
@@ -321,9 +333,26 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
             const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
             const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
             const uint32_t * wrow = wl + (m >> 3) * 288 + (m & 7) * 36 + g;
+            // software pipeline over e, written out: the LDS operands of e + 2 are requested at the top of iteration e and the MFMA results
+            // of e - 1 are folded into the chains in iteration e; a scheduling barrier per iteration keeps that order (left alone, the
+            // scheduler requests an operand one iteration ahead — ~70 cycles for an LDS latency of 130+ under eight waves — and every
+            // iteration of every wave waits).
+            uint32_t Wq[3]; bamd_h8 Bq[3][BAMD_MMA_NT]; bamd_f4 sprev[BAMD_MMA_NT];
+#define BAMD_LDB(e_, n_) (*(const bamd_h8 *) (st + (size_t) ((n_) * 16 + m) * BAMD_B16_REC + ((e_) * 4 + g) * 16))
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                Wq[e] = wrow[e * 4];
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) Bq[e][n] = BAMD_LDB(e, n);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const uint32_t wq = wrow[e * 4];
+                if (e + 2 < 8) {
+                    Wq[(e + 2) % 3] = wrow[(e + 2) * 4];
+#pragma unroll
+                    for (int n = 0; n < BAMD_MMA_NT; ++n) Bq[(e + 2) % 3][n] = BAMD_LDB(e + 2, n);
+                }
+                const uint32_t wq = Wq[e % 3];
                 uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
                 if (Q5) {                                    // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
                     const uint32_t qh = qht[(m >> 3) * 72 + (m & 7) * 9 + e];
@@ -341,15 +370,26 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                     a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2); a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
                 }
                 const bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
+                bamd_f4 si[BAMD_MMA_NT];
 #pragma unroll
                 for (int n = 0; n < BAMD_MMA_NT; ++n) {
-                    const bamd_h8 bv = *(const bamd_h8 *) (st + (size_t) (n * 16 + m) * BAMD_B16_REC + (e * 4 + g) * 16);
                     const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
-                    const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, z, 0, 0, 0);
+                    si[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, Bq[e % 3][n], z, 0, 0, 0);
+                    if (e > 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], si[i], acc[n][e][i]);
+                        for (int i = 0; i < 4; ++i) acc[n][e - 1][i] = fmaf(D[n][i], sprev[n][i], acc[n][e - 1][i]);
+                    }
                 }
+#pragma unroll
+                for (int n = 0; n < BAMD_MMA_NT; ++n) sprev[n] = si[n];
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int n = 0; n < BAMD_MMA_NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[n][7][i] = fmaf(D[n][i], sprev[n][i], acc[n][7][i]);
+            }
+#undef BAMD_LDB
         }
         // min terms: pm_l = m_2l S_2l + m_2l+1 S_2l+1; accm_l = fma(dmin, pm_l, accm_l)   (:6937-6941)
 #pragma unroll
@@ -459,8 +499,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
         for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
     }
     BAMD_STAGE_ISSUE(0, 0);
-    uint4 wa = ldnt<uint4>(rec0, (uint32_t) lane * 16u), wb = ldnt<uint4>(rec1, (uint32_t) lane * 16u);
-    uint2 qa = ldnt<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldnt<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
+    uint4 wa = ldw<uint4>(rec0, (uint32_t) lane * 16u), wb = ldw<uint4>(rec1, (uint32_t) lane * 16u);
+    uint2 qa = ldw<uint2>(rec0, 1024u + (uint32_t) lane * 8u), qb = ldw<uint2>(rec1, 1024u + (uint32_t) lane * 8u);
     uint4 hsc = *(const uint4 *) (recm + 1536 + (m & 7) * 16); uint32_t hd = *(const unsigned short *) (recm + 1664 + (m & 7) * 2);
     lds_dma_wait();
     __syncthreads();
@@ -478,8 +518,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
         BAMD_STAGE_ISSUE(more ? ci + 1 : ci, (ci + 1) & 1);  // after the previous prefetch was consumed (see the Q4_K kernel)
         {
             const uint32_t ro = (uint32_t) (more ? ci + 1 : ci) * 1680u;
-            wa = ldnt<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldnt<uint4>(rec1, ro + (uint32_t) lane * 16u);
-            qa = ldnt<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldnt<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
+            wa = ldw<uint4>(rec0, ro + (uint32_t) lane * 16u); wb = ldw<uint4>(rec1, ro + (uint32_t) lane * 16u);
+            qa = ldw<uint2>(rec0, ro + 1024u + (uint32_t) lane * 8u); qb = ldw<uint2>(rec1, ro + 1024u + (uint32_t) lane * 8u);
             hsc = *(const uint4 *) (recm + ro + 1536 + (m & 7) * 16); hd = *(const unsigned short *) (recm + ro + 1664 + (m & 7) * 2);
         }
         __builtin_amdgcn_sched_barrier(0);
