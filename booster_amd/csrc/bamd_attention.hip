@@ -4,15 +4,28 @@
 
 // ---- long contexts: three launches (scores | softmax | P.V), positions / rows spread over many workgroups ------------------
 // grid (Hkv, tiles of 64 positions), block 512 = 8 waves x (8 positions x 8 lanes); the GQ query heads of a KV head share K
-template <int GQ>
+#define BAMD_QK_NT 4                     /* tiles of 64 positions per workgroup whose K rows are in flight together */
+template <int GQ, int LG>                // LG = head_dim / 64 = 16-byte groups of a K row per lane
 __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
     const bamd_step_state * st = a.st;
     const int pos = st->pos, n_kv = st->n_kv;
-    const int hd = a.hd, Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx, L = hd >> 3;
+    constexpr int hd = 64 * LG, L = 8 * LG;
+    const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int hk = blockIdx.x;
+    // The K rows of this workgroup's first BAMD_QK_NT tiles are requested BEFORE the RoPE prologue, unconditionally (positions past
+    // the sequence read row 0): one memory latency for all of them, overlapped with the prologue.  (With the request inside the
+    // tile loop every tile cost a full HBM round trip: 10.2 us per layer at 8000 positions for 16 MB of K.)
+    uint4 kpre[BAMD_QK_NT][LG];
+#define BAMD_QK_PREFETCH(t0_) do { \
+        _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) { \
+            int i_ = ((t0_) + j * (int) gridDim.y) * 64 + (int) (threadIdx.x >> 6) * 8 + (int) ((threadIdx.x & 63) >> 3); i_ = i_ < pos ? i_ : 0; \
+            const unsigned short * kr_ = a.kc + (size_t) i_ * Ekv + hk * hd + (int) (threadIdx.x & 7) * L; \
+            _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = *(const uint4 *) (kr_ + g * 8); \
+        } } while (0)
+    BAMD_QK_PREFETCH((int) blockIdx.y);
     const float * rope = a.rope + (size_t) pos * hd;
     rope_heads(a.q + (size_t) hk * GQ * hd, rope, hd, GQ, qt, q16t, nullptr);
     rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
@@ -26,30 +39,34 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     }
     const int lane = threadIdx.x & 63, wave = wave_id(), e = lane & 7;
     const int tiles = (n_kv + 63) >> 6;
-    for (int tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
-        const int i = tile * 64 + wave * 8 + (lane >> 3);        // position
-        if (i >= n_kv) continue;
-        float sc[GQ];
+    for (int tile0 = blockIdx.y; tile0 < tiles; tile0 += BAMD_QK_NT * gridDim.y) {
+        float sc[BAMD_QK_NT][GQ];
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) sc[g] = -INFINITY;          // masked (KQ_mask, llama.cpp:14152-14200)
-        if (i <= pos) {
-            uint4 kreg[4];
+        for (int j = 0; j < BAMD_QK_NT; ++j) {
+            const int i = (tile0 + j * (int) gridDim.y) * 64 + wave * 8 + (lane >> 3);        // position
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                kreg[g] = make_uint4(0, 0, 0, 0);
-                if (g * 8 < L) kreg[g] = i == pos ? *(const uint4 *) (k16t + e * L + g * 8) : *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8);
+            for (int g = 0; g < GQ; ++g) sc[j][g] = -INFINITY;  // masked (KQ_mask, llama.cpp:14152-14200)
+            if (i <= pos) {                                      // (i <= pos < n_kv)
+                uint4 kreg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    kreg[g] = make_uint4(0, 0, 0, 0);
+                    if (g < LG) { const uint4 own = *(const uint4 *) (k16t + e * L + g * 8); kreg[g] = i == pos ? own : kpre[j][g < LG ? g : 0]; }
+                }
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
+                    const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * L) : kq_chain<false>(kreg, L, qt + g * hd + e * L, nullptr);
+                    sc[j][g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
+                }
             }
+            if (e == 0 && i < n_kv) {
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) {
-                const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * L) : kq_chain<false>(kreg, L, qt + g * hd + e * L, nullptr);
-                sc[g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
+                for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + i] = sc[j][g];
             }
         }
-        if (e == 0) {
-#pragma unroll
-            for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + i] = sc[g];
-        }
+        if (tile0 + BAMD_QK_NT * (int) gridDim.y < tiles) BAMD_QK_PREFETCH(tile0 + BAMD_QK_NT * (int) gridDim.y);   // (n_ctx > 64 x BAMD_QK_NT x gridDim.y only)
     }
+#undef BAMD_QK_PREFETCH
 }
 
 // softmax over n_kv scores of one head: grid (H), block 256.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
@@ -119,33 +136,47 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
     const unsigned short * vrow = a.vc + (size_t) (hk * hd + d) * n_ctx + e * 8;
     const float * p = a.probs + (size_t) h * n_ctx + e * 8;
     float acc = 0.f;
-    // two register sets of BAMD_PV_U blocks: the requests of the next set are in flight while the chain walks the current one
+    // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions (8 chain steps per lane) and possibly half a block
+    // (4 steps).  Sets of BAMD_PV_U full blocks run without a single condition — one v_fma_mix_f32 per chain step, three 16-byte
+    // requests per block — with the next set's requests in flight (two register sets); what does not fill a set is chained from
+    // the last prefetched set under wave-uniform branches.  (The first form of this kernel tested the block and the step count at
+    // every chain step: seven instructions per step, 15.7 us per layer at 8000 positions for 3.3 us of chain latency.)
+    const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
+    const int nsets = nfull / BAMD_PV_U, rem = nfull - nsets * BAMD_PV_U;
     uint4 vA[BAMD_PV_U], vB[BAMD_PV_U]; float4 paA[BAMD_PV_U], pbA[BAMD_PV_U], paB[BAMD_PV_U], pbB[BAMD_PV_U];
-#define BAMD_PV_LOAD(V_, PA_, PB_, base_) do { \
+#define BAMD_PV_LOAD(V_, PA_, PB_, set_) do { \
         _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) { \
-            const int b = (base_) + 64 * u < n_kv ? (base_) + 64 * u : 0;      /* unconditional requests (block 0 again past the end): counted waits */ \
+            int blk = (set_) * BAMD_PV_U + u; blk = blk < last ? blk : last;       /* unconditional requests (the last block again past the end) */ \
+            const int b = blk * 64; \
             V_[u] = *(const uint4 *) (vrow + b); PA_[u] = *(const float4 *) (p + b); PB_[u] = *(const float4 *) (p + b + 4); \
         } } while (0)
-#define BAMD_PV_CHAIN(V_, PA_, PB_, base_) do { \
+#define BAMD_PV_STEPS(V_, PA_, PB_, u_, n_) do { \
+        const uint32_t w[4] = { V_[u_].x, V_[u_].y, V_[u_].z, V_[u_].w }; \
+        const float pv[8] = { PA_[u_].x, PA_[u_].y, PA_[u_].z, PA_[u_].w, PB_[u_].x, PB_[u_].y, PB_[u_].z, PB_[u_].w }; \
+        _Pragma("unroll") for (int k = 0; k < (n_); ++k) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); } while (0)
+#define BAMD_PV_CHAIN(V_, PA_, PB_) do { _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) BAMD_PV_STEPS(V_, PA_, PB_, u, 8); } while (0)
+#define BAMD_PV_TAIL(V_, PA_, PB_) do { \
         _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) { \
-            const int b = (base_) + 64 * u; \
-            if (b < n_kv) {                                      /* one 64-position block = 8 chain steps per lane (n_kv % 64 == 32: 4) */ \
-                const uint32_t w[4] = { V_[u].x, V_[u].y, V_[u].z, V_[u].w }; \
-                const float pv[8] = { PA_[u].x, PA_[u].y, PA_[u].z, PA_[u].w, PB_[u].x, PB_[u].y, PB_[u].z, PB_[u].w }; \
-                const int nstep = n_kv - b >= 64 ? 8 : (n_kv - b) >> 3; \
-                _Pragma("unroll") for (int k = 0; k < 8; ++k) if (k < nstep) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); \
-            } \
+            if (u < rem) BAMD_PV_STEPS(V_, PA_, PB_, u, 8); \
+            else if (u == rem && half) BAMD_PV_STEPS(V_, PA_, PB_, u, 4); \
         } } while (0)
-    constexpr int STEP = 64 * BAMD_PV_U;
     BAMD_PV_LOAD(vA, paA, pbA, 0);
-    for (int b0 = 0; b0 < n_kv; b0 += 2 * STEP) {
-        BAMD_PV_LOAD(vB, paB, pbB, b0 + STEP);
-        BAMD_PV_CHAIN(vA, paA, pbA, b0);
-        BAMD_PV_LOAD(vA, paA, pbA, b0 + 2 * STEP);
-        BAMD_PV_CHAIN(vB, paB, pbB, b0 + STEP);
+    int s = 0;
+    for (; s + 2 <= nsets; s += 2) {
+        BAMD_PV_LOAD(vB, paB, pbB, s + 1);
+        BAMD_PV_CHAIN(vA, paA, pbA);
+        BAMD_PV_LOAD(vA, paA, pbA, s + 2);
+        BAMD_PV_CHAIN(vB, paB, pbB);
     }
+    if (s < nsets) {                                             // an odd number of full sets: one more, then the tail sits in set B
+        BAMD_PV_LOAD(vB, paB, pbB, s + 1);
+        BAMD_PV_CHAIN(vA, paA, pbA);
+        BAMD_PV_TAIL(vB, paB, pbB);
+    } else BAMD_PV_TAIL(vA, paA, pbA);
 #undef BAMD_PV_LOAD
+#undef BAMD_PV_STEPS
 #undef BAMD_PV_CHAIN
+#undef BAMD_PV_TAIL
     const float v = hsum8_tinyblas(acc);
     if (e == 0) a.out[(size_t) h * hd + d] = v;
 }
@@ -514,7 +545,12 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
     switch (gq) {
 #define CASE(G) case G: \
-        hipLaunchKernelGGL((attn_qk_kernel<G>), g1, dim3(512), 0, s, a); \
+        switch (a.hd >> 6) { \
+            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1>), g1, dim3(512), 0, s, a); break; \
+            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2>), g1, dim3(512), 0, s, a); break; \
+            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3>), g1, dim3(512), 0, s, a); break; \
+            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4>), g1, dim3(512), 0, s, a); break; \
+        } \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
         if (G >= 2) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2 > 0 ? G / 2 : 1)), 0, s, a, gq); /* two workgroups per KV head: all 256 CUs at Hkv x hd/8 = 128 */ \
         else hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \
