@@ -48,6 +48,7 @@ def lib():
         L.bamd_decode.argtypes = [vp, vp, ci, ci]
         L.bamd_get_logits.restype = C.POINTER(C.c_float); L.bamd_get_logits.argtypes = [vp]
         L.bamd_generate_greedy.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_float)]
+        L.bamd_kv_seq_rm.argtypes = [vp, ci, ci]; L.bamd_kv_seq_add.argtypes = [vp, ci, ci, ci]
         L.bamd_stage_step.argtypes = [vp, C.c_int32, vp, ci, vp, vp, ci, ci, vp]
         L.bamd_stage_token_to.argtypes = [vp, vp, vp]
         L.bamd_stage_prefill.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp]
@@ -133,6 +134,21 @@ class Context:
 
     def last_logits(self):
         return np.ctypeslib.as_array(lib().bamd_get_logits(self.h), shape=(self.model.n_vocab,)).copy()
+
+    def kv_seq_rm(self, p0, p1):
+        """llama_kv_cache_seq_rm(ctx, 0, p0, p1)"""
+        _chk(lib().bamd_kv_seq_rm(self.h, int(p0), int(p1)))
+
+    def kv_seq_add(self, p0, p1, delta):
+        """llama_kv_cache_seq_add(ctx, 0, p0, p1, delta)"""
+        _chk(lib().bamd_kv_seq_add(self.h, int(p0), int(p1), int(delta)))
+
+    def context_shift(self, n_keep, n_past):
+        """Booster's context shift (cpp/bridge.cpp:487-503); returns the new n_past"""
+        n_discard = (n_past - n_keep) // 2
+        self.kv_seq_rm(n_keep, n_keep + n_discard)
+        self.kv_seq_add(n_keep + n_discard, n_past, -n_discard)
+        return n_past - n_discard
 
     def profile_step(self, pos):
         launches = np.zeros(4, np.int32); ms = np.zeros(4, np.float64); nbytes = np.zeros(4, np.float64)

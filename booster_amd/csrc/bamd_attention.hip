@@ -5,13 +5,15 @@
 // ---- long contexts: three launches (scores | softmax | P.V), positions / rows spread over many workgroups ------------------
 // grid (Hkv, tiles of 64 positions), block 512 = 8 waves x (8 positions x 8 lanes); the GQ query heads of a KV head share K
 #define BAMD_QK_NT 4                     /* tiles of 64 positions per workgroup whose K rows are in flight together */
-template <int GQ, int LG>                // LG = head_dim / 64 = 16-byte groups of a K row per lane
+// SH: cells no longer follow positions (a context shift happened: a.cellpos).  The token's K / V go to cell st->cell, a cell is attended when it
+// holds a position <= pos (llama_set_inputs' mask, llama.cpp:14152-14200) — in CELL order, as the reference's soft_max and P.V run over the cache
+template <int GQ, int LG, bool SH>       // LG = head_dim / 64 = 16-byte groups of a K row per lane
 __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
     const bamd_step_state * st = a.st;
-    const int pos = st->pos, n_kv = st->n_kv;
+    const int pos = st->pos, n_kv = st->n_kv, cell = SH ? st->cell : pos;
     constexpr int hd = 64 * LG, L = 8 * LG;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int hk = blockIdx.x;
@@ -21,7 +23,7 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     uint4 kpre[BAMD_QK_NT][LG];
 #define BAMD_QK_PREFETCH(t0_) do { \
         _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) { \
-            int i_ = ((t0_) + j * (int) gridDim.y) * 64 + (int) (threadIdx.x >> 6) * 8 + (int) ((threadIdx.x & 63) >> 3); i_ = i_ < pos ? i_ : 0; \
+            int i_ = ((t0_) + j * (int) gridDim.y) * 64 + (int) (threadIdx.x >> 6) * 8 + (int) ((threadIdx.x & 63) >> 3); i_ = i_ < (SH ? n_kv : pos) ? i_ : 0; \
             const unsigned short * kr_ = a.kc + (size_t) i_ * Ekv + hk * hd + (int) (threadIdx.x & 7) * L; \
             _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = *(const uint4 *) (kr_ + g * 8); \
         } } while (0)
@@ -31,10 +33,10 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
     __syncthreads();
     // KV store by the block that owns the tile of `pos` — llm_build_kv_store, llama.cpp:7830-7875
-    if ((int) blockIdx.y == ((pos >> 6) % (int) gridDim.y)) {
+    if ((int) blockIdx.y == ((cell >> 6) % (int) gridDim.y)) {
         for (int i = threadIdx.x; i < hd; i += blockDim.x) {
-            a.kc[(size_t) pos * Ekv + hk * hd + i] = k16t[i];
-            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(pos)] = f2h(a.v[hk * hd + i]);
+            a.kc[(size_t) cell * Ekv + hk * hd + i] = k16t[i];
+            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(cell)] = f2h(a.v[hk * hd + i]);
         }
     }
     const int lane = threadIdx.x & 63, wave = wave_id(), e = lane & 7;
@@ -46,12 +48,14 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
             const int i = (tile0 + j * (int) gridDim.y) * 64 + wave * 8 + (lane >> 3);        // position
 #pragma unroll
             for (int g = 0; g < GQ; ++g) sc[j][g] = -INFINITY;  // masked (KQ_mask, llama.cpp:14152-14200)
-            if (i <= pos) {                                      // (i <= pos < n_kv)
+            bool live = i <= pos;                                // (i <= pos < n_kv)
+            if (SH) live = i < n_kv && (i == cell || (uint32_t) a.cellpos[i < n_kv ? i : 0] <= (uint32_t) pos);
+            if (live) {
                 uint4 kreg[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     kreg[g] = make_uint4(0, 0, 0, 0);
-                    if (g < LG) { const uint4 own = *(const uint4 *) (k16t + e * L + g * 8); kreg[g] = i == pos ? own : kpre[j][g < LG ? g : 0]; }
+                    if (g < LG) { const uint4 own = *(const uint4 *) (k16t + e * L + g * 8); kreg[g] = i == cell ? own : kpre[j][g < LG ? g : 0]; }
                 }
 #pragma unroll
                 for (int g = 0; g < GQ; ++g) {
@@ -503,6 +507,29 @@ __global__ void __launch_bounds__(256) kv_store_batch_kernel(bamd_attn_args a) {
 // ===========================================================================================================
 // launchers
 // ===========================================================================================================
+// ---- K-shift: after llama_kv_cache_seq_add the cached K rows of the moved cells are re-rotated by their position delta ------------
+// (llama_kv_cache_update_internal -> build_k_shift, llama.cpp:15245-15277, :8482-8512: ggml_rope_ext_inplace over the whole f16 K cache,
+// i.e. ggml_compute_forward_rope_f16, ggml.c:14169-14290 — x0, x1 from f16, x0*cos - x1*sin and x0*sin + x1*cos as separate f32
+// multiplies and one add each, back to f16; cells with delta 0 go through the same arithmetic with cos 1 / sin 0).
+// grid (cells), block Hkv*hd/2: one adjacent pair per thread, at its chain-major place (kperm).
+__global__ void __launch_bounds__(1024) k_shift_kernel(unsigned short * kc, int Hkv, int hd, const int32_t * tab_of_cell, const float * tab) {
+    const int cell = blockIdx.x, hp = hd >> 1, L = hd >> 3;
+    const float * row = tab + (size_t) tab_of_cell[cell] * hd;
+    for (int t = threadIdx.x; t < Hkv * hp; t += blockDim.x) {
+        const int hk = t / hp, p = t - hk * hp;
+        unsigned short * kr = kc + (size_t) cell * Hkv * hd + hk * hd;
+        const int i0 = kperm(2 * p, L), i1 = kperm(2 * p + 1, L);
+        const float x0 = h2f(kr[i0]), x1 = h2f(kr[i1]);
+        const float c = row[2 * p], sn = row[2 * p + 1];
+        const float t0 = x0 * c, t1 = x1 * sn, t2 = x0 * sn, t3 = x1 * c;
+        kr[i0] = f2h(t0 - t1); kr[i1] = f2h(t2 + t3);
+    }
+}
+void bamd_launch_k_shift(unsigned short * kc, int n_cells, int Hkv, int hd, const int32_t * tab_of_cell, const float * tab, hipStream_t s) {
+    int nt = Hkv * hd / 2; if (nt > 1024) nt = 1024; nt = (nt + 63) & ~63;
+    hipLaunchKernelGGL(k_shift_kernel, dim3(n_cells), dim3(nt), 0, s, kc, Hkv, hd, tab_of_cell, tab);
+}
+
 static void launch_attn_fused(const bamd_attn_args & a, int gq, dim3 grid, size_t lds, hipStream_t s) {
     switch (a.hd >> 6) {                                       // head_dim 64 / 128 / 192 / 256 (checked by the callers)
         case 1: hipLaunchKernelGGL((attn_fused_kernel<1>), grid, dim3(512), lds, s, a, gq); break;
@@ -535,6 +562,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
+    if (a.cellpos && max_tiles >= 0) return 1;                  // shifted cells: the three-launch path only (the caller passes -tiles)
     if (max_tiles >= 0 && !(ld & 63) && (size_t) ld * 8 <= BAMD_ATTN_LDS_MAX) {
         // the caller knows the sequence is short enough for one workgroup per query head and that ld bounds its padded length
         launch_attn_fused(a, gq, dim3(a.Hkv * gq), (size_t) ld * 8, s);
@@ -545,11 +573,16 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
     switch (gq) {
 #define CASE(G) case G: \
-        switch (a.hd >> 6) { \
-            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1>), g1, dim3(512), 0, s, a); break; \
-            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2>), g1, dim3(512), 0, s, a); break; \
-            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3>), g1, dim3(512), 0, s, a); break; \
-            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4>), g1, dim3(512), 0, s, a); break; \
+        if (a.cellpos) switch (a.hd >> 6) { \
+            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1, true>), g1, dim3(512), 0, s, a); break; \
+            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2, true>), g1, dim3(512), 0, s, a); break; \
+            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3, true>), g1, dim3(512), 0, s, a); break; \
+            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, true>), g1, dim3(512), 0, s, a); break; \
+        } else switch (a.hd >> 6) { \
+            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1, false>), g1, dim3(512), 0, s, a); break; \
+            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2, false>), g1, dim3(512), 0, s, a); break; \
+            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3, false>), g1, dim3(512), 0, s, a); break; \
+            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, false>), g1, dim3(512), 0, s, a); break; \
         } \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
         if (G >= 2) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2 > 0 ? G / 2 : 1)), 0, s, a, gq); /* two workgroups per KV head: all 256 CUs at Hkv x hd/8 = 128 */ \

@@ -536,7 +536,16 @@ BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID
     while (n_remain && n_past < max_embd_size && !p.stop.load()) {
         if (!embd.empty()) {
             if ((int) embd.size() > max_embd_size) embd.resize((size_t) max_embd_size);
-            // (context shift, bridge.cpp:482-507, can never trigger: the loop guard stops at n_ctx-4 positions)
+            // context shift, bridge.cpp:482-507 (ga_n == 1, params.n_keep = 0).  Kept for fidelity: the loop guard stops at n_ctx - 4 positions
+            // and an evaluation is at most one generated token or a prompt slice that fits, so the condition cannot hold — the level-1
+            // calls behind it are pinned against the reference where it does (tests/test_gpu_fullsize_ref.py, fixture "shift")
+            if (n_past + (int) embd.size() > n_ctx) {
+                if (p.n_predict == -2) break;
+                const int n_keep = 0, n_discard = (n_past - n_keep) / 2;
+                for (auto & st : p.stages)
+                    if (bamd_kv_seq_rm(st.ctx, n_keep, n_keep + n_discard) || bamd_kv_seq_add(st.ctx, n_keep + n_discard, n_past, -n_discard)) return 1;
+                n_past -= n_discard;
+            }
             for (int i = 0; i < (int) embd.size(); i += p.n_batch) {
                 int n_eval = std::min((int) embd.size() - i, p.n_batch);
                 for (int u = 0; u < n_eval; u += 512) {                      // llama_decode's n_ubatch = 512 micro-batches (llama.cpp:14615)

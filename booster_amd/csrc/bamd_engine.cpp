@@ -121,6 +121,12 @@ struct bamd_context {
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr; int graph_fused = -1;
+    // KV cell metadata (llama_kv_cache cells: pos / delta / head / used, llama.cpp:2700-2760) — inactive (cell i holds position i, nothing to
+    // track) until the first bamd_kv_seq_rm / bamd_kv_seq_add
+    struct Cells { bool active = false, has_shift = false; std::vector<int32_t> pos, delta; int head = 0, used = 0; } cells;
+    int n_cached = 0;               // positions evaluated so far (highest n_past + n_tokens seen): what the cells hold when tracking starts
+    int32_t * cellpos = nullptr;    // device copy of cells.pos (attention mask of the shifted path)
+    int32_t * shift_idx = nullptr; float * shift_tab = nullptr; int shift_tab_cap = 0;
     // stage-step graphs (bamd_stage_step): one per (want_logits, prefill_mode), valid for the pointers it was captured with
     struct StageGraph { hipGraphExec_t exec = nullptr; const void * token_src = nullptr, * hin = nullptr; void * hout = nullptr; int fused = -1; };
     StageGraph sgraph[2][2];
@@ -367,7 +373,10 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     delete c;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_n_ctx(const bamd_context * c) { return c->n_ctx; }
-extern "C" __attribute__((visibility("default"))) void bamd_kv_cache_clear(bamd_context * c) { (void) c; /* llama_kv_cache_clear resets cell metadata only; positions are passed per call here */ }
+extern "C" __attribute__((visibility("default"))) void bamd_kv_cache_clear(bamd_context * c) {
+    // llama_kv_cache_clear resets the cell metadata; positions are passed per call here, so only the shifted-cell tracking has anything to forget
+    c->cells.active = false; c->cells.has_shift = false; c->n_cached = 0;
+}
 
 // -------------------------------------------------------------------------------------------------------
 // the static per-token pipeline
@@ -390,7 +399,7 @@ static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.s
 // kernel (one workgroup per query head, serial over the sequence) wins below ~450 positions (measured crossover, 8B shape: 1.73 vs
 // 1.85 ms/token at 240, equal at 440, 2.06 vs 1.88 at 740) at any n_ctx (its LDS score rows are sized by the sequence bound, not by n_ctx); longer sequences take the
 // three-kernel path, whose cost is nearly flat up to a few thousand positions.
-static bool attn_fused_for(const bamd_context * c, int pos_hi) { (void) c; return g_attn_fused && pos_hi < 448; }
+static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && pos_hi < 448 && !c->cells.active; }   // shifted cells: three-launch path (attn_qk_kernel<.., SH>)
 // LDS row length of the single-launch / batched attention kernels for sequences up to position pos_hi: a multiple of 64, independent of n_ctx
 static int attn_lds_ld(const bamd_context * c, int pos_hi) { return std::min((pos_hi + 1 + 63) / 64 * 64, c->n_ctx_pad); }
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
@@ -418,6 +427,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         // single-launch kernel below 448 positions, three kernels (scores | softmax | P.V) above (attn_fused_for)
         t.tl = tl_next(c);
         t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances
+        t.cellpos = c->cells.active ? c->cellpos : nullptr;
         if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
         if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
@@ -461,6 +471,112 @@ static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_ke
         // keep best_key (the arg-max of the previous lm_head): rewrite only the leading fields
         HIPC(hipMemcpyAsync(c->st, &h, offsetof(bamd_step_state, best_key), hipMemcpyHostToDevice, s));
     } else HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// ---- KV cell bookkeeping after position edits (llama_kv_cache_seq_rm / _seq_add / find_slot / update) ------------------------------------
+// The reference keeps, per cache cell, the position it holds and a pending rotation delta (llama.cpp:2700-2760).  As long as nobody edits
+// positions, cell i holds position i and nothing is tracked here.  Booster's context shift (cpp/bridge.cpp:487-503) is
+//     llama_kv_cache_seq_rm (ctx, 0, n_keep, n_keep + n_discard);  llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);
+// after which cells and positions differ: freed cells are refilled in cell order (find_slot), the attention runs over CELLS (mask by the
+// position each holds), and the K rows of the moved cells are re-rotated by their delta before the next evaluation (K-shift).
+static int kv_activate(bamd_context * c) {
+    if (c->cells.active) return 0;
+    bamd_context::Cells & k = c->cells;
+    k.pos.assign((size_t) c->n_ctx, -1); k.delta.assign((size_t) c->n_ctx, 0);
+    const int n = std::min(c->n_cached, c->n_ctx);
+    for (int i = 0; i < n; ++i) k.pos[(size_t) i] = i;
+    k.used = n; k.head = n >= c->n_ctx ? 0 : n;          // llama_decode_internal: head += n_tokens, wraps to 0 at size (llama.cpp:14743-14748)
+    if (!c->cellpos && dev_alloc(c->allocs, (void **) &c->cellpos, (size_t) c->n_ctx_pad * 4)) return 1;
+    std::vector<int32_t> h((size_t) c->n_ctx_pad, -1);
+    memcpy(h.data(), k.pos.data(), (size_t) c->n_ctx * 4);
+    HIPC(hipMemcpy(c->cellpos, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    k.active = true;
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_rm(bamd_context * c, int p0, int p1) {     // llama_kv_cache_seq_rm(ctx, 0, p0, p1): llama.cpp:3150-3217
+    HIPC(hipSetDevice(c->m->device));
+    if (kv_activate(c)) return 1;
+    bamd_context::Cells & k = c->cells;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    int new_head = c->n_ctx;
+    for (int i = 0; i < c->n_ctx; ++i) {
+        if (k.pos[(size_t) i] >= p0 && k.pos[(size_t) i] < p1) {           // one sequence: a cell is empty once it leaves it
+            if (k.pos[(size_t) i] >= 0) k.used--;
+            k.pos[(size_t) i] = -1;
+            if (new_head == c->n_ctx) new_head = i;
+        }
+    }
+    if (new_head != c->n_ctx && new_head < k.head) k.head = new_head;
+    HIPC(hipMemcpy(c->cellpos, k.pos.data(), (size_t) c->n_ctx * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_add(bamd_context * c, int p0, int p1, int delta) {   // llama_kv_cache_seq_add: llama.cpp:3268-3313
+    HIPC(hipSetDevice(c->m->device));
+    if (kv_activate(c)) return 1;
+    bamd_context::Cells & k = c->cells;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    if (p0 == p1) return 0;
+    int new_head = c->n_ctx;
+    for (int i = 0; i < c->n_ctx; ++i) {
+        if (k.pos[(size_t) i] >= 0 && k.pos[(size_t) i] >= p0 && k.pos[(size_t) i] < p1) {
+            k.has_shift = true;
+            k.pos[(size_t) i] += delta; k.delta[(size_t) i] += delta;
+            if (k.pos[(size_t) i] < 0) { k.used--; k.pos[(size_t) i] = -1; if (new_head == c->n_ctx) new_head = i; }
+        }
+    }
+    k.head = new_head != c->n_ctx ? new_head : 0;
+    HIPC(hipMemcpy(c->cellpos, k.pos.data(), (size_t) c->n_ctx * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+// llama_kv_cache_update_internal (llama.cpp:15245-15277): apply the pending K-shift to every layer's K cache, clear the deltas
+static int kv_update(bamd_context * c, hipStream_t s) {
+    bamd_context::Cells & k = c->cells;
+    if (!k.has_shift) return 0;
+    bamd_model * m = c->m;
+    std::vector<int32_t> vals(1, 0), idx((size_t) c->n_ctx_pad, 0);     // row 0: delta 0 (the reference rotates EVERY cell, most by zero)
+    for (int i = 0; i < c->n_ctx; ++i) {
+        const int32_t d = k.delta[(size_t) i];
+        size_t j = 0; while (j < vals.size() && vals[j] != d) ++j;
+        if (j == vals.size()) vals.push_back(d);
+        idx[(size_t) i] = (int32_t) j;
+    }
+    if (vals.size() > 64) return fail("K-shift: more than 64 distinct pending deltas");
+    std::vector<float> tab(vals.size() * (size_t) m->hd);
+    for (size_t j = 0; j < vals.size(); ++j)
+        rope_row(tab.data() + j * m->hd, vals[j], m->hd, m->rope_theta, m->rope_freq_scale, m->rope_freqs.empty() ? nullptr : m->rope_freqs.data(),
+                 0.0f, 1.0f, m->n_ctx_train, 32.0f, 1.0f);               // the parameters of the context's own table (bamd_context_new)
+    if (!c->shift_idx && dev_alloc(c->allocs, (void **) &c->shift_idx, (size_t) c->n_ctx_pad * 4)) return 1;
+    if ((int) vals.size() > c->shift_tab_cap) { c->shift_tab = nullptr; if (dev_alloc(c->allocs, (void **) &c->shift_tab, (size_t) 64 * m->hd * 4)) return 1; c->shift_tab_cap = 64; }
+    HIPC(hipMemcpyAsync(c->shift_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(c->shift_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    for (size_t il = 0; il < m->layers.size(); ++il) bamd_launch_k_shift(c->kc[il], c->n_ctx, m->Hkv, m->hd, c->shift_idx, c->shift_tab, s);
+    HIPC(hipStreamSynchronize(s));                           // (idx / tab are host temporaries)
+    k.has_shift = false;
+    std::fill(k.delta.begin(), k.delta.end(), 0);
+    return 0;
+}
+// llama_kv_cache_find_slot for one token (llama.cpp:3028-3127) with llama_decode_internal's head handling (:14686-14688, :14743-14748);
+// *n_kv = the padded length the attention runs over (:14693-14701)
+static int kv_find_slot(bamd_context * c, int pos, int * cell, int * n_kv) {
+    bamd_context::Cells & k = c->cells;
+    const int size = c->n_ctx;
+    if (k.head > k.used + 2) k.head = 0;
+    int n_tested = 0;
+    for (;;) {
+        if (k.head + 1 > size) { n_tested += size - k.head; k.head = 0; continue; }
+        if (k.pos[(size_t) k.head] >= 0) { k.head += 1; n_tested += 1; if (n_tested >= size) return fail("KV cache full: no free cell (llama_decode would return 1)"); continue; }
+        break;
+    }
+    *cell = k.head;
+    k.pos[(size_t) k.head] = pos; k.used += 1;
+    int cell_max = 0;
+    for (int i = size; i > 0; --i) if (k.pos[(size_t) (i - 1)] >= 0) { cell_max = i; break; }
+    *n_kv = std::min(size, std::max(32, (cell_max + 31) / 32 * 32));
+    k.head += 1; if (k.head >= size) k.head = 0;
     return 0;
 }
 
@@ -583,6 +699,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     }
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
     hipStream_t s = c->stream;
+    if (c->cells.active && n_tokens > 1) { fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call"); return 1; }
+    if (!c->cells.active) c->n_cached = std::max(c->n_cached, n_past + n_tokens);
     if (hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s) != hipSuccess) { fail("H2D tokens"); return 1; }
     if (n_tokens > 1 && n_tokens <= BAMD_PREFILL_CAP && prefill_batch_supported(c, n_past + n_tokens - 1)) {
         // one micro-batch: every layer once for all tokens (each weight record unpacked once per 8 tokens), lm_head for the last
@@ -622,6 +740,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_co
     hipStream_t s = (hipStream_t) hip_stream;
     if (n_tokens < 2 || n_tokens > BAMD_PREFILL_CAP || !prefill_batch_supported(c, n_past + n_tokens - 1)) return 2;
     if (n_past < 0 || n_past + n_tokens > c->n_ctx) return fail("context overflow");
+    if (c->cells.active) return fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call");
+    c->n_cached = std::max(c->n_cached, n_past + n_tokens);
     if (m->with_embd) { if (!tokens) return fail("bamd_stage_prefill: tokens required on the first stage"); HIPC(hipMemcpyAsync(c->forced, tokens, (size_t) n_tokens * 4, hipMemcpyHostToDevice, s)); }
     else if (!hidden_in_dev) return fail("bamd_stage_prefill: hidden_in required");
     if (!m->with_output && !hidden_out_dev) return fail("bamd_stage_prefill: hidden_out required");
@@ -712,6 +832,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) return fail("bamd_generate_greedy needs a stage that owns embedding and output");
     if (n_steps < 1 || n_past < 1 || n_past + n_steps > c->n_ctx || n_steps + 1 > c->out_cap) return fail("bad n_past / n_steps");
+    if (c->cells.active) return fail("after a context shift (bamd_kv_seq_add) use bamd_decode per token: the device-side loop assumes cell = position");
+    c->n_cached = std::max(c->n_cached, n_past + n_steps);
     HIPC(hipSetDevice(m->device));
     hipStream_t s = c->stream;
     const int fused = attn_fused_for(c, n_past + n_steps) ? 1 : 0;
@@ -742,6 +864,14 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
     // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx;
+    int attn_hi = pos;                                   // what decides single-launch vs three-launch attention
+    if (c->cells.active) {
+        if (prefill_mode) return fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call");
+        int cell = 0, n_kv = 0;
+        if (kv_update(c, s) || kv_find_slot(c, pos, &cell, &n_kv)) return 1;
+        h.cell_plus1 = cell + 1; h.n_kv_fixed = n_kv; attn_hi = n_kv - 1;
+        HIPC(hipMemcpyAsync(c->cellpos + cell, &c->cells.pos[(size_t) cell], 4, hipMemcpyHostToDevice, s));
+    } else c->n_cached = std::max(c->n_cached, pos + 1);
     HIPC(hipMemcpyAsync(c->st, &h, sizeof h, hipMemcpyHostToDevice, s));
     const int32_t * forced = c->forced;
     if (token_dev) forced = (const int32_t *) token_dev;
@@ -755,7 +885,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
             bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, q);
             HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         }
-        if (enqueue_layers(c, prefill_mode, q, nullptr, pos)) return 1;
+        if (enqueue_layers(c, prefill_mode, q, nullptr, attn_hi)) return 1;
         if (m->with_output) { if (want_logits) enqueue_lm_head(c, q, nullptr); }
         else HIPC(hipMemcpyAsync(hidden_out_dev, c->x, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         return 0;
@@ -767,7 +897,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
         return 0;
     }
     bamd_context::StageGraph & sg = c->sgraph[want_logits ? 1 : 0][prefill_mode ? 1 : 0];
-    const int fused = attn_fused_for(c, pos) ? 1 : 0;
+    const int fused = attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0);     // 2: the shifted-cell kernels (other arguments: recapture)
     if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev || sg.fused != fused)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
     if (!sg.exec) {
         hipGraph_t g = nullptr;

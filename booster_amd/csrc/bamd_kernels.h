@@ -14,7 +14,10 @@ struct bamd_step_state {
     int32_t pos, n_kv, token;      // this step: position, padded KV length (llama.cpp:14693-14701), token id
     int32_t n_ctx;
     int32_t n_out;                 // arg-max tokens appended to out_tokens so far
-    int32_t pad_;
+    int32_t cell;                  // KV cell this step's token is stored in: = pos until positions were shifted (bamd_kv_seq_add), then the slot
+                                   // llama_kv_cache_find_slot picks (llama.cpp:3028-3127)
+    int32_t cell_plus1;            // host: cell of step 0 + 1 (0 = cells follow positions)
+    int32_t n_kv_fixed;            // host: padded KV length of this step when cells no longer follow positions (0 = from pos)
     unsigned long long best_key;   // arg-max key of the last lm_head (0 = none)
 };
 
@@ -46,6 +49,8 @@ struct bamd_attn_args {
     int lds_ld;                    // single-launch / batched kernels: floats per score / probability row in LDS — a multiple of 64 that bounds the padded
                                    // sequence length of this launch (or of every replay of the graph it is captured in); 0 = n_ctx
     unsigned long long * tl;       // phase-stamp block of this launch (BAMD_TIMING builds; null = off)
+    const int32_t * cellpos;       // [n_ctx] position held by every KV cell, -1 = free (after a context shift: cells no longer follow positions; the mask
+                                   // is the reference's "cell.pos > pos or empty -> -inf", llama.cpp:14152-14200); null = cell i holds position i
 };
 
 // batched prefill mat-mul: Y[t][row] = W[row,:] . Q8_K(a_t), T tokens
@@ -66,6 +71,9 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s);
 int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);
+// K-shift (build_k_shift, llama.cpp:8482-8512 -> ggml_compute_forward_rope_f16, ggml.c:14169-14290): every cell's K row re-rotated in place by
+// the cos / sin row tab[tab_of_cell[cell]] (row 0 = delta 0); kc chain-major f16 [n_cells][Hkv*hd]
+void bamd_launch_k_shift(unsigned short * kc, int n_cells, int Hkv, int hd, const int32_t * tab_of_cell, const float * tab, hipStream_t s);
 size_t bamd_blob_bytes(int K);
 size_t bamd_blob16_bytes(int K);
 // blob: int8 activations for matmul_batch_kernel (may be null); blob16: f16 copy for the MFMA kernel (may be null)

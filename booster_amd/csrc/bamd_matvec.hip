@@ -205,9 +205,10 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
         st->token = tok;
         if (do_embed) {
             st->pos = st->pos_base + step;
+            st->cell = st->cell_plus1 ? st->cell_plus1 - 1 + step : st->pos;
             int n_kv = (st->pos + 1 + 31) / 32 * 32;
             if (n_kv > st->n_ctx) n_kv = st->n_ctx;
-            st->n_kv = n_kv;
+            st->n_kv = st->n_kv_fixed ? st->n_kv_fixed : n_kv;
             st->step = step + 1;
         }
         if (do_embed) st->best_key = 0ull;                   // a flush-only call leaves the key for the next generate call

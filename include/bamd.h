@@ -55,6 +55,17 @@ void           bamd_kv_cache_clear(bamd_context * c);                   /* llama
 int           bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past);
 const float * bamd_get_logits(bamd_context * c);                        /* llama_get_logits: host, n_vocab floats */
 
+/* Position edits of the KV cache, sequence 0 — llama_kv_cache_seq_rm / llama_kv_cache_seq_add (cpp/src/llama.cpp:3150-3217, :3268-3313),
+ * the two calls of Booster's context shift (cpp/bridge.cpp:487-503):
+ *     bamd_kv_seq_rm (ctx, n_keep, n_keep + n_discard);  bamd_kv_seq_add(ctx, n_keep + n_discard, n_past, -n_discard);  n_past -= n_discard;
+ * Cells whose position leaves the sequence are freed and refilled in cell order (llama_kv_cache_find_slot, :3028-3127); the K rows of
+ * moved cells are re-rotated by their delta before the next evaluation (K-shift: build_k_shift :8482-8512, ggml.c:14169-14290); the
+ * attention then runs over cells and masks by the position each holds — all as the reference does, bit for bit.  After the first edit
+ * tokens are evaluated one per bamd_decode / bamd_stage_step call (bamd_generate_greedy and multi-token calls return an error).
+ * Negative p0 / p1 mean 0 / infinity as in llama.h.  Layer-split: call on every stage's context.  Return 0 on success. */
+int bamd_kv_seq_rm(bamd_context * c, int p0, int p1);
+int bamd_kv_seq_add(bamd_context * c, int p0, int p1, int delta);
+
 /* Greedy decode entirely on the device: n_steps single-token steps starting at position n_past; step 0 consumes
  * the arg-max of the logits left by the previous bamd_decode/bamd_generate_greedy call.  out_tokens receives
  * n_steps+1 ids: the token fed to each step, then the arg-max after the last step.  One hipGraph per step,

@@ -13,7 +13,12 @@
 //   timing        f64 [4]                prompt seconds, decode seconds, n_threads, n_decode
 // Container: the flat BGLD0001 format of gen_golden.cpp (reader: tests/goldenio.py).
 //
-// usage: ref_run <model.gguf> <n_threads> <n_prompt> <n_decode> <n_ctx> <out.bgld>
+// usage: ref_run <model.gguf> <n_threads> <n_prompt> <n_decode> <n_ctx> <out.bgld> [n_keep]
+// n_keep (optional, >= 0): generate PAST n_ctx with Booster's context shift — the statements of cpp/bridge.cpp:487-503, run whenever
+// n_past + 1 > n_ctx (in the bridge itself its generation loop stops at n_ctx - 4 first, so the shift never fires there; here it does):
+//     n_discard = (n_past - n_keep) / 2;  llama_kv_cache_seq_rm(ctx, 0, n_keep, n_keep + n_discard);
+//     llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);  n_past -= n_discard;
+// recorded in addition:  shift_steps i32 [n_shifts] (decode steps before which a shift ran), n_past_of_step i32 [n_decode].
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +42,7 @@ static void rec(const std::string & name, uint32_t dtype, const std::vector<int6
 int main(int argc, char ** argv) {
     if (argc < 7) { fprintf(stderr, "usage: %s model.gguf n_threads n_prompt n_decode n_ctx out.bgld\n", argv[0]); return 2; }
     const int n_threads = atoi(argv[2]), n_prompt = atoi(argv[3]), n_decode = atoi(argv[4]), n_ctx = atoi(argv[5]);
+    const int n_keep = argc > 7 ? atoi(argv[7]) : -1;
     llama_backend_init();
     llama_model_params mp = llama_model_default_params();
     mp.n_gpu_layers = 0; mp.use_mmap = true;
@@ -73,9 +79,20 @@ int main(int argc, char ** argv) {
     const double tp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     llama_token tok = take();
     double td = 0.0;
+    int n_past = n_prompt;
+    std::vector<int32_t> shift_steps, past_of_step;
     for (int s = 0; s < n_decode; ++s) {
+        if (n_keep >= 0 && n_past + 1 > n_ctx) {
+            const int n_left = n_past - n_keep, n_discard = n_left / 2;
+            llama_kv_cache_seq_rm (ctx, 0, n_keep, n_keep + n_discard);
+            llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);
+            n_past -= n_discard;
+            shift_steps.push_back(s);
+        }
+        past_of_step.push_back(n_past);
         auto t1 = std::chrono::steady_clock::now();
-        if (llama_decode(ctx, llama_batch_get_one(&tok, 1, n_prompt + s, 0))) { fprintf(stderr, "ref_run: decode failed\n"); return 1; }
+        if (llama_decode(ctx, llama_batch_get_one(&tok, 1, n_past, 0))) { fprintf(stderr, "ref_run: decode failed\n"); return 1; }
+        n_past += 1;
         td += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         tok = take();
     }
@@ -89,6 +106,10 @@ int main(int argc, char ** argv) {
     rec("probe_idx", 2, { NP }, pidx.data(), pidx.size() * 4);
     rec("probe_logits", 0, { NP, (int64_t) toks.size() }, probes.data(), probes.size() * 4);
     rec("top_logit", 0, { (int64_t) tops.size() }, tops.data(), tops.size() * 4);
+    if (n_keep >= 0) {
+        rec("shift_steps", 2, { (int64_t) shift_steps.size() }, shift_steps.data(), shift_steps.size() * 4);
+        rec("n_past_of_step", 2, { (int64_t) past_of_step.size() }, past_of_step.data(), past_of_step.size() * 4);
+    }
     const double timing[4] = { tp, td, (double) n_threads, (double) n_decode };
     rec("timing", 3, { 8, 4 }, timing, sizeof timing);
     fclose(g_f);

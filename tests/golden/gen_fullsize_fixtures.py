@@ -7,7 +7,7 @@ numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture c
 prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
 logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
 
-    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k
+    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift
 """
 import hashlib
 import os
@@ -27,7 +27,11 @@ CONFIGS = {
     # one pipeline stage of Llama-3-70B Q4_K_M (the last: 10 layers + output layer), 70B widths, Q5_K attn_v outside the "more bits" layers
     "70b_stage": (dict(E=8192, H=64, Hkv=8, L=10, F=28672, V=128256, theta=500000.0, type_fn="70b"), 8, 16, 256),
     "m7q6k_8k": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=32000, theta=10000.0, type_fn="q6k", embd_type=Q6), 8064, 16, 8192),
+    # generation past n_ctx with Booster's context shift (cpp/bridge.cpp:487-503; ref_run's n_keep argument).  A small GQA model,
+    # n_ctx 96, 150 generated tokens: three shifts, holes refilled in cell order, K rows re-rotated in place three times over
+    "shift": (dict(E=512, H=8, Hkv=2, L=3, F=768, V=512, theta=500000.0), 40, 150, 96),
 }
+N_KEEP = {"shift": 8}
 
 
 def type_fn_of(tag, L):
@@ -76,7 +80,8 @@ def main():
         p = ensure_model(cfg)
         out = os.path.join(ROOT, "tests", "golden", "fullsize_%s.bgld" % cfg)
         t0 = time.time()
-        r = subprocess.run([exe, p, str(threads), str(n_prompt), str(n_decode), str(n_ctx), out], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+        extra = [str(N_KEEP[cfg])] if cfg in N_KEEP else []
+        r = subprocess.run([exe, p, str(threads), str(n_prompt), str(n_decode), str(n_ctx), out] + extra, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
         dg, sz = file_digest(p)
         line = r.stdout.decode().strip().splitlines()[-1]
         with open(out + ".txt", "w") as f:
