@@ -48,7 +48,7 @@ def lib():
         L.bamd_decode.argtypes = [vp, vp, ci, ci]
         L.bamd_get_logits.restype = C.POINTER(C.c_float); L.bamd_get_logits.argtypes = [vp]
         L.bamd_generate_greedy.argtypes = [vp, ci, ci, vp, C.POINTER(C.c_float)]
-        L.bamd_kv_seq_rm.argtypes = [vp, ci, ci]; L.bamd_kv_seq_add.argtypes = [vp, ci, ci, ci]
+        L.bamd_kv_seq_rm.argtypes = [vp, ci, ci]; L.bamd_kv_seq_add.argtypes = [vp, ci, ci, ci]; L.bamd_kv_seq_div.argtypes = [vp, ci, ci, ci]
         L.bamd_stage_step.argtypes = [vp, C.c_int32, vp, ci, vp, vp, ci, ci, vp]
         L.bamd_stage_token_to.argtypes = [vp, vp, vp]
         L.bamd_stage_prefill.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp]
@@ -142,6 +142,10 @@ class Context:
     def kv_seq_add(self, p0, p1, delta):
         """llama_kv_cache_seq_add(ctx, 0, p0, p1, delta)"""
         _chk(lib().bamd_kv_seq_add(self.h, int(p0), int(p1), int(delta)))
+
+    def kv_seq_div(self, p0, p1, d):
+        """llama_kv_cache_seq_div(ctx, 0, p0, p1, d)"""
+        _chk(lib().bamd_kv_seq_div(self.h, int(p0), int(p1), int(d)))
 
     def context_shift(self, n_keep, n_past):
         """Booster's context shift (cpp/bridge.cpp:487-503); returns the new n_past"""

@@ -532,25 +532,46 @@ extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_add(bamd_conte
     HIPC(hipMemcpy(c->cellpos, k.pos.data(), (size_t) c->n_ctx * 4, hipMemcpyHostToDevice));
     return 0;
 }
+extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_div(bamd_context * c, int p0, int p1, int d) {       // llama_kv_cache_seq_div: llama.cpp:3315-3350 (Self-Extend)
+    HIPC(hipSetDevice(c->m->device));
+    if (d < 1) return fail("bamd_kv_seq_div: divisor < 1");
+    if (kv_activate(c)) return 1;
+    bamd_context::Cells & k = c->cells;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = 0x7fffffff;
+    if (p0 == p1) return 0;
+    for (int i = 0; i < c->n_ctx; ++i) {
+        if (k.pos[(size_t) i] >= 0 && k.pos[(size_t) i] >= p0 && k.pos[(size_t) i] < p1) {
+            k.has_shift = true;
+            const int32_t p_old = k.pos[(size_t) i];
+            k.pos[(size_t) i] /= d; k.delta[(size_t) i] += k.pos[(size_t) i] - p_old;
+        }
+    }
+    HIPC(hipMemcpy(c->cellpos, k.pos.data(), (size_t) c->n_ctx * 4, hipMemcpyHostToDevice));
+    return 0;
+}
 // llama_kv_cache_update_internal (llama.cpp:15245-15277): apply the pending K-shift to every layer's K cache, clear the deltas
 static int kv_update(bamd_context * c, hipStream_t s) {
     bamd_context::Cells & k = c->cells;
     if (!k.has_shift) return 0;
     bamd_model * m = c->m;
     std::vector<int32_t> vals(1, 0), idx((size_t) c->n_ctx_pad, 0);     // row 0: delta 0 (the reference rotates EVERY cell, most by zero)
-    for (int i = 0; i < c->n_ctx; ++i) {
-        const int32_t d = k.delta[(size_t) i];
-        size_t j = 0; while (j < vals.size() && vals[j] != d) ++j;
-        if (j == vals.size()) vals.push_back(d);
-        idx[(size_t) i] = (int32_t) j;
+    {
+        std::vector<int32_t> sorted(k.delta.begin(), k.delta.end());
+        std::sort(sorted.begin(), sorted.end());
+        sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+        for (int32_t d : sorted) if (d != 0) vals.push_back(d);           // a context shift: one value; Self-Extend: up to one per cell
+        for (int i = 0; i < c->n_ctx; ++i) {
+            const int32_t d = k.delta[(size_t) i];
+            idx[(size_t) i] = d == 0 ? 0 : (int32_t) (std::lower_bound(vals.begin() + 1, vals.end(), d) - vals.begin());
+        }
     }
-    if (vals.size() > 64) return fail("K-shift: more than 64 distinct pending deltas");
     std::vector<float> tab(vals.size() * (size_t) m->hd);
     for (size_t j = 0; j < vals.size(); ++j)
         rope_row(tab.data() + j * m->hd, vals[j], m->hd, m->rope_theta, m->rope_freq_scale, m->rope_freqs.empty() ? nullptr : m->rope_freqs.data(),
                  0.0f, 1.0f, m->n_ctx_train, 32.0f, 1.0f);               // the parameters of the context's own table (bamd_context_new)
     if (!c->shift_idx && dev_alloc(c->allocs, (void **) &c->shift_idx, (size_t) c->n_ctx_pad * 4)) return 1;
-    if ((int) vals.size() > c->shift_tab_cap) { c->shift_tab = nullptr; if (dev_alloc(c->allocs, (void **) &c->shift_tab, (size_t) 64 * m->hd * 4)) return 1; c->shift_tab_cap = 64; }
+    if (!c->shift_tab) { if (dev_alloc(c->allocs, (void **) &c->shift_tab, (size_t) (c->n_ctx + 1) * m->hd * 4)) return 1; c->shift_tab_cap = c->n_ctx + 1; }
     HIPC(hipMemcpyAsync(c->shift_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(c->shift_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     for (size_t il = 0; il < m->layers.size(); ++il) bamd_launch_k_shift(c->kc[il], c->n_ctx, m->Hkv, m->hd, c->shift_idx, c->shift_tab, s);

@@ -65,6 +65,9 @@ const float * bamd_get_logits(bamd_context * c);                        /* llama
  * Negative p0 / p1 mean 0 / infinity as in llama.h.  Layer-split: call on every stage's context.  Return 0 on success. */
 int bamd_kv_seq_rm(bamd_context * c, int p0, int p1);
 int bamd_kv_seq_add(bamd_context * c, int p0, int p1, int delta);
+/* llama_kv_cache_seq_div(ctx, 0, p0, p1, d) (llama.cpp:3315-3350): positions in [p0, p1) divided by d, the difference added to the pending
+ * rotation — with bamd_kv_seq_add the three calls of Self-Extend (cpp/bridge.cpp:507-523; ga_n is fixed to 1 there, so Booster never issues them). */
+int bamd_kv_seq_div(bamd_context * c, int p0, int p1, int d);
 
 /* Greedy decode entirely on the device: n_steps single-token steps starting at position n_past; step 0 consumes
  * the arg-max of the logits left by the previous bamd_decode/bamd_generate_greedy call.  out_tokens receives

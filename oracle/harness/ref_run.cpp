@@ -18,6 +18,8 @@
 // n_past + 1 > n_ctx (in the bridge itself its generation loop stops at n_ctx - 4 first, so the shift never fires there; here it does):
 //     n_discard = (n_past - n_keep) / 2;  llama_kv_cache_seq_rm(ctx, 0, n_keep, n_keep + n_discard);
 //     llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);  n_past -= n_discard;
+// n_keep < -1 encodes Self-Extend instead: -(100 * ga_n + ga_w), e.g. -216 = group factor 2, window 16 — the loop of cpp/bridge.cpp:507-523
+// (llama_kv_cache_seq_add / _seq_div / _seq_add per window) run before every evaluation, as the bridge would with ga_n > 1.
 // recorded in addition:  shift_steps i32 [n_shifts] (decode steps before which a shift ran), n_past_of_step i32 [n_decode].
 #include <chrono>
 #include <cstdint>
@@ -81,7 +83,20 @@ int main(int argc, char ** argv) {
     double td = 0.0;
     int n_past = n_prompt;
     std::vector<int32_t> shift_steps, past_of_step;
+    const int ga_n = n_keep < -1 ? (-n_keep) / 100 : 1, ga_w = n_keep < -1 ? (-n_keep) % 100 : 0;
+    int ga_i = 0;
     for (int s = 0; s < n_decode; ++s) {
+        if (ga_n > 1) {
+            while (n_past >= ga_i + ga_w) {
+                const int ib = (ga_n * ga_i) / ga_w, bd = (ga_w / ga_n) * (ga_n - 1), dd = (ga_w / ga_n) - ib * bd - ga_w;
+                llama_kv_cache_seq_add(ctx, 0, ga_i, n_past, ib * bd);
+                llama_kv_cache_seq_div(ctx, 0, ga_i + ib * bd, ga_i + ib * bd + ga_w, ga_n);
+                llama_kv_cache_seq_add(ctx, 0, ga_i + ib * bd + ga_w, n_past + ib * bd, dd);
+                n_past -= bd;
+                ga_i += ga_w / ga_n;
+                shift_steps.push_back(s);
+            }
+        }
         if (n_keep >= 0 && n_past + 1 > n_ctx) {
             const int n_left = n_past - n_keep, n_discard = n_left / 2;
             llama_kv_cache_seq_rm (ctx, 0, n_keep, n_keep + n_discard);
@@ -106,7 +121,7 @@ int main(int argc, char ** argv) {
     rec("probe_idx", 2, { NP }, pidx.data(), pidx.size() * 4);
     rec("probe_logits", 0, { NP, (int64_t) toks.size() }, probes.data(), probes.size() * 4);
     rec("top_logit", 0, { (int64_t) tops.size() }, tops.data(), tops.size() * 4);
-    if (n_keep >= 0) {
+    if (n_keep >= 0 || n_keep < -1) {
         rec("shift_steps", 2, { (int64_t) shift_steps.size() }, shift_steps.data(), shift_steps.size() * 4);
         rec("n_past_of_step", 2, { (int64_t) past_of_step.size() }, past_of_step.data(), past_of_step.size() * 4);
     }
