@@ -9,6 +9,12 @@ template <> struct RecOf<BAMD_Q4_K> { typedef RecQ4K type; };
 template <> struct RecOf<BAMD_Q5_K> { typedef RecQ5K type; };
 template <> struct RecOf<BAMD_Q6_K> { typedef RecQ6K type; };
 
+// The fields a launch needs for its FIRST requests travel as leading scalar kernel parameters: with -amdgpu-kernarg-preload-count the
+// hardware places them in SGPRs at wave launch (gfx950 kernarg preload), so the activation and ring requests do not wait for an s_load of
+// the argument block; the struct behind them carries everything else.
+#define BAMD_LEAD_PARAMS const float * x_, const float * nw_, const void * w0_, const void * w1_, int K_, float eps_
+#define BAMD_LEAD_TAKE(a_) do { (a_).x = x_; (a_).normw = nw_; (a_).seg[0].w = w0_; (a_).seg[1].w = w1_; (a_).K = K_; (a_).eps = eps_; } while (0)
+#define BAMD_LEAD_ARGS(a_) (a_).x, (a_).normw, (a_).seg[0].w, (a_).seg[1].w, (a_).K, (a_).eps
 __device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned char * smem) {
     const int nb = a.K >> 8;
     ProArgs pa;

@@ -14,7 +14,8 @@
 // (a.cnt_q / a.cnt_r = row-groups / wave slots, quotient and remainder).  TYPE1 != 0: two segments of different types with at most one
 // row-group per wave (fused QKV with a Q6_K / Q5_K attn_v): the wave's row-group picks the branch, each branch is straight-line.
 template <int TYPE0, int TYPE1, int PRO, int EPI>
-__global__ void __launch_bounds__(512) matvec_fast_kernel(bamd_mv_args a) {
+__global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+    BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TL_STAMP(a.tl, 0);
     const int nb = a.K >> 8;
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(bamd_mv_args a) {
 // ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
 template <int PRO, int EPI, int T0, int T1>
 static void launch_fast_a_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, a);
+    hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
 }
 template <int PRO, int EPI>
 static bool launch_fast_a_types(const bamd_mv_args & a, int t0, int t1, int grid, hipStream_t s) {

@@ -3,7 +3,8 @@
 #include "bamd_matvec_core.h"
 
 template <int TYPE, int NBW, int M, int PRO, int EPI, bool ONEB>
-__global__ void __launch_bounds__(512) matvec_split_fast_kernel(bamd_mv_args a) {
+__global__ void __launch_bounds__(512) matvec_split_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+    BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TL_STAMP(a.tl, 0);
     const int nb = a.K >> 8;
@@ -113,7 +114,8 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
     }
 }
 template <int TA, int TB, int NBW, int MA>
-__global__ void __launch_bounds__(512) matvec_split_mixed_kernel(bamd_mv_args a) {
+__global__ void __launch_bounds__(512) matvec_split_mixed_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+    BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TL_STAMP(a.tl, 0);
     const int nb = a.K >> 8;
@@ -130,7 +132,7 @@ template <int TA, int TB, int NBW, int MA>
 static void launch_mixed_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (MA + 1) * nb * 256 * 4;
-    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 // fused QKV launch with two differently typed segments; false: shape not covered (mode A takes it)
 bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s) {
@@ -151,7 +153,7 @@ template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false>
 static void launch_fast_b_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (NBW * M > 8 ? 1 : 2) * M * nb * 256 * 4;
-    hipLaunchKernelGGL((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 template <int PRO, int EPI>
 static bool launch_fast_b_types(const bamd_mv_args & a, int t, int nbw, int grid, hipStream_t s) {
