@@ -87,6 +87,18 @@ def main():
         out[k] = dict(n=len(rs), **agg)
         ph = " ".join("p%d %.1f/%.1f/%.1f" % (p, agg["p%d_min" % p], agg["p%d_med" % p], agg["p%d_max" % p]) for p in range(1, 8) if "p%d_med" % p in agg)
         print("%-14s %5d %7.2f %7.2f %6.2f | %s" % (k, len(rs), agg.get("gap_us", 0.0), agg["span_us"], agg["entry_skew_us"], ph))
+    # per-wave exit per launch kind: median over workgroups and layers of (exit of wave w - first entry of the launch)
+    wexit = {}
+    for i in range(tl.shape[0]):
+        if rows[i] is None:
+            continue
+        k = "lm_head" if i == 5 * L else names[i % 5]
+        full = tl[i].astype(np.float64); full[full == 0] = np.nan
+        if np.all(np.isnan(full[:, 16:24])):
+            continue
+        wexit.setdefault(k, []).append(np.nanmedian(full[:, 16:24], axis=0) - rows[i]["start"])
+    for k, v in wexit.items():
+        print("%-10s median exit of waves 0..7 (us): " % k + " ".join("%.1f" % (x / 100.0) for x in np.nanmedian(np.array(v), axis=0)))
     tot = (rows[-1]["end"] - rows[0]["start"]) / 100.0
     print("step (first entry -> last exit): %.1f us" % tot)
     out["step_us"] = tot
