@@ -185,6 +185,14 @@ class Context:
     def stage_token_to(self, token_dev_ptr, stream_ptr):
         _chk(lib().bamd_stage_token_to(self.h, token_dev_ptr, stream_ptr))
 
+    def stage_logits(self, stream_ptr):
+        """host logits of the last stage_step(want_logits=True) on the last stage (synchronises the stream)"""
+        lib().bamd_stage_get_logits.restype = C.POINTER(C.c_float); lib().bamd_stage_get_logits.argtypes = [C.c_void_p, C.c_void_p]
+        ptr = lib().bamd_stage_get_logits(self.h, stream_ptr)
+        if not ptr:
+            raise BamdError("bamd_stage_get_logits failed")
+        return np.ctypeslib.as_array(ptr, shape=(self.model.n_vocab,)).copy()
+
     def stage_argmax(self, stream_ptr):
         t = C.c_int32(0)
         _chk(lib().bamd_stage_argmax(self.h, stream_ptr, C.byref(t)))

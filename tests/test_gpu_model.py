@@ -100,6 +100,48 @@ def test_layer_split_stages_equal_single_stage(bamd, tmp_path):
         s.close()
 
 
+def test_layer_split_context_shift_equals_single_stage(bamd, tmp_path):
+    """Booster's context shift (bamd_kv_seq_rm + bamd_kv_seq_add, applied to every stage's context) through three layer-split stages
+    gives the logits of the single-stage run, which tests/test_gpu_fullsize_ref.py pins to the genuine reference: cells refilled in
+    the same order and K rows re-rotated per stage, greedy tokens identical for 90 steps across two shifts (n_ctx 64)."""
+    import torch
+    p = str(tmp_path / "syn_shift.gguf")
+    gguf.write_synthetic_llama(p, E=512, H=8, Hkv=2, L=4, F=768, V=512, seed=11)
+    n_ctx, n_keep = 64, 4
+    full = bamd.Model(p); cf = bamd.Context(full, n_ctx)
+    stages = [bamd.Model(p, 0, 0, 1, True, False), bamd.Model(p, 0, 1, 3, False, False), bamd.Model(p, 0, 3, 4, False, True)]
+    ctxs = [bamd.Context(s, n_ctx) for s in stages]
+    hid = [torch.zeros(512, dtype=torch.float32, device="cuda") for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    prompt = [(7919 * i + 13) % 512 for i in range(12)]
+    lg = None
+    for pos, t in enumerate(prompt):
+        lg = cf.decode([t], pos)
+        ctxs[0].stage_step(t, pos, None, hid[0].data_ptr(), False, False, stream)
+        ctxs[1].stage_step(t, pos, hid[0].data_ptr(), hid[1].data_ptr(), False, False, stream)
+        ctxs[2].stage_step(t, pos, hid[1].data_ptr(), None, True, False, stream)
+    n_past, shifts = len(prompt), 0
+    for step in range(90):
+        tok = ctxs[2].stage_argmax(stream)
+        assert tok == int(np.argmax(lg)), "step %d after %d shifts" % (step, shifts)
+        if n_past + 1 > n_ctx:
+            n_new = cf.context_shift(n_keep, n_past)
+            for c in ctxs:
+                assert c.context_shift(n_keep, n_past) == n_new
+            n_past = n_new; shifts += 1
+        lg = cf.decode([tok], n_past)
+        ctxs[0].stage_step(tok, n_past, None, hid[0].data_ptr(), False, False, stream)
+        ctxs[1].stage_step(tok, n_past, hid[0].data_ptr(), hid[1].data_ptr(), False, False, stream)
+        ctxs[2].stage_step(tok, n_past, hid[1].data_ptr(), None, True, False, stream)
+        n_past += 1
+    assert shifts == 2
+    assert np.array_equal(ctxs[2].stage_logits(stream).view(np.uint32), lg.view(np.uint32)), "all logits of the last step"
+    for c in ctxs + [cf]:
+        c.close()
+    for s in stages + [full]:
+        s.close()
+
+
 def test_pipeline_schedule_single_gpu(bamd, tmp_path):
     """booster_amd.pipeline.run_pipeline with world = 1 on the GPU == bamd_decode greedy loop (token feedback on the device)."""
     import torch
