@@ -543,11 +543,11 @@ static void launch_attn_fused(const bamd_attn_args & a, int gq, dim3 grid, size_
 int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
     if (a.hd > 256 || (a.hd & 63) || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || !a.batch) return 1;
-    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    if (gq < 1 || gq > 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
     // as many query heads of a KV head per workgroup as have their score rows fit the LDS (ld floats each: the probabilities replace
     // the scores in place); a single head per workgroup runs on attn_fused_kernel (separate rows: 2 x ld floats)
-    int gqh = gq;
+    int gqh = (gq == 2 || gq == 4 || gq == 8) ? gq : 1;          // other ratios (3: Llama-3.2-3B): one query head per workgroup
     while (gqh > 1 && (size_t) gqh * ld * 4 > BAMD_ATTN_LDS_MAX) gqh >>= 1;
     const size_t lds_g = (size_t) gqh * ld * 4;
     const dim3 grid(a.Hkv * gq / (gqh > 1 ? gqh : 1), T);
@@ -560,7 +560,7 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
 
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
-    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return 1;
+    if (gq < 1 || gq > 8) return 1;
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
     if (a.cellpos && max_tiles >= 0) return 1;                  // shifted cells: the three-launch path only (the caller passes -tiles)
     if (max_tiles >= 0 && !(ld & 63) && (size_t) ld * 8 <= BAMD_ATTN_LDS_MAX) {
@@ -585,10 +585,10 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
             default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, false>), g1, dim3(512), 0, s, a); break; \
         } \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
-        if (G >= 2) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2 > 0 ? G / 2 : 1)), 0, s, a, gq); /* two workgroups per KV head: all 256 CUs at Hkv x hd/8 = 128 */ \
+        if ((G & 1) == 0) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2)), 0, s, a, gq); /* even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128) */ \
         else hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \
         break;
-        CASE(1) CASE(2) CASE(4) CASE(8)
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: return 1;
     }

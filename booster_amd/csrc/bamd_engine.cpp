@@ -222,7 +222,7 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     }
     if (m->H % m->Hkv) return fail("n_head % n_head_kv != 0");
     const int gq = m->H / m->Hkv;
-    if (gq != 1 && gq != 2 && gq != 4 && gq != 8) return fail("GQA ratio must be 1, 2, 4 or 8");
+    if (gq < 1 || gq > 8) return fail("GQA ratio (heads per KV head) must be 1 .. 8");
     if (m->hd % 64 || m->hd > 256) return fail("head dim must be 64, 128, 192 or 256");
     if (m->E % 256 || m->F % 256) return fail("n_embd and n_ff must be multiples of 256");
     if (m->E > 32768 || m->F > 131072) return fail("n_embd / n_ff beyond what the kernels' LDS budgets were sized for");
@@ -609,7 +609,7 @@ extern "C" int bamd_stage_step(bamd_context * c, int32_t token, const void * tok
 static bool prefill_batch_supported(const bamd_context * c, int pos_hi) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
-    if (!(g_prefill_batch && g_attn_fused && (size_t) attn_lds_ld(c, pos_hi) * 8 <= 144 * 1024 && m->hd <= 256 && (m->hd & 63) == 0 && (gq == 1 || gq == 2 || gq == 4 || gq == 8))) return false;
+    if (!(g_prefill_batch && g_attn_fused && (size_t) attn_lds_ld(c, pos_hi) * 8 <= 144 * 1024 && m->hd <= 256 && (m->hd & 63) == 0 && gq >= 1 && gq <= 8)) return false;
     // every mat-mul needs a kernel: the MFMA kernels take every K-quant at any K; the integer-dot kernel takes any
     // K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
     auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };

@@ -98,7 +98,8 @@ def test_mul_mat_batch_sweep(bamd, po, i, t, K, rows, T, norm, resid):
 
 def attn_cases(n, seed):
     rng = np.random.default_rng(seed)
-    shapes = [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 256), (8, 2, 128), (6, 3, 192), (16, 2, 64)]
+    shapes = [(4, 1, 128), (4, 2, 64), (8, 8, 64), (8, 1, 256), (8, 2, 128), (6, 3, 192), (16, 2, 64),
+              (6, 2, 128), (12, 4, 64), (10, 2, 64), (7, 1, 128), (12, 2, 64)]      # heads per KV head 3 (Llama-3.2-3B), 5, 7, 6
     out = []
     for i in range(n):
         H, Hkv, hd = shapes[int(rng.integers(0, len(shapes)))]
@@ -108,10 +109,10 @@ def attn_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("i,H,Hkv,hd,n_ctx,pos,prefill,long_path", attn_cases(28, 99))
+@pytest.mark.parametrize("i,H,Hkv,hd,n_ctx,pos,prefill,long_path", attn_cases(48, 99))
 def test_attention_sweep(bamd, po, i, H, Hkv, hd, n_ctx, pos, prefill, long_path):
     """one token's attention at random head layouts (GQA 1 / 2 / 4 / 8, head_dim 64 ... 256), context sizes and positions, through the
-    single-launch kernel and through the three-launch path, T = 1 and T > 1 score arithmetic: output, KV-cache bytes (and probabilities on
+    single-launch kernel and through the three-launch path (heads per KV head 1 .. 8), T = 1 and T > 1 score arithmetic: output, KV-cache bytes (and probabilities on
     the three-launch path) against the oracle"""
     from test_gpu_ops import oracle_attention
     rng = np.random.default_rng(5100 + i)
@@ -131,3 +132,64 @@ def test_attention_sweep(bamd, po, i, H, Hkv, hd, n_ctx, pos, prefill, long_path
         got = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=prefill)
     assert np.array_equal(kc, kc2) and np.array_equal(vc, vc2), "case %d: KV store" % i
     assert np.array_equal(bits(got), bits(want)), "case %d: attention output (H %d Hkv %d hd %d n_ctx %d pos %d prefill %d long %d)" % (i, H, Hkv, hd, n_ctx, pos, prefill, long_path)
+
+
+ARCHS = [
+    # E, H, Hkv, L, F, V, type mix, rope_freqs, theta, embd type
+    dict(E=768, H=6, Hkv=2, L=2, F=1280, V=300, mix="q4km", rope_freqs=False, theta=10000.0),       # K/256 = 3 and 5: off the specialised tables
+    dict(E=512, H=8, Hkv=8, L=3, F=1024, V=256, mix="q6k", rope_freqs=True, theta=500000.0),        # MHA, head_dim 64, every matrix Q6_K, llama-3.1 factors
+    dict(E=1024, H=4, Hkv=1, L=2, F=2816, V=520, mix="q5v", rope_freqs=False, theta=500000.0),      # head_dim 256, GQA 4, Q5_K attn_v, F = 11 super-blocks
+    dict(E=2048, H=16, Hkv=2, L=2, F=2048, V=1000, mix="q4km", rope_freqs=False, theta=1000000.0),  # GQA 8, K/256 = 8: the specialised tables
+    dict(E=768, H=4, Hkv=2, L=2, F=2304, V=264, mix="q4k", rope_freqs=True, theta=10000.0),         # head_dim 192
+]
+
+
+def arch_type_fn(mix, L):
+    from booster_amd import gguf
+    if mix == "q6k":
+        return lambda name, il: gguf.Q6_K
+    if mix == "q4k":
+        return lambda name, il: gguf.Q4_K
+    if mix == "q5v":
+        return lambda name, il: gguf.Q5_K if name == "attn_v" else gguf.q4_k_m_type(name, il, L)
+    return None
+
+
+@pytest.mark.parametrize("ai", range(len(ARCHS)))
+def test_model_architecture_sweep(bamd, po, tmp_path, ai):
+    """whole models of odd proportions against the oracle: a 19-token batched prompt (MFMA prefill kernels), the same prompt token by token,
+    then 24 single-token steps and the device-side greedy loop — logits bit for bit"""
+    from booster_amd import gguf
+    a = dict(ARCHS[ai]); mix = a.pop("mix")
+    p = str(tmp_path / ("arch%d.gguf" % ai))
+    gguf.write_synthetic_llama(p, seed=31 + ai, type_fn=arch_type_fn(mix, a["L"]), embd_type=gguf.Q6_K if mix == "q6k" else gguf.Q4_K, **a)
+    r = gguf.GGUFReader(p)
+    om = po.OracleModel(r); oc = po.OracleContext(om, 64, nthreads=8)
+    m = bamd.Model(p); ctx = bamd.Context(m, 64); ctx2 = bamd.Context(m, 64)
+    V = a["V"]
+    prompt = [(7919 * i + 13) % V for i in range(19)]
+    lg_o = oc.decode(prompt, 0)
+    lg_g = ctx.decode(prompt, 0)                            # one micro-batch
+    assert np.array_equal(bits(lg_g), bits(lg_o)), "arch %d: batched prompt, max |d| = %g" % (ai, np.abs(lg_g - lg_o).max())
+    for i, t in enumerate(prompt):                          # the same prompt one token per call: T = 1 arithmetic differs from T > 1 by design
+        lg1 = ctx2.decode([t], i)
+    lg1_o = None
+    oc2 = po.OracleContext(om, 64, nthreads=8)
+    for i, t in enumerate(prompt):
+        lg1_o = oc2.decode([t], i)
+    assert np.array_equal(bits(lg1), bits(lg1_o)), "arch %d: token-by-token prompt" % ai
+    n_past = len(prompt)
+    toks = []
+    for s in range(24):
+        t = int(np.argmax(lg_o)); toks.append(t)
+        lg_o = oc.decode([t], n_past); lg_g = ctx.decode([t], n_past); n_past += 1
+        assert np.array_equal(bits(lg_g), bits(lg_o)), "arch %d: step %d, max |d| = %g" % (ai, s, np.abs(lg_g - lg_o).max())
+    # the device-side loop from the batched prompt's state
+    ctx3 = bamd.Context(m, 64)
+    ctx3.decode(prompt, 0)
+    out, _ = ctx3.generate_greedy(len(prompt), 24)
+    assert [int(x) for x in out[:24]] == toks, "arch %d: device-side greedy tokens" % ai
+    assert np.array_equal(bits(ctx3.last_logits()), bits(lg_o)), "arch %d: logits after the device-side loop" % ai
+    for c in (ctx, ctx2, ctx3):
+        c.close()
+    oc.close(); oc2.close(); m.close()
