@@ -400,13 +400,16 @@ __global__ void __launch_bounds__(512) attn_batch_kernel(bamd_attn_args a, int g
     for (int t0 = 0; t0 < n_kv; t0 += 64) {
         const int i = t0 + r_pos;
         const bool valid = i < n_kv && i <= pos;
+        // unconditional requests (a masked position reads row `pos`, which this micro-batch stored), every chain runs, the mask is a select:
+        // a conditional load is a branch with a full wait at its join
+        const unsigned short * krow = a.kc + (size_t) (valid ? i : pos) * Ekv + hk * hd + e * L;
         uint4 kl[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) kl[g] = (valid && g * 8 < L) ? *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) kl[g] = g * 8 < L ? *(const uint4 *) (krow + g * 8) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int hh = 0; hh < GQH; ++hh) {
-            float v = -INFINITY;                                   // masked (KQ_mask, llama.cpp:14152-14200)
-            if (valid) v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
+            float v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
+            v = valid ? v : -INFINITY;                             // masked (KQ_mask, llama.cpp:14152-14200)
             if (e == 0 && i < n_kv) sc[(size_t) hh * ld + i] = v;
         }
     }
