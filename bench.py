@@ -16,9 +16,10 @@ N > 1: Booster's `gpus:` layer split (llama.cpp:5932-5969), one process per GPU:
        "strong"); the throughput with N independent sequences in flight (Booster's pods) is reported beside it.
 --model 70b: the same with Llama-3-70B Q4_K_M shapes (80 layers; BASELINE config 4 at --gpus 8); m7q6k: Mistral-7B, all Q6_K.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (the quantised mat-vec launches, all weight
-streaming): achieved = algorithmic weight bytes per launch / mean launch duration, measured here with HIP events around
-every launch of an eager step; `traffic` is NOT measured in this run: it is the per-launch HBM read bytes of the committed
+Prints ONE JSON line (rank 0).  `roofline` is for the DOMINANT kernel — the launch kind with the largest share of the step time
+(gate/up on this workload): achieved = its algorithmic weight bytes per launch / its mean launch duration, measured here with HIP
+events around every launch of eager steps; `roofline.per_kind` lists every launch kind the same way and
+`roofline.all_matvec_launches` the average over all weight-streaming launches (the figure round 1 reported); `traffic` is NOT measured in this run: it is the per-launch HBM read bytes of the committed
 rocprofv3 PMC pass (profiles/), quoted for comparison.  `cpu_baseline` times the GENUINE reference CPU path
 (oracle/_ref/ref_bench, built in the build container and shipped prebuilt) on this box's host cores on the same GGUF:
 a 16-token prefill and 32 single-token decode steps, rank 0, N = 1 only.
@@ -196,28 +197,44 @@ def main():
         dt = time.perf_counter() - t0
         n_past += steps
         tok_s = steps / dt
-        # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length
-        L_, MS_, B_ = np.zeros(3), np.zeros(3), np.zeros(3)
+        # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length, per launch kind
+        KINDS = ["qkv", "attention", "other", "wo", "gate_up", "ffn_down", "lm_head"]
+        KERNEL_OF = {"qkv": "matvec_split_fast_kernel / matvec_split_mixed_kernel (fused QKV, RMSNorm prologue)", "wo": "matvec_split_fast_kernel (wo, +residual)",
+                     "gate_up": "matvec_fast_kernel<Q4_K, RMSNorm prologue, silu(gate)*up epilogue> (ffn_gate + ffn_up)", "ffn_down": "matvec_split_fast_kernel (ffn_down, +residual)",
+                     "lm_head": "matvec_fast_kernel<Q6_K, arg-max epilogue> (output)", "attention": "attn_fused_kernel"}
+        LK, MSK, BK = np.zeros(7), np.zeros(7), np.zeros(7)
         ev_over = []
         reps = 4
         for i in range(reps):
-            l, ms, b = ctx.profile_step(n_past - 1)
-            L_ += l[:3]; MS_ += ms[:3]; B_ += b[:3]; ev_over.append(ms[3])
+            l, ms, b = ctx.profile_step_kinds(n_past - 1)
+            LK += l[:7]; MSK += ms[:7]; BK += b[:7]; ev_over.append(ms[7])
+        mv = [0, 3, 4, 5, 6]                                             # the mat-vec launches; 1 = attention, 2 = other
+        L_ = np.array([LK[mv].sum(), LK[1], LK[2]]); MS_ = np.array([MSK[mv].sum(), MSK[1], MSK[2]]); B_ = np.array([BK[mv].sum(), BK[1], BK[2]])
         ev_empty_ms = float(np.median(ev_over))                          # what an EMPTY event pair reads on the same stream
         # An event pair around a kernel adds less than an empty pair reads (the second record overlaps the kernel's tail), so the
         # per-launch overhead is calibrated against the timed region itself: the eager per-launch times of one step, minus the
-        # overhead, must add up to the step time the hipGraph replay measured above.  (Check: rocprofv3's mean mat-vec duration
-        # for the same workload, profiles/r01_kernel_stats.csv.)
+        # overhead, must add up to the step time the hipGraph replay measured above.  (Check: rocprofv3's mean durations
+        # for the same workload, profiles/r02_kernel_stats.csv.)
         step_ms = dt / steps * 1e3
         ev_overhead_ms = min(max((float(MS_.sum()) / reps - step_ms) / (float(L_.sum()) / reps), 0.0), ev_empty_ms)
         mv_bytes_per_launch = B_[0] / L_[0]
         mv_ms_per_launch = max(MS_[0] / L_[0] - ev_overhead_ms, 1e-6)
-        achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
+        family_achieved = mv_bytes_per_launch / (mv_ms_per_launch * 1e-3) / 1e9
+        # the DOMINANT kernel = the launch kind with the largest share of the step time
+        per_kind = {}
+        for k in range(7):
+            if LK[k] > 0:
+                t_ms = max(MSK[k] / LK[k] - ev_overhead_ms, 1e-6)
+                per_kind[KINDS[k]] = dict(launches_per_token=int(LK[k] / reps), us_per_launch=round(t_ms * 1e3, 3), bytes_per_launch=int(BK[k] / LK[k]),
+                                          GBps=round(BK[k] / LK[k] / (t_ms * 1e-3) / 1e9, 1), share_of_step=round(t_ms * LK[k] / reps / step_ms, 4))
+        dom = max((k for k in per_kind if k not in ("other",)), key=lambda k: per_kind[k]["share_of_step"])
+        achieved = per_kind[dom]["GBps"]
         traffic = None                                                   # HBM bytes per launch from the committed PMC pass, if any
         try:
             if args.model == "8b":                                           # quoted from the committed PMC pass of this workload, not measured in this run
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_summary.json")))
-                traffic = int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
+                names = {"gate_up": "matvec_fast_kernel<12, 0, 1, 2>", "lm_head": "matvec_fast_kernel<14, 0, 1, 3>"}
+                traffic = int(pm["per_kernel"][names[dom]]["mean_hbm_read_bytes"]) if dom in names and names[dom] in pm["per_kernel"] else int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
         except Exception:
             pass
         n_kv_avg = N_PROMPT + warmup + steps / 2.0
@@ -234,8 +251,11 @@ def main():
                         prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3), empty_event_pair_us=round(ev_empty_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                           traffic=traffic, traffic_source="profiles/r02_pmc_fetch_summary.json (committed rocprofv3 PMC pass of this workload; not measured in this run)",
-                          kernel="quantised mat-vec launches (matvec_fast_kernel / matvec_split_fast_kernel: Q4_K/Q5_K/Q6_K weights x Q8_K activations, fused prologue/epilogue)",
-                          bytes_per_launch=int(mv_bytes_per_launch), us_per_launch=round(mv_ms_per_launch * 1e3, 3)),
+                          kernel="%s: %s — the launch kind with the largest share of the step (%.1f %%)" % (dom, KERNEL_OF.get(dom, dom), 100.0 * per_kind[dom]["share_of_step"]),
+                          bytes_per_launch=per_kind[dom]["bytes_per_launch"], us_per_launch=per_kind[dom]["us_per_launch"],
+                          per_kind=per_kind,
+                          all_matvec_launches=dict(GBps=round(family_achieved, 1), frac=round(family_achieved / HBM_PEAK_GBS, 4), bytes_per_launch=int(mv_bytes_per_launch),
+                                                   us_per_launch=round(mv_ms_per_launch * 1e3, 3))),
         )
         if not args.no_cpu_baseline:
             try:

@@ -53,7 +53,7 @@ def lib():
         L.bamd_stage_token_to.argtypes = [vp, vp, vp]
         L.bamd_stage_prefill.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp]
         L.bamd_stage_argmax.argtypes = [vp, vp, C.POINTER(C.c_int32)]
-        L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]
+        L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]; L.bamd_profile_step_kinds.argtypes = [vp, ci, vp, vp, vp]
         L.bamd_timeline_step.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
         L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
@@ -153,6 +153,12 @@ class Context:
         self.kv_seq_rm(n_keep, n_keep + n_discard)
         self.kv_seq_add(n_keep + n_discard, n_past, -n_discard)
         return n_past - n_discard
+
+    def profile_step_kinds(self, pos):
+        """per launch kind: [qkv, attention, other, wo, gate/up, ffn_down, lm_head, empty event pair] -> (launches, ms, bytes)"""
+        launches = np.zeros(8, np.int32); ms = np.zeros(8, np.float64); nbytes = np.zeros(8, np.float64)
+        _chk(lib().bamd_profile_step_kinds(self.h, pos, _p(launches), _p(ms), _p(nbytes)))
+        return launches, ms, nbytes
 
     def profile_step(self, pos):
         launches = np.zeros(4, np.int32); ms = np.zeros(4, np.float64); nbytes = np.zeros(4, np.float64)

@@ -383,8 +383,9 @@ extern "C" __attribute__((visibility("default"))) void bamd_kv_cache_clear(bamd_
 // -------------------------------------------------------------------------------------------------------
 struct StepTimer {                 // optional per-launch HIP-event timing (bamd_profile_step)
     bool on = false;
-    std::vector<hipEvent_t> ev; std::vector<int> cls; std::vector<double> bytes;
-    void begin(hipStream_t s, int c, double b) { if (!on) return; hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, s); ev.push_back(a); cls.push_back(c); bytes.push_back(b); }
+    std::vector<hipEvent_t> ev; std::vector<int> cls, kind; std::vector<double> bytes;
+    // c: 0 mat-vec, 1 attention, 2 other; k: which launch of the layer (0 qkv, 1 attention, 2 other, 3 wo, 4 gate/up, 5 ffn_down, 6 lm_head)
+    void begin(hipStream_t s, int c, double b, int k = -1) { if (!on) return; hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, s); ev.push_back(a); cls.push_back(c); kind.push_back(k < 0 ? c : k); bytes.push_back(b); }
     void end(hipStream_t s) { if (!on) return; hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, s); ev.push_back(b); }
 };
 
@@ -433,19 +434,19 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x; a.tl = tl_next(c);
-        if (tm) tm->begin(s, 0, (double) ly.wo.bytes);
+        if (tm) tm->begin(s, 0, (double) ly.wo.bytes, 3);
         bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
         if (tm) tm->end(s);
         // 4. h = silu(Wg . a) * (Wu . a),  a = Q8_K(rms_norm(x2) * ffn_norm)  (llama.cpp:8869-8885)
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wg, c->h); seg_of(a.seg[1], ly.wu, c->h); a.nseg = 2; a.x = c->x2; a.normw = ly.ffn_norm; a.eps = m->eps; a.K = m->E; a.tl = tl_next(c);
-        if (tm) tm->begin(s, 0, (double) (ly.wg.bytes + ly.wu.bytes));
+        if (tm) tm->begin(s, 0, (double) (ly.wg.bytes + ly.wu.bytes), 4);
         bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_SILU_MUL, m->n_cu, s);
         if (tm) tm->end(s);
         // 5. x = x2 + Wd . Q8_K(h)                                          (llama.cpp:8885, :8902)
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wd, c->x); a.nseg = 1; a.x = c->h; a.K = m->F; a.res = c->x2; a.tl = tl_next(c);
-        if (tm) tm->begin(s, 0, (double) ly.wd.bytes);
+        if (tm) tm->begin(s, 0, (double) ly.wd.bytes, 5);
         bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
         if (tm) tm->end(s);
     }
@@ -455,7 +456,7 @@ static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
     bamd_model * m = c->m;
     bamd_mv_args a; memset(&a, 0, sizeof a);
     seg_of(a.seg[0], m->output, c->logits); a.nseg = 1; a.x = c->x; a.normw = m->out_norm; a.eps = m->eps; a.K = m->E; a.best_key = &c->st->best_key; a.tl = tl_next(c);
-    if (tm) tm->begin(s, 0, (double) m->output.bytes);
+    if (tm) tm->begin(s, 0, (double) m->output.bytes, 6);
     bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_ARGMAX, m->n_cu, s);
     if (tm) tm->end(s);
 }
@@ -968,7 +969,9 @@ const GgufFile * bamd_model_gguf(const bamd_model * m) { return m->file.get(); }
 extern "C" __attribute__((visibility("default"))) int bamd_model_device(const bamd_model * m) { return m->device; }
 
 // ---- measurement -----------------------------------------------------------------------------------------
-extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
+// one eager step at position pos with a HIP event pair around every launch; per launch kind (StepTimer::begin) the launch count, the summed
+// event time and the summed algorithmic bytes; entry 7 = what an EMPTY event pair reads on this stream (median of 9)
+static int profile_step_kinds(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) return fail("profile needs a full single-stage model");
     HIPC(hipSetDevice(m->device));
@@ -981,16 +984,15 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
     if (enqueue_layers(c, 0, s, &tm, pos)) return 1;
     enqueue_lm_head(c, s, &tm);
     HIPC(hipStreamSynchronize(s));
-    for (int i = 0; i < 4; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
+    for (int i = 0; i < 8; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
     const int n_kv = std::min(c->n_ctx, (pos + 1 + 31) / 32 * 32);
     for (size_t i = 0; i < tm.cls.size(); ++i) {
         float t = 0.f; hipEventElapsedTime(&t, tm.ev[2 * i], tm.ev[2 * i + 1]);
-        const int k = tm.cls[i];
+        const int k = tm.kind[i];
         launches[k] += 1; ms[k] += t;
-        bytes[k] += k == 1 ? (double) n_kv * m->Hkv * m->hd * 2 * 2 : tm.bytes[i];
+        bytes[k] += tm.cls[i] == 1 ? (double) n_kv * m->Hkv * m->hd * 2 * 2 : tm.bytes[i];
     }
     for (auto e : tm.ev) hipEventDestroy(e);
-    // entry 3: what an empty event pair reads on this stream (median of 9) — subtract it per launch
     {
         std::vector<float> ov;
         for (int i = 0; i < 9; ++i) {
@@ -1000,8 +1002,21 @@ extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_con
             hipEventDestroy(a); hipEventDestroy(b);
         }
         std::sort(ov.begin(), ov.end());
-        launches[3] = 9; ms[3] = ov[4]; bytes[3] = 0;
+        launches[7] = 9; ms[7] = ov[4]; bytes[7] = 0;
     }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bamd_profile_step_kinds(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
+    return profile_step_kinds(c, pos, launches, ms, bytes);
+}
+// the same folded into three classes: [0] all mat-vec launches, [1] attention, [2] other, [3] the empty event pair
+extern "C" __attribute__((visibility("default"))) int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes) {
+    int l[8]; double t[8], b[8];
+    if (profile_step_kinds(c, pos, l, t, b)) return 1;
+    for (int i = 0; i < 4; ++i) { launches[i] = 0; ms[i] = 0; bytes[i] = 0; }
+    const int cls_of[7] = { 0, 1, 2, 0, 0, 0, 0 };
+    for (int k = 0; k < 7; ++k) { launches[cls_of[k]] += l[k]; ms[cls_of[k]] += t[k]; bytes[cls_of[k]] += b[k]; }
+    launches[3] = l[7]; ms[3] = t[7]; bytes[3] = 0;
     return 0;
 }
 

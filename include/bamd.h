@@ -169,6 +169,8 @@ void bamd_set_prefill_batch(int on);   /* 2 = batched, but Q4_K mat-muls on the 
  * KV bytes read).  Entry 3: ms[3] = what an EMPTY event pair reads on that stream (to subtract per launch).
  * Arrays must hold 4 entries. */
 int bamd_profile_step(bamd_context * c, int pos, int * launches, double * ms, double * bytes);
+/* the same per launch kind — arrays of 8: [0] fused QKV, [1] attention, [2] other, [3] wo, [4] gate/up, [5] ffn_down, [6] lm_head, [7] an empty event pair */
+int bamd_profile_step_kinds(bamd_context * c, int pos, int * launches, double * ms, double * bytes);
 
 /* Micro-benchmark: `iters` back-to-back launches of one mat-vec shape on random resident weights (pro: 0 plain,
  * 1 RMSNorm prologue; epi: 0 store, 1 +residual, 2 silu(gate)*up pair, 3 store+arg-max; mode as below). */
