@@ -3,12 +3,18 @@
     python tools/reduce_prefill_profiles.py gpurun_out/pprof profiles r01
 """
 import csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):
+    """gpurun merges every call's output into the same directory: take the file of the LAST run"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 from collections import defaultdict
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_prefill_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), os.path.join(dst, tag + "_prefill_kernel_stats.csv"))
 agg = defaultdict(lambda: defaultdict(list))
-for r in csv.DictReader(open(glob.glob(os.path.join(src, "pmc", "*", "*_counter_collection.csv"))[0])):
+for r in csv.DictReader(open(newest(os.path.join(src, "pmc", "*", "*_counter_collection.csv")))):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE "

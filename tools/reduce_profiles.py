@@ -3,17 +3,23 @@
     python tools/reduce_profiles.py gpurun_out/prof profiles r01
 """
 import csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):
+    """gpurun merges every call's output into the same directory: take the file of the LAST run"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 from collections import defaultdict
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, tag + "_bench_n1.json"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), os.path.join(dst, tag + "_kernel_stats.csv"))
 
 # PMC pass: FETCH_SIZE is reported in KB and, on gfx950, reads half of what a wide coalesced stream fetches (MI355X_MICROARCH.md, HBM)
 agg = defaultdict(list)
-for r in csv.DictReader(open(glob.glob(os.path.join(src, "pmc", "*", "*_counter_collection.csv"))[0])):
+for r in csv.DictReader(open(newest(os.path.join(src, "pmc", "*", "*_counter_collection.csv")))):
     if r["Counter_Name"] == "FETCH_SIZE":
         agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline",
