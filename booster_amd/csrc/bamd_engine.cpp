@@ -89,7 +89,8 @@ struct DevLayer {
 struct bamd_model {
     int device = 0;
     int E = 0, H = 0, Hkv = 0, hd = 0, L = 0, F = 0, V = 0, n_ctx_train = 0, n_rot = 0;
-    float eps = 1e-5f, rope_theta = 10000.f, rope_freq_scale = 1.f;
+    float eps = 1e-5f, rope_theta = 10000.f, rope_freq_scale = 1.f, rope_ext_factor = 0.f, rope_attn_factor = 1.f;
+    int rope_n_ctx_orig = 0;
     int layer_first = 0, layer_last = 0;
     bool with_embd = true, with_output = true;
     std::vector<float> rope_freqs;   // host copy (optional)
@@ -211,14 +212,20 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     m->n_rot = m->hd; if (g.get_u32("llama.rope.dimension_count", u)) m->n_rot = (int) u;
     if (m->n_rot != m->hd) return fail("llama.rope.dimension_count != n_embd/n_head is not supported");
     g.get_f32("llama.rope.freq_base", m->rope_theta);
-    {   // RoPE scaling as llm_load_hparams reads it (llama.cpp:4636-4648): the type defaults to "linear" when the key is absent, the
+    {   // RoPE scaling as llm_load_hparams reads it (llama.cpp:4630-4650): the type defaults to "linear" when the key is absent, the
         // factor comes from rope.scaling.factor or the legacy rope.scale_linear, freq_scale = 1 / factor; a "none" type never scales
-        // (llama_new_context_with_model, llama.cpp:16682-16684).  YaRN is out of scope: rejected.
+        // (llama_new_context_with_model, llama.cpp:16682-16684).  YaRN: ext_factor = 1 (:16686-16688), the magnitude factor is
+        // rope.scaling.attn_factor for every type (:16690), the correction range comes from rope.scaling.original_context_length
+        // (default: the training context; :4630-4631, :16670-16672) with beta_fast 32 / beta_slow 1 (:16441-16442).
         std::string st = "linear"; float factor = 0.f;
         g.get_str("llama.rope.scaling.type", st);
-        if (st != "none" && st != "linear") return fail("rope scaling type \"" + st + "\" not supported");
+        if (st != "none" && st != "linear" && st != "yarn") return fail("rope scaling type \"" + st + "\" not supported");
         if (!g.get_f32("llama.rope.scaling.factor", factor)) g.get_f32("llama.rope.scale_linear", factor);
         m->rope_freq_scale = (factor == 0.f || st == "none") ? 1.0f : 1.0f / factor;
+        m->rope_ext_factor = st == "yarn" ? 1.0f : 0.0f;
+        m->rope_attn_factor = 1.0f; g.get_f32("llama.rope.scaling.attn_factor", m->rope_attn_factor);
+        m->rope_n_ctx_orig = m->n_ctx_train;
+        if (g.get_u32("llama.rope.scaling.original_context_length", u) && u != 0) m->rope_n_ctx_orig = (int) u;
     }
     if (m->H % m->Hkv) return fail("n_head % n_head_kv != 0");
     const int gq = m->H / m->Hkv;
@@ -337,7 +344,7 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
         std::vector<float> tab((size_t) n_ctx * m->hd);
         for (int p = 0; p < n_ctx; ++p)
             rope_row(tab.data() + (size_t) p * m->hd, p, m->hd, m->rope_theta, m->rope_freq_scale, m->rope_freqs.empty() ? nullptr : m->rope_freqs.data(),
-                     0.0f, 1.0f, m->n_ctx_train, 32.0f, 1.0f);
+                     m->rope_ext_factor, m->rope_attn_factor, m->rope_n_ctx_orig, 32.0f, 1.0f);
         if (dev_alloc(c->allocs, (void **) &c->rope, tab.size() * 4)) return 1;
         HIPC(hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     }
@@ -570,7 +577,7 @@ static int kv_update(bamd_context * c, hipStream_t s) {
     std::vector<float> tab(vals.size() * (size_t) m->hd);
     for (size_t j = 0; j < vals.size(); ++j)
         rope_row(tab.data() + j * m->hd, vals[j], m->hd, m->rope_theta, m->rope_freq_scale, m->rope_freqs.empty() ? nullptr : m->rope_freqs.data(),
-                 0.0f, 1.0f, m->n_ctx_train, 32.0f, 1.0f);               // the parameters of the context's own table (bamd_context_new)
+                 m->rope_ext_factor, m->rope_attn_factor, m->rope_n_ctx_orig, 32.0f, 1.0f);   // the parameters of the context's own table (bamd_context_new)
     if (!c->shift_idx && dev_alloc(c->allocs, (void **) &c->shift_idx, (size_t) c->n_ctx_pad * 4)) return 1;
     if (!c->shift_tab) { if (dev_alloc(c->allocs, (void **) &c->shift_tab, (size_t) (c->n_ctx + 1) * m->hd * 4)) return 1; c->shift_tab_cap = c->n_ctx + 1; }
     HIPC(hipMemcpyAsync(c->shift_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));

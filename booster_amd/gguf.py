@@ -213,7 +213,7 @@ def q4_k_m_type_70b(name, il, n_layer=80):
 
 
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
-                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0):
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0, rope_scaling=None):
     """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.
     reuse_layers: generate each (tensor kind, type) once and reuse the bytes in every layer (fast path for the
     multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged)."""
@@ -242,6 +242,15 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
     w.add_f32("llama.attention.layer_norm_rms_epsilon", eps)
     w.add_u32("llama.rope.dimension_count", hd)
     w.add_f32("llama.rope.freq_base", theta)
+    if rope_scaling:                                        # dict(type=..., factor=..., orig_ctx=..., attn_factor=...): llama.rope.scaling.*
+        if "type" in rope_scaling:
+            w.add_str("llama.rope.scaling.type", rope_scaling["type"])
+        if "factor" in rope_scaling:
+            w.add_f32("llama.rope.scaling.factor", float(rope_scaling["factor"]))
+        if "orig_ctx" in rope_scaling:
+            w.add_u32("llama.rope.scaling.original_context_length", int(rope_scaling["orig_ctx"]))
+        if "attn_factor" in rope_scaling:
+            w.add_f32("llama.rope.scaling.attn_factor", float(rope_scaling["attn_factor"]))
     w.add_u32("llama.vocab_size", V)
     if vocab is None:
         w.add_str("tokenizer.ggml.model", "no_vocab")

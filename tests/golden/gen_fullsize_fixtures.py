@@ -7,7 +7,7 @@ numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture c
 prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
 logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
 
-    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift selfextend
+    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift selfextend yarn
 """
 import hashlib
 import os
@@ -30,6 +30,9 @@ CONFIGS = {
     # generation past n_ctx with Booster's context shift (cpp/bridge.cpp:487-503; ref_run's n_keep argument).  A small GQA model,
     # n_ctx 96, 150 generated tokens: three shifts, holes refilled in cell order, K rows re-rotated in place three times over
     "shift": (dict(E=512, H=8, Hkv=2, L=3, F=768, V=512, theta=500000.0), 40, 150, 96),
+    # YaRN rope scaling (llama.rope.scaling.type = "yarn", factor 4, original context 64, attn_factor 1.25): positions on both sides of the
+    # original context, a batched prompt and single-token steps
+    "yarn": (dict(E=512, H=8, Hkv=2, L=3, F=768, V=512, theta=10000.0, n_ctx_train=256, rope_scaling=dict(type="yarn", factor=4.0, orig_ctx=64, attn_factor=1.25)), 90, 40, 256),
     # Self-Extend (cpp/bridge.cpp:507-523 with ga_n = 2, ga_w = 16; ref_run's n_keep = -(100 ga_n + ga_w)): positions compressed window by
     # window, every cell its own rotation delta
     "selfextend": (dict(E=512, H=8, Hkv=2, L=3, F=768, V=512, theta=500000.0), 40, 60, 128),
