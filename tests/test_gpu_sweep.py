@@ -193,3 +193,18 @@ def test_model_architecture_sweep(bamd, po, tmp_path, ai):
     for c in (ctx, ctx2, ctx3):
         c.close()
     oc.close(); oc2.close(); m.close()
+
+
+@pytest.mark.parametrize("t", [12, 13, 14])
+@pytest.mark.parametrize("K,rows", [(28672, 264), (16384, 72), (10240, 1032)])
+def test_mul_mat_vec_large_k(bamd, po, t, K, rows):
+    """K beyond 8192 with one wave per row-group (Llama-3-70B's ffn_down: K = 28672; these shapes run on the generic kernel — a specialised
+    instance measured no faster) against the oracle, with the residual epilogue"""
+    rng = np.random.default_rng(31 * t + K)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    res = rng.standard_normal(rows).astype(np.float32)
+    fast = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=1)
+    generic = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=17)
+    want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0] + res
+    assert np.array_equal(bits(fast), bits(generic)) and np.array_equal(bits(fast), bits(want)), "type %d K %d rows %d" % (t, K, rows)
