@@ -141,6 +141,13 @@ __device__ __forceinline__ void split_dispatch(const uint8_t * w, int nb, int fi
                                                const ProArgs & pa, bool do_pro, float * part0, int & rgctr, int nvalid) {
     const int nbw = nb >> 3;
     ActPro<PRO == BAMD_PRO_NORM> ap, ap2;
+    if (nb & 7) {                                        // uneven K-split (split_supported): NBW = the larger share
+        if (nbw == 5)      split_stream<TYPE, REC, 6, 1, 2, EPI, PRO, false, false, true>(w, nb, first, count, stride, out, res, pa, ap, ap2, do_pro, do_pro, part0, rgctr, nvalid);
+        else if (nbw == 6) split_stream<TYPE, REC, 7, 1, 2, EPI, PRO, false, false, true>(w, nb, first, count, stride, out, res, pa, ap, ap2, do_pro, do_pro, part0, rgctr, nvalid);
+        else if (nbw == 2) split_stream<TYPE, REC, 3, 2, 2, EPI, PRO, false, false, true>(w, nb, first, count, stride, out, res, pa, ap, ap2, do_pro, do_pro, part0, rgctr, nvalid);
+        else __builtin_trap();
+        return;
+    }
     // (records per wave per row-group, row-groups per batch, term buffers): the batch is the prefetch depth.  K = 14336 with M = 2
     // (all of ffn_down's work per workgroup in flight from the first instruction, single-buffered) measured no better for Q4_K and
     // 14 % worse for Q6_K than M = 1: the kernel is instruction-issue bound, not latency bound.
@@ -254,13 +261,15 @@ template <int PRO>
 static void launch_mv_split(const bamd_mv_args & a, int epi, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const int nbw = nb >> 3;
-    const int M = nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8, NBUF = 2;                  // must match split_dispatch
+    const int M = (nb & 7) ? (nbw == 2 ? 2 : 1) : nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8, NBUF = 2;   // must match split_dispatch
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) NBUF * M * nb * 256 * 4;   // 112..128 KiB of term buffers
     if (epi == BAMD_EPI_ADD) hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_ADD>),   dim3(grid), dim3(512), lds, s, a);
     else                     hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_STORE>), dim3(grid), dim3(512), lds, s, a);
 }
 
-static bool split_supported(int nb) { const int nbw = nb >> 3; return (nb & 7) == 0 && (nbw == 1 || nbw == 2 || nbw == 4 || nbw == 7); }
+// K / 256 a multiple of 8 with 1, 2, 4 or 7 records per wave; or uneven shares of 2-3, 5-6, 6-7 records (17..23, 41..47, 49..55 super-blocks:
+// Llama-2-13B's n_embd 5120, Llama-2-7B's n_ff 11008, Llama-2-13B's n_ff 13824)
+static bool split_supported(int nb) { const int nbw = nb >> 3; return (nb & 7) == 0 ? (nbw == 1 || nbw == 2 || nbw == 4 || nbw == 7) : (nbw == 2 || nbw == 5 || nbw == 6); }
 
 static const bool g_mv_generic = [] { const char * e = getenv("BAMD_MV_GENERIC"); return e && e[0] == '1'; }();
 

@@ -125,7 +125,9 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
 
 // ONEB (fast kernels): every workgroup has exactly M row-groups — one batch, no refills, no loop: the waits for the ring stay counted
 // (record by record) instead of one full wait at the loop head
-template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false>
+// UNEVEN: K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks): the first nb % 8 waves take NBW records of
+// a row-group, the others NBW - 1; a wave's ring slot past its share re-requests its last record and its term is not parked (wave-uniform).
+template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false, bool UNEVEN = false>
 __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
                                              ActPro<PRO == BAMD_PRO_NORM> & ap, ActPro<PRO == BAMD_PRO_NORM> & ap2, bool issue_here, bool do_pro,
@@ -137,14 +139,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     const bamd_rsrc rs = weight_rsrc(w);
     const int rgb = nb * RECB;
     const int rg_step = stride * rgb;
-    const int i0 = wave * NBW;                               // this wave's first super-block inside a row
+    const int n_w = UNEVEN ? (NBW - 1) + (wave < (nb & 7) ? 1 : 0) : NBW;                  // this wave's records per row-group
+    const int i0 = UNEVEN ? wave * (NBW - 1) + (wave < (nb & 7) ? wave : (nb & 7)) : wave * NBW;   // its first super-block inside a row
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
     // PLAIN prologue: wave w consumes only the activations of its own K-slice (blocks i0 .. i0+NBW-1), so it quantises exactly
     // those — no workgroup barrier, and a wave starts on its records as soon as ITS blocks are done.  (NORM needs the sum of
     // squares of the whole vector: shared prologue as in mode A.)
     constexpr bool OWN = PRO == BAMD_PRO_PLAIN;
     if (issue_here) {                                        // (the fast kernels issue these at entry)
-        if (OWN) { ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + NBW); if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + NBW); }
+        if (OWN) { ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + n_w); if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + n_w); }
         else BAMD_PRO_ISSUE(ap, pa);                         // activation loads go out FIRST
     }
     // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
@@ -158,15 +161,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         // activation prologue would wait for the whole ring to land before it starts
         if (SMALLK || m < count) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs, bbase + m * rg_step + j * RECB, lane);
+            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs, bbase + m * rg_step + (UNEVEN && j >= n_w ? n_w - 1 : j) * RECB, lane);
         }
     }
     TL_STAMP(pa.tl, 1);
     if (do_pro) {
         if (OWN) {
             static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");
-            ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
-            if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + NBW);
+            ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
+            if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
         } else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
         else BAMD_PRO_FINISH(ap, pa);
     }
@@ -188,9 +191,11 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                     const int s = m * NBW + j;
                     const int ci = i0 + j;
                     pin_rec(ring[s]);
-                    const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
-                    P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
-                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + j * RECB, lane);
+                    if (!UNEVEN || j < n_w) {
+                        const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
+                        P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
+                    }
+                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + (UNEVEN && j >= n_w ? n_w - 1 : j) * RECB, lane);
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1 || s == D - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -202,13 +207,15 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
             // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
             const float4 * P = (const float4 *) (B0 + (size_t) wave * rg_floats);
             RowAcc A = { 0.f, 0.f };
-            for (int i = 0; i < nb; i += 8) {                // nb % 8 == 0 here; the 16-byte LDS reads of 8 blocks issued together
+            int i = 0;
+            for (; i + 8 <= nb; i += 8) {                    // the 16-byte LDS reads of 8 blocks issued together
                 float4 t[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
             }
+            if (UNEVEN) for (; i < nb; ++i) { const float4 t = P[i * 64 + lane]; chain_step<TYPE>(A, t.x, t.y, t.z, t.w); }
             const float val = finish_row<TYPE>(A);
             if ((lane & 7) == 0 && crow < nvalid) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
             if (r0 == 0) TL_STAMP(pa.tl, 5);

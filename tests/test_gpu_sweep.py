@@ -208,3 +208,23 @@ def test_mul_mat_vec_large_k(bamd, po, t, K, rows):
     generic = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=17)
     want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0] + res
     assert np.array_equal(bits(fast), bits(generic)) and np.array_equal(bits(fast), bits(want)), "type %d K %d rows %d" % (t, K, rows)
+
+
+@pytest.mark.parametrize("t", [12, 13, 14])
+@pytest.mark.parametrize("K,rows,norm", [(11008, 520, False), (13824, 264, False), (5120, 640, True), (5120, 1032, False), (4352, 72, True), (12032, 40, False)])
+def test_mul_mat_vec_uneven_split(bamd, po, t, K, rows, norm):
+    """split-K when K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks; 17 and 47 at the edges of the
+    ranges): uneven shares per wave == one wave per row-group == the oracle"""
+    rng = np.random.default_rng(13 * t + K + rows)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32) if norm else None
+    res = None if norm else rng.standard_normal(rows).astype(np.float32)
+    split = bamd.op_mul_mat_vec(t, W, rows, K, x, norm_w=w, eps=1e-5, residual=res, mode=2)
+    rowwise = bamd.op_mul_mat_vec(t, W, rows, K, x, norm_w=w, eps=1e-5, residual=res, mode=1)
+    a = x if w is None else (po.rms_norm(x, 1e-5) * w).astype(np.float32)
+    want = po.mul_mat_q(t, W, rows, K, a, nthreads=8)[0]
+    if res is not None:
+        want = want + res
+    assert np.array_equal(bits(split), bits(want)), "split-K differs from the oracle (type %d K %d rows %d)" % (t, K, rows)
+    assert np.array_equal(bits(rowwise), bits(want)), "row-wise differs from the oracle (type %d K %d rows %d)" % (t, K, rows)
