@@ -2,7 +2,9 @@
   m7q6k : Mistral-7B shapes, every matrix Q6_K (config 5), n_ctx 8192 — greedy decode at a short and at a long sequence
   70b   : the last stage of Llama-3-70B Q4_K_M split over 8 GPUs (config 4): 10 of the 80 layers + output layer — prompt micro-batch and
           greedy decode of that stage alone (what one of the eight GPUs does per token)
-usage: config_bench.py m7q6k|70b"""
+  l2-7b : Llama-2-7B Q4_K_M shapes (MHA: 32 KV heads, n_ff 11008 = 43 super-blocks, vocabulary 32000) — the model family the reference's Janus id
+          table was written for; not a BASELINE configuration
+usage: config_bench.py m7q6k|70b|l2-7b"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -39,6 +41,14 @@ if which == "m7q6k":
     E, F, L, V = 4096, 14336, 32, 32000
     W = (L * (E * (E + 2 * 1024) + E * E + 3 * E * F) + V * E) // 256 * 210
     run(path, V, 8192, 7936, 2 * L * 1024 * 2, W)
+elif which == "l2-7b":
+    path = "/dev/shm/bamd_l2_7b.gguf"
+    if not os.path.exists(path):
+        t0 = time.time()
+        gguf.write_synthetic_llama(path, E=4096, H=32, Hkv=32, L=32, F=11008, V=32000, theta=10000.0, n_ctx_train=4096, seed=7, reuse_layers=True)
+        print("gguf %.1f s" % (time.time() - t0))
+    m_ = b.Model(path); W = m_.weight_bytes; m_.close()
+    run(path, 32000, 4096, 3584, 2 * 32 * 4096 * 2, W)
 else:
     path = "/dev/shm/bamd_70b_stage.gguf"
 
