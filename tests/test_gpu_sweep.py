@@ -211,10 +211,10 @@ def test_mul_mat_vec_large_k(bamd, po, t, K, rows):
 
 
 @pytest.mark.parametrize("t", [12, 13, 14])
-@pytest.mark.parametrize("K,rows,norm", [(11008, 520, False), (13824, 264, False), (5120, 640, True), (5120, 1032, False), (4352, 72, True), (12032, 40, False)])
+@pytest.mark.parametrize("K,rows,norm", [(11008, 520, False), (13824, 264, False), (5120, 640, True), (5120, 1032, False), (4352, 72, True), (12032, 40, False), (3072, 3072, False), (3072, 1032, True), (2304, 24, False), (3840, 520, True)])
 def test_mul_mat_vec_uneven_split(bamd, po, t, K, rows, norm):
-    """split-K when K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks; 17 and 47 at the edges of the
-    ranges): uneven shares per wave == one wave per row-group == the oracle"""
+    """split-K when K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks, Llama-3.2-3B's 3072 = 12; 9, 15, 17
+    and 47 at the edges of the ranges): uneven shares per wave == one wave per row-group == the oracle"""
     rng = np.random.default_rng(13 * t + K + rows)
     W = random_kquant_tensor(t, K, rows, rng)
     x = (rng.standard_normal(K) * 2).astype(np.float32)
