@@ -251,9 +251,13 @@ struct ActPro {
     // SMALLK: the caller guarantees K <= 256 * BAMD_ACT_BATCH * (waves per workgroup), so the first batch is the whole share of this
     // wave and the loops over further batches (whose in-loop requests force a full s_waitcnt at their exit — which would also wait for
     // the weight ring issued before this call) are compiled out
-    template <bool SMALLK = false>
+    struct NoMid { __device__ __forceinline__ void operator()() const { } };
+    // mid: called once behind the first workgroup barrier (NORM) / at the start (plain).  The mode-A kernels request the second half of their
+    // weight ring there: a CU's texture path takes ~1.5 us to accept the requests of eight full rings, every wave sits in its issue stage
+    // for that long, and the barrier behind the sum of squares waited for the last of them
+    template <bool SMALLK = false, typename MID = NoMid>
     __device__ __forceinline__ void finish(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
-                                           uint32_t * q8, int * S, float * yd, double * red) {
+                                           uint32_t * q8, int * S, float * yd, double * red, MID mid = MID()) {
         const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
         const int step = nwaves * BAMD_ACT_BATCH;
         float scale = 1.0f;
@@ -275,13 +279,14 @@ struct ActPro {
             if (lane == 0) red[wave] = s;
             TL_STAMP(tl, 5);
             __syncthreads();
+            mid();
             double tot = 0.0;
             for (int w2 = 0; w2 < nwaves; ++w2) tot += red[w2];
             // sum / n in double (ggml.c:11879).  For n a power of two (4096, 8192) the quotient is an exact scaling, so the product with the
             // exact reciprocal is the same double — without the ~30 dependent f64 instructions of an IEEE division
             const float mean = (K & (K - 1)) == 0 ? (float) (tot * (1.0 / (double) K)) : (float) (tot / (double) K);
             scale = 1.0f / sqrtf(mean + eps);
-        }
+        } else mid();
         quantize_batch(scale, K, wave, q8, S, yd);
         if (!SMALLK) for (int i0 = wave + step; i0 < nb; i0 += step) {
             ActPro<NORM> t; t.issue(x, nw, K, i0);
@@ -528,6 +533,7 @@ struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S
 #define BAMD_PRO_ISSUE(ap, pa) do { (ap).tl = (pa).tl; (ap).issue((pa).x, (pa).nw, (pa).K, wave_id()); } while (0)
 #define BAMD_PRO_FINISH(ap, pa) (ap).finish((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
 #define BAMD_PRO_FINISH_SMALLK(ap, pa) (ap).template finish<true>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
+#define BAMD_PRO_FINISH_SMALLK_MID(ap, pa, mid) (ap).template finish<true>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red, mid)
 
 __device__ __forceinline__ void get_scale_min_k4(int j, const uint8_t * q, int & d, int & m) {
     if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; }

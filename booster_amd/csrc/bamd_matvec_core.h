@@ -58,10 +58,26 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
     // the one of the busy waves: one copy of the prologue, no join in front of the counted waits)
     const int offA = count > 0 ? first * rgb : 0;
     const int fill_step = count > 0 ? RECB : 0;
+#ifndef BAMD_RING_SPLIT
+#define BAMD_RING_SPLIT 1            /* fast mode-A kernels: the second half of the ring is requested behind the prologue's first barrier */
+#endif
+    constexpr bool RSPLIT = BAMD_RING_SPLIT && SMALLK && PRO == BAMD_PRO_NORM;
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
+    for (int s = 0; s < (RSPLIT ? D / 2 : D); ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
     TL_STAMP(pa.tl, 1);
-    if (do_pro) { if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa); else BAMD_PRO_FINISH(ap, pa); }
+    if (do_pro) {
+        if (RSPLIT) {
+            auto second_half = [&]() {
+#pragma unroll
+                for (int s = D / 2; s < D; ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
+            };
+            BAMD_PRO_FINISH_SMALLK_MID(ap, pa, second_half);
+        } else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
+        else BAMD_PRO_FINISH(ap, pa);
+    } else if (RSPLIT) {
+#pragma unroll
+        for (int s = D / 2; s < D; ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
+    }
     TL_STAMP(pa.tl, 2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     for (int r = 0; r < count; ++r) {
@@ -154,25 +170,41 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     // r0+M+m, i.e. a constant M*rg_step further on: the loader needs one wave-uniform base per batch and nothing per record
     int bbase = first * rgb + i0 * RECB;
     REC ring[D];
+#ifndef BAMD_RING_SPLIT_B
+#define BAMD_RING_SPLIT_B 1          /* fast split-K kernels: the second half of the ring is requested behind (inside) the activation prologue */
+#endif
+#ifndef BAMD_RING_SPLIT_MIN
+#define BAMD_RING_SPLIT_MIN 6        /* ... for rings of at least this many records per wave */
+#endif
+    constexpr bool RSPLIT = BAMD_RING_SPLIT_B && SMALLK && !UNEVEN && D >= BAMD_RING_SPLIT_MIN;
+    constexpr int DH = RSPLIT ? D / 2 : D;                   // slots requested before the prologue
+    auto ring_fill = [&](const int s0, const int s1) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        // generic kernels: no redundant requests when the stream is short.  Fast kernels (SMALLK): the launcher picks M <= the row-groups of
-        // every workgroup, so the requests are unconditional — a branch around them costs a full s_waitcnt at the join, i.e. the
-        // activation prologue would wait for the whole ring to land before it starts
-        if (SMALLK || m < count) {
+        for (int m = 0; m < M; ++m) {
+            // generic kernels: no redundant requests when the stream is short.  Fast kernels (SMALLK): the launcher picks M <= the row-groups of
+            // every workgroup, so the requests are unconditional — a branch around them costs a full s_waitcnt at the join, i.e. the
+            // activation prologue would wait for the whole ring to land before it starts
+            if (SMALLK || m < count) {
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs, bbase + m * rg_step + (UNEVEN && j >= n_w ? n_w - 1 : j) * RECB, lane);
+                for (int j = 0; j < NBW; ++j) {
+                    const int sl = m * NBW + j;
+                    if (sl >= s0 && sl < s1) load_rec(ring[sl], rs, bbase + m * rg_step + (UNEVEN && j >= n_w ? n_w - 1 : j) * RECB, lane);
+                }
+            }
         }
-    }
+    };
+    ring_fill(0, DH);
     TL_STAMP(pa.tl, 1);
     if (do_pro) {
         if (OWN) {
             static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");
             ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
+            if (RSPLIT) ring_fill(DH, D);
             if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
-        } else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
+        } else if (RSPLIT) { auto second_half = [&]() { ring_fill(DH, D); }; BAMD_PRO_FINISH_SMALLK_MID(ap, pa, second_half); }
+        else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
         else BAMD_PRO_FINISH(ap, pa);
-    }
+    } else if (RSPLIT) ring_fill(DH, D);
     TL_STAMP(pa.tl, 2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     for (int r0 = 0; r0 < (ONEB ? 1 : count); r0 += M) {

@@ -52,10 +52,14 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
 #pragma unroll
         for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs0, (b + m * grid) * rgbA + (i0 + j) * RA, lane);
     const int lastoff = SAME ? g_last * rgbA : (g_last - nrg0) * rgbB;
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) load_rec(ringL[j], rs1, lastoff + (i0 + j) * RB, lane);
     TL_STAMP(pa.tl, 1);
-    BAMD_PRO_FINISH_SMALLK(ap, pa);
+    // the last row-group's records are requested behind the prologue's first barrier (stream_segment: the texture path of a CU is busy
+    // accepting the first rings for ~1 us, and the barrier would wait for the slowest wave's issue stage)
+    auto last_ring = [&]() {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) load_rec(ringL[j], rs1, lastoff + (i0 + j) * RB, lane);
+    };
+    BAMD_PRO_FINISH_SMALLK_MID(ap, pa, last_ring);
     TL_STAMP(pa.tl, 2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
