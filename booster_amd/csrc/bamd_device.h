@@ -154,6 +154,9 @@ struct ActPro {
     // the loads of this wave's first batch of blocks: issued at kernel entry, AHEAD of the bulk weight prefetch, so the
     // (tiny, latency-critical) activation read is not queued behind megabytes of weight requests
     // blocks i0, i0 + bstride, ... below blimit (defaults: this wave's share of the whole vector, interleaved over the waves)
+    // NB: batch slots in use (compile time) — K = 4096 on eight waves fills two of the four; the others would request the last block again
+    // and run the whole quantisation arithmetic on it for nothing
+    template <int NB = BAMD_ACT_BATCH>
     __device__ __forceinline__ void issue(const float * __restrict__ x, const float * __restrict__ nw, int K, int i0, int bstride = 0, int blimit = 0) {
         const int lane = threadIdx.x & 63;
         if (bstride == 0) { bstride = blockDim.x >> 6; blimit = K >> 8; }
@@ -162,7 +165,7 @@ struct ActPro {
         // batches into one memory round trip each — and held back the weight ring that is issued after them
         okmask = 0;
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int i = i0 + b * bstride;
             const bool ok = i < blimit;
             okmask |= ok ? 1 << b : 0;
@@ -179,12 +182,13 @@ struct ActPro {
     //     0x400000 offset do not touch that byte), and MIN(127, .) (:3617) never binds for |iscale * x| <= 127(1 + 2^-23);
     //   - the sum of the four signed bytes is one v_dot4 against 0x01010101;
     //   - the four wave-max chains are interleaved step by step (DPP results need wait states); row_bcast leaves the result in lane 63.
+    template <int NB = BAMD_ACT_BATCH>
     __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd, int bstride = 0, int blimit = 0) {
         const int lane = threadIdx.x & 63;
         const int nwaves = bstride ? bstride : (int) (blockDim.x >> 6), nb = bstride ? blimit : (K >> 8);
-        uint32_t amaxb[BAMD_ACT_BATCH];
+        uint32_t amaxb[NB];
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             if (NORM) {                                  // y = (x*scale)*w : ggml_vec_scale_f32 then ggml_mul (llama.cpp:7940-7950)
                 v[b].x = (v[b].x * scale) * w[b].x; v[b].y = (v[b].y * scale) * w[b].y;
                 v[b].z = (v[b].z * scale) * w[b].z; v[b].w = (v[b].w * scale) * w[b].w;
@@ -192,25 +196,25 @@ struct ActPro {
             const float a = fmaxf(fmaxf(fmaxf(fabsf(v[b].x), fabsf(v[b].y)), fabsf(v[b].z)), fabsf(v[b].w));
             amaxb[b] = __float_as_uint(a);               // non-negative floats order like their bit patterns
         }
-        uint32_t t[BAMD_ACT_BATCH], wmax[BAMD_ACT_BATCH];
+        uint32_t t[NB], wmax[NB];
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(amaxb[b], (uint32_t) dpp_z<DPP_XOR1>((int) amaxb[b]));
+        for (int b = 0; b < NB; ++b) t[b] = umax_(amaxb[b], (uint32_t) dpp_z<DPP_XOR1>((int) amaxb[b]));
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_XOR2>((int) t[b]));
+        for (int b = 0; b < NB; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_XOR2>((int) t[b]));
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) t[b]));
+        for (int b = 0; b < NB; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_HALF_MIRROR>((int) t[b]));
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_MIRROR>((int) t[b]));
+        for (int b = 0; b < NB; ++b) t[b] = umax_(t[b], (uint32_t) dpp_z<DPP_MIRROR>((int) t[b]));
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x142, 0xa, 0xf, false));   // row_bcast:15
+        for (int b = 0; b < NB; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x142, 0xa, 0xf, false));   // row_bcast:15
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x143, 0xc, 0xf, false));   // row_bcast:31
+        for (int b = 0; b < NB; ++b) t[b] = umax_(t[b], (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t[b], 0x143, 0xc, 0xf, false));   // row_bcast:31
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) wmax[b] = (uint32_t) __builtin_amdgcn_readlane((int) t[b], 63);
+        for (int b = 0; b < NB; ++b) wmax[b] = (uint32_t) __builtin_amdgcn_readlane((int) t[b], 63);
         // the scale comes from the FIRST element of largest magnitude (strict > scan of the reference): lowest lane, lowest element
-        float mine[BAMD_ACT_BATCH];
+        float mine[NB];
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const float M = __uint_as_float(wmax[b]);
             const bool ex = fabsf(v[b].x) == M, ey = fabsf(v[b].y) == M, ez = fabsf(v[b].z) == M;
             float m = v[b].w;                            // branch-free selects, lowest element wins
@@ -219,7 +223,7 @@ struct ActPro {
         }
         int mxv = __float_as_int(1.0f);
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const unsigned long long who = __ballot(amaxb[b] == wmax[b]);
             const int first = __ffsll((long long) who) - 1;
             const int mxb = __builtin_amdgcn_readlane(__float_as_int(mine[b]), first);
@@ -228,7 +232,7 @@ struct ActPro {
         const float isc = -127.f / __int_as_float(mxv);  // lane b: block b (other lanes: -127)
         const float dd = 1.0f / isc;
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int i = i0 + b * nwaves;
             if (i < nb) {                                // wave-uniform
                 const float iscale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isc), b));
@@ -255,7 +259,7 @@ struct ActPro {
     // mid: called once behind the first workgroup barrier (NORM) / at the start (plain).  The mode-A kernels request the second half of their
     // weight ring there: a CU's texture path takes ~1.5 us to accept the requests of eight full rings, every wave sits in its issue stage
     // for that long, and the barrier behind the sum of squares waited for the last of them
-    template <bool SMALLK = false, typename MID = NoMid>
+    template <bool SMALLK = false, typename MID = NoMid, int NB = BAMD_ACT_BATCH>
     __device__ __forceinline__ void finish(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
                                            uint32_t * q8, int * S, float * yd, double * red, MID mid = MID()) {
         const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
@@ -265,7 +269,7 @@ struct ActPro {
             // sum of squares in double (ggml.c:11874-11877), fixed tree order instead of the reference's sequential order
             double s = 0.0;
 #pragma unroll
-            for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 if (okmask >> b & 1) { s += (double) (v[b].x * v[b].x); s += (double) (v[b].y * v[b].y); s += (double) (v[b].z * v[b].z); s += (double) (v[b].w * v[b].w); }
             }
             if (!SMALLK) for (int i0 = wave + step; i0 < nb; i0 += step) {          // only for K > 256 * 4 * nwaves
@@ -287,7 +291,7 @@ struct ActPro {
             const float mean = (K & (K - 1)) == 0 ? (float) (tot * (1.0 / (double) K)) : (float) (tot / (double) K);
             scale = 1.0f / sqrtf(mean + eps);
         } else mid();
-        quantize_batch(scale, K, wave, q8, S, yd);
+        quantize_batch<NB>(scale, K, wave, q8, S, yd);
         if (!SMALLK) for (int i0 = wave + step; i0 < nb; i0 += step) {
             ActPro<NORM> t; t.issue(x, nw, K, i0);
             t.quantize_batch(scale, K, i0, q8, S, yd);
@@ -534,6 +538,9 @@ struct ProArgs { const float * x, * nw; float eps; int K; uint32_t * q8; int * S
 #define BAMD_PRO_FINISH(ap, pa) (ap).finish((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
 #define BAMD_PRO_FINISH_SMALLK(ap, pa) (ap).template finish<true>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red)
 #define BAMD_PRO_FINISH_SMALLK_MID(ap, pa, mid) (ap).template finish<true>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red, mid)
+// the same with NB batch slots (the launcher guarantees K <= 256 * NB * waves)
+#define BAMD_PRO_ISSUE_NB(ap, pa, NB_) do { (ap).tl = (pa).tl; (ap).template issue<NB_>((pa).x, (pa).nw, (pa).K, wave_id()); } while (0)
+#define BAMD_PRO_FINISH_NB_MID(ap, pa, mid, NB_) (ap).template finish<true, decltype(mid), NB_>((pa).x, (pa).nw, (pa).eps, (pa).K, (pa).q8, (pa).S, (pa).yd, (pa).red, mid)
 
 __device__ __forceinline__ void get_scale_min_k4(int j, const uint8_t * q, int & d, int & m) {
     if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; }

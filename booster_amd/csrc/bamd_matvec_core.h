@@ -12,6 +12,9 @@ template <> struct RecOf<BAMD_Q6_K> { typedef RecQ6K type; };
 // The fields a launch needs for its FIRST requests travel as leading scalar kernel parameters: with -amdgpu-kernarg-preload-count the
 // hardware places them in SGPRs at wave launch (gfx950 kernarg preload), so the activation and ring requests do not wait for an s_load of
 // the argument block; the struct behind them carries everything else.
+// activation batch slots of a wave that takes NBW_ blocks of the vector: the first ActPro holds up to BAMD_ACT_BATCH, a second one the rest
+#define BAMD_NB1(NBW_) ((NBW_) < BAMD_ACT_BATCH ? (NBW_) : BAMD_ACT_BATCH)
+#define BAMD_NB2(NBW_) ((NBW_) > BAMD_ACT_BATCH ? (NBW_) - BAMD_ACT_BATCH : 1)
 #define BAMD_LEAD_PARAMS const float * x_, const float * nw_, const void * w0_, const void * w1_, int K_, float eps_
 #define BAMD_LEAD_TAKE(a_) do { (a_).x = x_; (a_).normw = nw_; (a_).seg[0].w = w0_; (a_).seg[1].w = w1_; (a_).K = K_; (a_).eps = eps_; } while (0)
 #define BAMD_LEAD_ARGS(a_) (a_).x, (a_).normw, (a_).seg[0].w, (a_).seg[1].w, (a_).K, (a_).eps
@@ -34,7 +37,7 @@ __device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned ch
 // s_waitcnt vmcnt(N) waits.  The ring is filled BEFORE the activation prologue (weights do not depend on it), so
 // the first HBM round trip overlaps the RMSNorm/Q8_K work.  With PAIR each row-group is streamed twice back to
 // back — gate (wA) then up (wB) — and the epilogue fuses silu(gate)*up.
-template <int TYPE, typename REC, int D, int EPI, int PRO, bool SMALLK = false>
+template <int TYPE, typename REC, int D, int EPI, int PRO, bool SMALLK = false, int NBP = BAMD_ACT_BATCH>
 __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb,
                                                int first, int count, int stride, float * __restrict__ out,
                                                const float * __restrict__ res, const ProArgs & pa, ActPro<PRO == BAMD_PRO_NORM> & ap,
@@ -71,8 +74,8 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
 #pragma unroll
                 for (int s = D / 2; s < D; ++s) load_rec(ring[s], rsA, offA + s * fill_step, lane);
             };
-            BAMD_PRO_FINISH_SMALLK_MID(ap, pa, second_half);
-        } else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
+            BAMD_PRO_FINISH_NB_MID(ap, pa, second_half, NBP);
+        } else if (SMALLK) { auto nm = []() { }; BAMD_PRO_FINISH_NB_MID(ap, pa, nm, NBP); }
         else BAMD_PRO_FINISH(ap, pa);
     } else if (RSPLIT) {
 #pragma unroll
@@ -163,7 +166,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     // squares of the whole vector: shared prologue as in mode A.)
     constexpr bool OWN = PRO == BAMD_PRO_PLAIN;
     if (issue_here) {                                        // (the fast kernels issue these at entry)
-        if (OWN) { ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + n_w); if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + n_w); }
+        if (OWN) { ap.template issue<BAMD_NB1(NBW)>(pa.x, pa.nw, pa.K, i0, 1, i0 + n_w); if (NBW > BAMD_ACT_BATCH) ap2.template issue<BAMD_NB2(NBW)>(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + n_w); }
         else BAMD_PRO_ISSUE(ap, pa);                         // activation loads go out FIRST
     }
     // ring slot (m, j) holds record i0+j of row-group r0+m; after it is consumed it is refilled with the same record of row-group
@@ -198,10 +201,13 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     if (do_pro) {
         if (OWN) {
             static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");
-            ap.quantize_batch(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
+            ap.template quantize_batch<BAMD_NB1(NBW)>(1.0f, pa.K, i0, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
             if (RSPLIT) ring_fill(DH, D);
-            if (NBW > BAMD_ACT_BATCH) ap2.quantize_batch(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
-        } else if (RSPLIT) { auto second_half = [&]() { ring_fill(DH, D); }; BAMD_PRO_FINISH_SMALLK_MID(ap, pa, second_half); }
+            if (NBW > BAMD_ACT_BATCH) ap2.template quantize_batch<BAMD_NB2(NBW)>(1.0f, pa.K, i0 + BAMD_ACT_BATCH, pa.q8, pa.S, pa.yd, 1, i0 + n_w);
+        } else if (SMALLK && !UNEVEN) {                      // shared prologue of a fast kernel: NBW blocks per wave (issued with BAMD_PRO_ISSUE_NB at entry)
+            auto second_half = [&]() { if (RSPLIT) ring_fill(DH, D); };
+            BAMD_PRO_FINISH_NB_MID(ap, pa, second_half, BAMD_NB1(NBW));
+        }
         else if (SMALLK) BAMD_PRO_FINISH_SMALLK(ap, pa);
         else BAMD_PRO_FINISH(ap, pa);
     } else if (RSPLIT) ring_fill(DH, D);

@@ -13,7 +13,8 @@
 // mode A.  TYPE1 == 0: one segment (or the gate/up pair: seg[0] and seg[1] of TYPE0, EPI_SILU_MUL), any number of row-groups per wave
 // (a.cnt_q / a.cnt_r = row-groups / wave slots, quotient and remainder).  TYPE1 != 0: two segments of different types with at most one
 // row-group per wave (fused QKV with a Q6_K / Q5_K attn_v): the wave's row-group picks the branch, each branch is straight-line.
-template <int TYPE0, int TYPE1, int PRO, int EPI>
+// NBP: activation batch slots per wave (K <= 256 * NBP * 8): 2 for K <= 4096, else 4
+template <int TYPE0, int TYPE1, int PRO, int EPI, int NBP>
 __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
     BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -21,7 +22,7 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd
     const int nb = a.K >> 8;
     const ProArgs pa = carve_lds(a, smem);
     ActPro<PRO == BAMD_PRO_NORM> ap;
-    BAMD_PRO_ISSUE(ap, pa);                                  // activation requests: the first memory instructions of the kernel
+    BAMD_PRO_ISSUE_NB(ap, pa, NBP);                          // activation requests: the first memory instructions of the kernel
     const int wave = wave_id(), nwaves = blockDim.x >> 6;
     const int slot = blockIdx.x + gridDim.x * wave;          // consecutive row-groups land on different CUs
     const int stride = gridDim.x * nwaves;
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd
         const int count = a.cnt_q + (slot < a.cnt_r ? 1 : 0);
         const uint8_t * wA = (const uint8_t *) a.seg[0].w;
         const uint8_t * wB = PAIR ? (const uint8_t *) a.seg[1].w : wA;
-        stream_segment<TYPE0, REC0, 8, EPI, PRO, true>(wA, wB, nb, slot, count, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);   // count == 0: prologue only
+        stream_segment<TYPE0, REC0, 8, EPI, PRO, true, NBP>(wA, wB, nb, slot, count, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);   // count == 0: prologue only
     } else {
         typedef typename RecOf<TYPE1 == 0 ? TYPE0 : TYPE1>::type REC1;
         constexpr int T1 = TYPE1 == 0 ? TYPE0 : TYPE1;
@@ -42,10 +43,10 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd
         const int nv1 = a.seg[1].nvalid > 0 ? a.seg[1].nvalid : a.seg[1].nrows;
         if (slot >= nrg0 && slot < nrg0 + nrg1) {
             const uint8_t * w1 = (const uint8_t *) a.seg[1].w;
-            stream_segment<T1, REC1, 8, EPI, PRO, true>(w1, w1, nb, slot - nrg0, 1, stride, a.seg[1].out, a.res, pa, ap, false, true, best, nv1);
+            stream_segment<T1, REC1, 8, EPI, PRO, true, NBP>(w1, w1, nb, slot - nrg0, 1, stride, a.seg[1].out, a.res, pa, ap, false, true, best, nv1);
         } else {                                             // segment 0, or no work (count 0: prologue only)
             const uint8_t * w0 = (const uint8_t *) a.seg[0].w;
-            stream_segment<TYPE0, REC0, 8, EPI, PRO, true>(w0, w0, nb, slot, slot < nrg0 ? 1 : 0, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);
+            stream_segment<TYPE0, REC0, 8, EPI, PRO, true, NBP>(w0, w0, nb, slot, slot < nrg0 ? 1 : 0, stride, a.seg[0].out, a.res, pa, ap, false, true, best, nv0);
         }
     }
     if (EPI == BAMD_EPI_ARGMAX) {
@@ -69,7 +70,8 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd
 // ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
 template <int PRO, int EPI, int T0, int T1>
 static void launch_fast_a_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
+    if ((a.K >> 8) <= 16) hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI, 2>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
+    else                  hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI, 4>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
 }
 template <int PRO, int EPI>
 static bool launch_fast_a_types(const bamd_mv_args & a, int t0, int t1, int grid, hipStream_t s) {

@@ -12,9 +12,9 @@ __global__ void __launch_bounds__(512) matvec_split_fast_kernel(BAMD_LEAD_PARAMS
     ActPro<PRO == BAMD_PRO_NORM> ap, ap2;
     if (PRO == BAMD_PRO_PLAIN) {                             // own K-slice only (see split_stream)
         const int i0 = wave_id() * NBW;
-        ap.issue(pa.x, pa.nw, pa.K, i0, 1, i0 + NBW);
-        if (NBW > BAMD_ACT_BATCH) ap2.issue(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + NBW);
-    } else BAMD_PRO_ISSUE(ap, pa);
+        ap.template issue<BAMD_NB1(NBW)>(pa.x, pa.nw, pa.K, i0, 1, i0 + NBW);
+        if (NBW > BAMD_ACT_BATCH) ap2.template issue<BAMD_NB2(NBW)>(pa.x, pa.nw, pa.K, i0 + BAMD_ACT_BATCH, 1, i0 + NBW);
+    } else BAMD_PRO_ISSUE_NB(ap, pa, BAMD_NB1(NBW));         // shared prologue: wave w takes blocks w, w + 8, ...: NBW of them
     float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double));
     int rgctr = 0;
     const int count = a.cnt_q + ((int) blockIdx.x < a.cnt_r ? 1 : 0);
@@ -59,7 +59,7 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
 #pragma unroll
         for (int j = 0; j < NBW; ++j) load_rec(ringL[j], rs1, lastoff + (i0 + j) * RB, lane);
     };
-    BAMD_PRO_FINISH_SMALLK_MID(ap, pa, last_ring);
+    BAMD_PRO_FINISH_NB_MID(ap, pa, last_ring, BAMD_NB1(NBW));
     TL_STAMP(pa.tl, 2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
     const size_t rg_floats = BAMD_TERM_FLOATS(nb);
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(512) matvec_split_mixed_kernel(BAMD_LEAD_PARAM
     const int nb = a.K >> 8;
     const ProArgs pa = carve_lds(a, smem);
     ActPro<true> ap;
-    BAMD_PRO_ISSUE(ap, pa);
+    BAMD_PRO_ISSUE_NB(ap, pa, BAMD_NB1(NBW));
     float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double));
     const int g_last = MA * (int) gridDim.x + (int) blockIdx.x;       // index of this workgroup's last row-group in the concatenated segments
     if (g_last < (a.seg[0].nrows >> 3)) split_mixed_body<TA, TA, NBW, MA>(a, pa, ap, part0, g_last);
