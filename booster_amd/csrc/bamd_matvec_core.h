@@ -246,12 +246,21 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
             const float4 * P = (const float4 *) (B0 + (size_t) wave * rg_floats);
             RowAcc A = { 0.f, 0.f };
             int i = 0;
-            for (; i + 8 <= nb; i += 8) {                    // the 16-byte LDS reads of 8 blocks issued together
-                float4 t[8];
+            if (nb >= 8) {                                   // the 16-byte LDS reads of 8 blocks issued together, the next 8 in flight behind them
+                float4 t[8], tn[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+                for (int u = 0; u < 8; ++u) t[u] = P[u * 64 + lane];
+                for (; i + 16 <= nb; i += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) tn[u] = P[(i + 8 + u) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = tn[u];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+                i += 8;
             }
             if (UNEVEN) for (; i < nb; ++i) { const float4 t = P[i * 64 + lane]; chain_step<TYPE>(A, t.x, t.y, t.z, t.w); }
             const float val = finish_row<TYPE>(A);
