@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -330,6 +331,7 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
 // variable BOOSTER_GPUS="w0,w1,...,w7"  replaces them with up to eight — same rule, more devices.
 #define BAMD_MAX_GPUS 8
 bool plan_stages(int n_layer, const int * gpu, int n_gpu, int device_count, std::vector<std::pair<int, std::pair<int, int>>> & out, std::string & err) {
+    if (n_layer < 1) { err = "model has no layers"; return false; }
     int n_gpu_layers = 0;
     for (int i = 0; i < n_gpu; ++i) n_gpu_layers += gpu[i];
     if (n_gpu_layers <= 0) { err = "the gpu weights are all zero: this build has no CPU path"; return false; }
@@ -390,8 +392,6 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
             return 0;
         };
         auto stamp = [&](size_t s) -> int { return hipEventRecord(p.stages[s].done, (hipStream_t) p.stages[s].stream()) != hipSuccess; };
-        // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
-        // and shapes without batched kernels, step token by token
         bool batched = n > 1 && n <= 512;
         for (size_t s = 0; s < p.stages.size() && batched; ++s) {
             Stage & st = p.stages[s];
@@ -449,12 +449,8 @@ BAMD_API void init(char * swap, char * debug) {
     bamd_backend_init();
 }
 
-BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_size, int gpu1, int gpu2, int gpu3, int gpu4, int context, int predict,
-                            int32_t mirostat, float mirostat_tau, float mirostat_eta, float temperature, int top_k, float top_p, float typical_p,
-                            float repetition_penalty, int penalty_last_n, int32_t janus, int32_t depth, float scale, float hi, float lo, uint32_t seed,
-                            char * debug) {
-    (void) threads; (void) mirostat; (void) mirostat_tau; (void) mirostat_eta; (void) temperature; (void) top_k; (void) top_p; (void) typical_p;
-    (void) repetition_penalty; (void) penalty_last_n; (void) seed;
+static void * init_context_impl(int idx, char * modelName, int batch_size, int gpu1, int gpu2, int gpu3, int gpu4, int context, int predict,
+                                int32_t janus, int32_t depth, float scale, float hi, float lo, char * debug) {
     if (idx < 0 || idx >= 8 || !modelName) return nullptr;
     { std::lock_guard<std::mutex> lk(g_mu); g_debug = debug ? debug : ""; }
     const std::string path = modelName;                       // the Go side leaks its C.CString; we keep our own copy anyway
@@ -511,8 +507,19 @@ BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_si
     return raw;
 }
 
-BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID, char * prompt) {
-    (void) sessionID;
+// the cgo symbol: sampling parameters other than Janus' are accepted and ignored exactly as the reference's bridge ignores them
+// (cpp/bridge.cpp:118-171 stores them, do_inference only ever calls the Janus sampler); no C++ exception may cross into Go
+BAMD_API void * initContext(int idx, char * modelName, int threads, int batch_size, int gpu1, int gpu2, int gpu3, int gpu4, int context, int predict,
+                            int32_t mirostat, float mirostat_tau, float mirostat_eta, float temperature, int top_k, float top_p, float typical_p,
+                            float repetition_penalty, int penalty_last_n, int32_t janus, int32_t depth, float scale, float hi, float lo, uint32_t seed,
+                            char * debug) {
+    (void) threads; (void) mirostat; (void) mirostat_tau; (void) mirostat_eta; (void) temperature; (void) top_k; (void) top_p; (void) typical_p;
+    (void) repetition_penalty; (void) penalty_last_n; (void) seed;
+    try { return init_context_impl(idx, modelName, batch_size, gpu1, gpu2, gpu3, gpu4, context, predict, janus, depth, scale, hi, lo, debug); }
+    catch (const std::exception & e) { fprintf(stderr, "initContext: %s\n", e.what()); return nullptr; }
+}
+
+static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * prompt) {
     if (idx < 0 || idx >= 8 || !ctx || !jobID || !prompt) return 1;
     Pod & p = *(Pod *) ctx;
     const std::string job = jobID, text = prompt;
@@ -581,6 +588,12 @@ BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID
     j.prompt_eval = p.n_p_eval ? (int64_t) (p.t_p_eval_ms / (double) p.n_p_eval) : 0;
     j.timing = p.n_eval ? (int64_t) (p.t_eval_ms / (double) p.n_eval) : 0;
     return p.n_p_eval + p.n_eval;
+}
+
+BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID, char * prompt) {
+    (void) sessionID;
+    try { return do_inference_impl(idx, ctx, jobID, prompt); }
+    catch (const std::exception & e) { fprintf(stderr, "doInference: %s\n", e.what()); return 1; }
 }
 
 BAMD_API void stopInference(int idx) {

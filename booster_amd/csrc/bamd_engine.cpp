@@ -35,6 +35,16 @@ static int fail(const std::string & m) { g_err = m; return 1; }
 
 extern "C" __attribute__((visibility("default"))) const char * bamd_last_error(void) { return g_err.c_str(); }
 
+// owners for the short-lived HIP objects of the measurement entry points (an early error return must not leak them)
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+};
+struct OwnedStream { hipStream_t s = nullptr; ~OwnedStream() { if (s) hipStreamDestroy(s); } };
+struct OwnedDevMem { void * p = nullptr; ~OwnedDevMem() { if (p) hipFree(p); } };
+struct OwnedGraphExec { hipGraphExec_t g = nullptr; ~OwnedGraphExec() { if (g) hipGraphExecDestroy(g); } };
+
 // -------------------------------------------------------------------------------------------------------
 // RoPE table on the host — ggml_rope_cache_init / rope_yarn / ggml_rope_yarn_corr_dims (ggml.c:13994-14041).
 // cos/sin come from the host libm exactly like the reference's CPU path; the device only looks them up.
@@ -174,6 +184,7 @@ static int upload_mat(bamd_model * m, const GgufTensor * t, DevMat & d, bool kee
         if (stream_dst) d.stream = stream_dst;
         else { if (dev_alloc(m->allocs, &d.stream, stream_bytes)) return 1; if (d.nrows_pad != d.nrows) HIPC(hipMemsetAsync(d.stream, 0, stream_bytes, s)); }
         bamd_launch_repack(rawdev, d.stream, d.type, d.nrows, d.K, s);
+        HIPC(hipGetLastError());
         m->weight_bytes += (int64_t) t->nbytes;
     }
     HIPC(hipStreamSynchronize(s));     // staging buffer is reused by the next tensor
@@ -188,12 +199,7 @@ static int upload_f32(bamd_model * m, const GgufTensor * t, float ** p, int n, h
 }
 
 static int model_load_impl(bamd_model * m, const char * path, int device, int lf, int ll, int with_embd, int with_output) {
-    int ndev = bamd_device_count();
-    if (ndev <= 0) return fail("no HIP device available: libbooster_amd has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail("bad device index");
-    HIPC(hipSetDevice(device));
-    m->device = device;
-    { hipDeviceProp_t p; HIPC(hipGetDeviceProperties(&p, device)); m->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
+    // the file is read and its header validated before any device is touched: a bad file is reported as such on any machine
     m->file.reset(new GgufFile());
     std::string err;
     if (!m->file->open(path, err)) return fail(err);
@@ -208,6 +214,8 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     m->Hkv = m->H; if (g.get_u32("llama.attention.head_count_kv", u)) m->Hkv = (int) u;
     if (!g.get_f32("llama.attention.layer_norm_rms_epsilon", m->eps)) return fail("missing llama.attention.layer_norm_rms_epsilon");
     m->n_ctx_train = 2048; if (g.get_u32("llama.context_length", u)) m->n_ctx_train = (int) u;
+    if (m->E <= 0 || m->L <= 0 || m->F <= 0 || m->H <= 0 || m->Hkv <= 0) return fail("embedding_length, block_count, feed_forward_length and head counts must be positive");
+    if (m->E % m->H) return fail("llama.embedding_length is not a multiple of llama.attention.head_count");
     m->hd = m->E / m->H;
     m->n_rot = m->hd; if (g.get_u32("llama.rope.dimension_count", u)) m->n_rot = (int) u;
     if (m->n_rot != m->hd) return fail("llama.rope.dimension_count != n_embd/n_head is not supported");
@@ -241,14 +249,22 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     if (!te) return fail("missing token_embd.weight");
     if (te->ne.size() != 2 || (int) te->ne[0] != m->E) return fail("token_embd.weight: row length != llama.embedding_length");
     m->V = (int) te->ne[1];
+    if (m->V <= 0) return fail("token_embd.weight: empty vocabulary");
     if (const GgufTensor * rf = g.tensor("rope_freqs.weight")) {
         if (rf->type != BAMD_F32 || (int) rf->ne[0] < m->hd / 2) return fail("bad rope_freqs.weight");
         m->rope_freqs.assign((const float *) rf->data, (const float *) rf->data + m->hd / 2);
     }
+    const int ndev = bamd_device_count();
+    if (ndev <= 0) return fail("no HIP device available: libbooster_amd has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("bad device index");
+    HIPC(hipSetDevice(device));
+    m->device = device;
+    { hipDeviceProp_t p; HIPC(hipGetDeviceProperties(&p, device)); m->n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }
     hipStream_t s; HIPC(hipStreamCreate(&s));
     size_t stage_bytes = 0;
     for (auto & t : g.tensors) stage_bytes = std::max(stage_bytes, t.nbytes);
-    void * staging = nullptr; HIPC(hipMalloc(&staging, stage_bytes));
+    void * staging = nullptr;
+    { const hipError_t e = hipMalloc(&staging, stage_bytes ? stage_bytes : 16); if (e != hipSuccess) { hipStreamDestroy(s); return fail(std::string("staging buffer: ") + hipGetErrorString(e)); } }
     int rc = 0;
     do {
         if (m->with_embd) { if ((rc = upload_mat(m, te, m->tok_embd, true, false, staging, s))) break; }
@@ -718,14 +734,15 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
 extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past) {
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) { fail("bamd_decode needs a stage that owns embedding and output"); return 1; }
-    if (n_tokens < 1 || n_tokens > c->forced_cap) { fail("n_tokens out of range"); return 1; }
-    if (n_past < 0 || n_past + n_tokens > c->n_ctx) { fail("context overflow"); return 1; }
+    if (!tokens || n_tokens < 1) { fail("n_tokens out of range"); return 1; }
+    if (n_past < 0 || n_past > c->n_ctx - n_tokens) { fail("context overflow"); return 1; }
     if (n_tokens > BAMD_PREFILL_CAP && g_prefill_batch) {
         // llama_decode's n_ubatch split (llama.cpp:14615): micro-batches of 512, the logits are those of the last token
         for (int i = 0; i < n_tokens; i += BAMD_PREFILL_CAP)
             if (bamd_decode(c, tokens + i, std::min(BAMD_PREFILL_CAP, n_tokens - i), n_past + i)) return 1;
         return 0;
     }
+    if (n_tokens > c->forced_cap) { fail("n_tokens out of range (token by token evaluation takes at most 4096 per call)"); return 1; }
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
     hipStream_t s = c->stream;
     if (c->cells.active && n_tokens > 1) { fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call"); return 1; }
@@ -870,17 +887,17 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     if (!c->graph && build_graph(c, n_past + n_steps)) return 1;
     c->graph_fused = fused;
     if (set_state(c, n_past, s, true)) return 1;
-    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-    HIPC(hipEventRecord(e0, s));
+    EventPair ev; HIPC(ev.create());
+    HIPC(hipEventRecord(ev.a, s));
     for (int t = 0; t < n_steps; ++t) HIPC(hipGraphLaunch(c->graph, s));
-    HIPC(hipEventRecord(e1, s));
+    HIPC(hipEventRecord(ev.b, s));
     enqueue_begin(c, 0, 0, s);                                        // flush the last arg-max into out_tokens
+    HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(out_tokens, c->out_tokens, (size_t) (n_steps + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPC(hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     c->logits_host_valid = true;
-    if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, ev.a, ev.b));
     return 0;
 }
 
@@ -955,6 +972,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_token_to(bamd_c
 }
 extern "C" __attribute__((visibility("default"))) int bamd_stage_argmax(bamd_context * c, void * hip_stream, int32_t * token) {
     hipStream_t s = (hipStream_t) hip_stream;
+    HIPC(hipSetDevice(c->m->device));
     bamd_step_state h;
     HIPC(hipMemcpyAsync(&h, c->st, sizeof h, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
@@ -1040,31 +1058,34 @@ extern "C" __attribute__((visibility("default"))) int bamd_timeline_step(bamd_co
     const int cap = (int) m->layers.size() * 5 + 1;
     if (cap > cap_launches) return fail("bamd_timeline_step: output buffer too small");
     const size_t bytes = (size_t) cap * BAMD_TL_SLOT_WORDS * 8;
-    unsigned long long * buf = nullptr;
-    HIPC(hipMalloc((void **) &buf, bytes));
+    OwnedDevMem mem;
+    HIPC(hipMalloc(&mem.p, bytes));
+    unsigned long long * buf = (unsigned long long *) mem.p;
     HIPC(hipMemsetAsync(buf, 0, bytes, s));
     int32_t tok = 1;
     HIPC(hipMemcpyAsync(c->forced, &tok, 4, hipMemcpyHostToDevice, s));
     c->tl_base = buf; c->tl_slot = 0; c->tl_cap = cap;
-    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipGraph_t g = nullptr; OwnedGraphExec ge;
+    {
+        const hipError_t eb = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (eb != hipSuccess) { c->tl_base = nullptr; c->tl_slot = 0; c->tl_cap = 0; return fail(std::string("timeline capture: ") + hipGetErrorString(eb)); }
+    }
     enqueue_begin(c, 1, 1, s);
     int rc = enqueue_layers(c, 0, s, nullptr, pos);
     enqueue_lm_head(c, s, nullptr);
     hipError_t e = hipStreamEndCapture(s, &g);
     *n_launches = c->tl_slot;
     c->tl_base = nullptr; c->tl_slot = 0; c->tl_cap = 0;
-    if (rc || e != hipSuccess) { if (g) hipGraphDestroy(g); hipFree(buf); return rc ? rc : fail("timeline capture failed"); }
-    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (rc || e != hipSuccess) { if (g) hipGraphDestroy(g); return rc ? rc : fail("timeline capture failed"); }
+    e = hipGraphInstantiate(&ge.g, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
-    if (e != hipSuccess) { hipFree(buf); return fail("timeline graph instantiate failed"); }
+    if (e != hipSuccess) { ge.g = nullptr; return fail("timeline graph instantiate failed"); }
     for (int r = 0; r < replays; ++r) {
-        if (set_state(c, pos, s, false)) { hipGraphExecDestroy(ge); hipFree(buf); return 1; }
-        HIPC(hipGraphLaunch(ge, s));
+        if (set_state(c, pos, s, false)) return 1;
+        HIPC(hipGraphLaunch(ge.g, s));
     }
     HIPC(hipStreamSynchronize(s));
     HIPC(hipMemcpy(out, buf, (size_t) *n_launches * BAMD_TL_SLOT_WORDS * 8, hipMemcpyDeviceToHost));
-    hipGraphExecDestroy(ge); hipFree(buf);
     return 0;
 }
 
@@ -1091,6 +1112,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_quantize_q8_K(cons
     if (!dx || !dout || (norm_w && !dw)) return fail("device alloc/copy failed");
     HIPC(hipMemset(dout, 0, ob));
     bamd_launch_quantize_q8k_test(dx, dw, eps, (int) k, norm_w != nullptr, dout, nullptr);
+    HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(out_blocks, dout, ob, hipMemcpyDeviceToHost));
     return 0;
@@ -1118,6 +1140,7 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
     if (wB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
     a.x = dx; a.normw = dw; a.eps = eps; a.K = k; a.res = dres; a.best_key = key; a.mode = mode;
     bamd_launch_matvec(a, norm_w ? BAMD_PRO_NORM : BAMD_PRO_PLAIN, epi, n_cu0(), nullptr);
+    HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(y, dy, (size_t) nrows * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1149,6 +1172,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
         a.blob = (const uint8_t *) blob; a.K = k; a.T = T; a.ldo = nrows; a.res = dres;
         if (bamd_launch_matmul_batch(a, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, n_cu0(), nullptr)) return fail("batched mat-mul: unsupported shape");
     }
+    HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(y, dy, (size_t) T * nrows * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1159,6 +1183,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_ffn_gate_up(int ty
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_get_row(int type, const void * w_raw, int nrows, int k, int row, float * y) {
     if (need_device()) return 1;
+    if (type != BAMD_F32 && type != BAMD_F16 && !bamd_is_kquant(type)) return fail("bad type");
+    if (k <= 0 || (bamd_is_kquant(type) && k % 256)) return fail("bad row length");
     if (row < 0 || row >= nrows) return fail("row out of range");
     Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows;
     void * raw = t.up(w_raw, wb); float * dy = (float *) t.up(nullptr, (size_t) k * 4);
@@ -1167,6 +1193,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_get_row(int type, 
     int32_t * forced = (int32_t *) t.up(&row, 4); int32_t * outt = (int32_t *) t.up(nullptr, 64);
     if (!raw || !dy || !st || !forced || !outt) return fail("device alloc/copy failed");
     bamd_launch_step_begin(st, forced, 1, outt, raw, type, k, nrows, dy, 1, nullptr);
+    HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(y, dy, (size_t) k * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1198,7 +1225,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     const bool split_path = (prefill_mode & 2) != 0;   // bit 1: force the three-kernel (long-context) path
     prefill_mode &= 1;
     if (need_device()) return 1;
-    if (pos < 0 || pos >= n_ctx || n_ctx % 32 || H % Hkv) return fail("bad attention shape");
+    if (H <= 0 || Hkv <= 0 || hd <= 0 || hd % 64 || hd > 256 || n_ctx <= 0 || pos < 0 || pos >= n_ctx || n_ctx % 32 || H % Hkv) return fail("bad attention shape");
     Tmp t; const int Ekv = Hkv * hd; const int n_ctx_pad = (n_ctx + 63) / 64 * 64; const size_t kvb = (size_t) n_ctx_pad * Ekv * 2;
     std::vector<float> rope((size_t) n_ctx * hd, 0.f);
     memcpy(rope.data() + (size_t) pos * hd, rope_row_h, (size_t) hd * 4);
@@ -1215,6 +1242,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx_pad; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
     { const int tiles = std::min(std::max(n_ctx / 64, 1), 32);
       if (bamd_launch_attention(a, H / Hkv, split_path ? -tiles : tiles, nullptr)) return fail("unsupported head configuration"); }
+    HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(out, a.out, (size_t) H * hd * 4, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(kd.data(), a.kc, kvb, hipMemcpyDeviceToHost));
@@ -1257,15 +1285,17 @@ extern "C" __attribute__((visibility("default"))) int bamd_bench_matvec(int type
     if (strB) { a.seg[1] = a.seg[0]; a.seg[1].w = strB; a.nseg = 2; }
     a.x = dx; a.normw = dw; a.eps = 1e-5f; a.K = k; a.res = dres; a.best_key = key; a.mode = mode;
     const int ncu = n_cu0();
-    hipStream_t s; HIPC(hipStreamCreate(&s));
+    if (iters < 1) return fail("iters < 1");
+    OwnedStream os; HIPC(hipStreamCreate(&os.s));
+    hipStream_t s = os.s;
     for (int i = 0; i < 3; ++i) bamd_launch_matvec(a, pro, epi, ncu, s);
-    hipEvent_t e0, e1; HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-    HIPC(hipEventRecord(e0, s));
+    HIPC(hipGetLastError());
+    EventPair ev; HIPC(ev.create());
+    HIPC(hipEventRecord(ev.a, s));
     for (int i = 0; i < iters; ++i) bamd_launch_matvec(a, pro, epi, ncu, s);
-    HIPC(hipEventRecord(e1, s));
+    HIPC(hipEventRecord(ev.b, s));
     HIPC(hipStreamSynchronize(s));
-    float ms = 0.f; HIPC(hipEventElapsedTime(&ms, e0, e1));
+    float ms = 0.f; HIPC(hipEventElapsedTime(&ms, ev.a, ev.b));
     *us_per_launch = ms * 1000.0f / (float) iters;
-    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return 0;
 }

@@ -61,3 +61,43 @@ def test_split_model_reads_like_the_single_file(tmp_path):
     os.rename(shards[2] + ".away", shards[2])
     odd = str(tmp_path / "renamed.gguf"); os.rename(shards[0], odd)
     assert probe(odd)[0] == 1                                    # the first shard must carry the -00001-of-0000N.gguf name
+
+
+def _patch_u32(blob, key, value):
+    """overwrite the UINT32 value of one metadata key of a GGUF image (length-prefixed key, u32 type tag 4, u32 value)"""
+    import struct
+    tag = struct.pack("<Q", len(key)) + key.encode() + struct.pack("<I", 4)
+    at = blob.index(tag) + len(tag)
+    return blob[:at] + struct.pack("<I", value) + blob[at + 4:]
+
+
+def test_model_header_is_validated_before_any_device(tmp_path):
+    """a GGUF whose hyper-parameters the kernels cannot take (or that would divide by zero) is refused by name at load, on any machine:
+    the header is read and checked before the first HIP call; only a well-formed file gets as far as 'no HIP device'"""
+    import booster_amd
+    good = str(tmp_path / "ok.gguf")
+    gguf.write_synthetic_llama(good, E=256, H=2, Hkv=1, L=1, F=512, V=64, seed=5)
+    blob = open(good, "rb").read()
+
+    def load_error(image):
+        p = str(tmp_path / "bad.gguf")
+        open(p, "wb").write(image)
+        try:
+            booster_amd.Model(p).close()
+        except booster_amd.BamdError as e:
+            return str(e)
+        return ""
+
+    assert "head counts must be positive" in load_error(_patch_u32(blob, "llama.attention.head_count", 0))
+    assert "head counts must be positive" in load_error(_patch_u32(blob, "llama.attention.head_count_kv", 0))
+    assert "head counts must be positive" in load_error(_patch_u32(blob, "llama.block_count", 0))
+    assert "not a multiple of llama.attention.head_count" in load_error(_patch_u32(blob, "llama.attention.head_count", 3))
+    hd64 = _patch_u32(blob, "llama.rope.dimension_count", 64)
+    assert "n_head % n_head_kv" in load_error(_patch_u32(_patch_u32(hd64, "llama.attention.head_count", 4), "llama.attention.head_count_kv", 3))
+    assert "GQA ratio" in load_error(_patch_u32(_patch_u32(hd64, "llama.embedding_length", 1024), "llama.attention.head_count", 16))
+    assert "rope.dimension_count" in load_error(_patch_u32(blob, "llama.rope.dimension_count", 64))
+    assert "general.architecture" in load_error(blob.replace(b"\x05\x00\x00\x00\x00\x00\x00\x00llama", b"\x05\x00\x00\x00\x00\x00\x00\x00qwen2", 1))
+    assert "GGUF" in load_error(b"GGML" + blob[4:]) or "magic" in load_error(b"GGML" + blob[4:])
+    assert load_error(blob[: len(blob) // 2]) != ""                  # truncated file
+    if booster_amd.device_count() <= 0:
+        assert "no HIP device" in load_error(blob)                    # the well-formed file: refused only for want of a GPU
