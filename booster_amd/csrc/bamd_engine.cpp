@@ -145,7 +145,7 @@ struct bamd_context {
     // phase-stamp blocks (bamd_timeline_step, BAMD_TIMING builds): one block of BAMD_TL_SLOT_WORDS u64 per launch
     unsigned long long * tl_base = nullptr; int tl_slot = 0, tl_cap = 0;
     int bcap = 0;
-    float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr, * bu = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
+    float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
 
@@ -647,7 +647,7 @@ static int ensure_batch_buffers(bamd_context * c) {
     const size_t T = BAMD_PREFILL_CAP, Ekv = (size_t) m->Hkv * m->hd;
     if (dev_alloc(c->allocs, (void **) &c->bx, T * m->E * 4) || dev_alloc(c->allocs, (void **) &c->bx2, T * m->E * 4) ||
         dev_alloc(c->allocs, (void **) &c->bqkv, T * (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->batt, T * m->E * 4) ||
-        dev_alloc(c->allocs, (void **) &c->bh, T * m->F * 4) || dev_alloc(c->allocs, (void **) &c->bu, T * m->F * 4) ||
+        dev_alloc(c->allocs, (void **) &c->bh, T * m->F * 4) ||
         dev_alloc(c->allocs, (void **) &c->bblob, T * bamd_blob_bytes(std::max(m->E, m->F))) ||
         dev_alloc(c->allocs, (void **) &c->bblob16, T * bamd_blob16_bytes(std::max(m->E, m->F)))) return 1;
     c->bcap = (int) T;
@@ -660,9 +660,9 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
     if (epi == BAMD_EPI_SILU_MUL) {
         if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q5_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
             const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
-            if (bamd_launch_matmul_mfma(a.seg[0].w, a.seg[0].type, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, a.ldo, s)) return 1;   // gate -> h
-            if (bamd_launch_matmul_mfma(a.seg[1].w, a.seg[1].type, nv, a.seg[1].nrows, a.K, c->bblob16, T, c->bu, nullptr, a.ldo, s)) return 1;          // up
-            bamd_launch_silu_mul(a.seg[0].out, c->bu, a.seg[0].out, (size_t) T * a.ldo, s);
+            if (bamd_launch_matmul_mfma(a.seg[0].w, a.seg[0].type, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, BAMD_EPI_STORE, a.ldo, s)) return 1;   // gate -> h
+            // up, with h = silu(gate) * up as its epilogue (every element is read and rewritten by the one lane that owns it)
+            if (bamd_launch_matmul_mfma(a.seg[1].w, a.seg[1].type, nv, a.seg[1].nrows, a.K, c->bblob16, T, a.seg[0].out, a.seg[0].out, BAMD_EPI_SILU_MUL, a.ldo, s)) return 1;
             return 0;
         }
         return bamd_launch_matmul_batch(a, epi, m->n_cu, s);
@@ -672,7 +672,7 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
         if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q5_K || a.seg[i].type == BAMD_Q6_K)) {
             const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
             const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
-            if (bamd_launch_matmul_mfma(a.seg[i].w, a.seg[i].type, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, a.ldo, s)) return 1;
+            if (bamd_launch_matmul_mfma(a.seg[i].w, a.seg[i].type, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, res ? BAMD_EPI_ADD : BAMD_EPI_STORE, a.ldo, s)) return 1;
         } else rest.seg[rest.nseg++] = a.seg[i];
     }
     if (rest.nseg) {
@@ -1165,7 +1165,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
     if (impl == 1) {
-        if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
+        if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
     } else {
         bamd_mm_args a; memset(&a, 0, sizeof a);
         a.seg[0].w = str; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows_pad; a.seg[0].nvalid = nrows; a.nseg = 1;

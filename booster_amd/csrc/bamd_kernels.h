@@ -78,10 +78,10 @@ size_t bamd_blob_bytes(int K);
 size_t bamd_blob16_bytes(int K);
 // blob: int8 activations for matmul_batch_kernel (may be null); blob16: f16 copy for the MFMA kernel (may be null)
 void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, void * blob16, hipStream_t s);
-// Q4_K matrices on the matrix cores (exact): out[t][row] = W[row,:] . Q8_K(a_t) (+ res).  1 = type / shape not supported
-int  bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
-                             hipStream_t s);
-void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s);
+// K-quant matrices on the matrix cores (exact): y[t][row] = W[row,:] . Q8_K(a_t); epi BAMD_EPI_STORE: out = y; BAMD_EPI_ADD: out = y + res;
+// BAMD_EPI_SILU_MUL: out = silu(res) * y (res = the gate projection, may alias out).  1 = type / shape not supported
+int  bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int epi,
+                             int ldo, hipStream_t s);
 int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported

@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
             const int row = rt * 16 + 4 * g + i;
             if (t < a.T && row < a.nrows) {
                 const size_t o = (size_t) t * a.ldo + row;
-                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[o]) * val : val;   // SILU_MUL: res = the gate projection
             }
         }
     }
@@ -591,17 +591,11 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
             const int row = rt * 16 + 4 * g + i;
             if (t < a.T && row < a.nrows) {
                 const size_t o = (size_t) t * a.ldo + row;
-                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : val;
+                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[o]) * val : val;   // SILU_MUL: res = the gate projection
             }
         }
     }
 }
-// h[t][i] = silu(gate[t][i]) * up[t][i] — the SILU_MUL epilogue of the mat-vec kernels as its own pass (ggml_v_silu op for op)
-__global__ void __launch_bounds__(256) silu_mul_kernel(const float * __restrict__ gate, const float * __restrict__ up, float * __restrict__ h, size_t n) {
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) h[i] = v_silu(gate[i]) * up[i];
-}
-
 // grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile
 template <int EPI>
 __global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
@@ -686,29 +680,23 @@ int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStrea
     }
     return 0;
 }
-int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int ldo,
-                            hipStream_t s) {
+int bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int epi,
+                            int ldo, hipStream_t s) {
     if ((type != BAMD_Q4_K && type != BAMD_Q5_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 255)) return 1;
+    if (epi != BAMD_EPI_STORE && epi != BAMD_EPI_ADD && epi != BAMD_EPI_SILU_MUL) return 1;
+    if ((epi != BAMD_EPI_STORE) != (res != nullptr)) return 1;
     bamd_mma_args a; a.w = (const uint8_t *) w_stream; a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
     dim3 grid((T + BAMD_MMA_TOK - 1) / BAMD_MMA_TOK, (nrows_pad / 16 + (nrows_pad % 16 ? 1 : 0) + 7) / 8);
-    if (type == BAMD_Q6_K) {
-        const size_t lds6 = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA6_WAVE_LDS;
-        if (res) hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_ADD>),   grid, dim3(512), lds6, s, a);
-        else     hipLaunchKernelGGL((matmul_mfma_q6k_kernel<BAMD_EPI_STORE>), grid, dim3(512), lds6, s, a);
-        return 0;
-    }
+#define BAMD_MMA_LAUNCH(KERNEL, LDS, ...) do { \
+        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(512), LDS, s, a); \
+        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(512), LDS, s, a); \
+        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(512), LDS, s, a); } while (0)
     const size_t lds = BAMD_MMA_NSTAGE * BAMD_MMA_STAGE + 8 * BAMD_MMA_WAVE_LDS;
-    if (type == BAMD_Q5_K) {
-        if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD, true>),   grid, dim3(512), lds, s, a);
-        else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE, true>), grid, dim3(512), lds, s, a);
-        return 0;
-    }
-    if (res) hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_ADD, false>),   grid, dim3(512), lds, s, a);
-    else     hipLaunchKernelGGL((matmul_mfma_q4k_kernel<BAMD_EPI_STORE, false>), grid, dim3(512), lds, s, a);
+    if (type == BAMD_Q6_K) { const size_t lds6 = 2 * BAMD_MMA_STAGE + 8 * BAMD_MMA6_WAVE_LDS; BAMD_MMA_LAUNCH(matmul_mfma_q6k_kernel, lds6); }
+    else if (type == BAMD_Q5_K) BAMD_MMA_LAUNCH(matmul_mfma_q4k_kernel, lds, , true);
+    else                        BAMD_MMA_LAUNCH(matmul_mfma_q4k_kernel, lds, , false);
+#undef BAMD_MMA_LAUNCH
     return 0;
-}
-void bamd_launch_silu_mul(const float * gate, const float * up, float * h, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, gate, up, h, n);
 }
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s) {
     hipLaunchKernelGGL(embed_batch_kernel, dim3(T), dim3(256), 0, s, tokens, (const uint8_t *) embd, embd_type, E, V, x);
