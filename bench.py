@@ -169,6 +169,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     model_name, CFG, _ = MODELS[args.model]
     path = model_path(args.model)
+    if dist is not None:                                  # rank 0 picks the directory (free space changes while it writes): every rank uses its choice
+        box = [path]
+        dist.broadcast_object_list(box, src=0)
+        path = box[0]
     ensure_model(path, rank, args.model)
     if dist is not None:
         dist.barrier()
