@@ -213,10 +213,11 @@ def q4_k_m_type_70b(name, il, n_layer=80):
 
 
 def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_ctx_train=8192, seed=7,
-                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0, rope_scaling=None):
+                          type_fn=None, rope_freqs=False, embd_type=Q4_K, reuse_layers=False, vocab=None, n_split=0, rope_scaling=None, tied=False):
     """Write a synthetic Llama-architecture GGUF (tokenizer.ggml.model = no_vocab) with random K-quant blocks.
     reuse_layers: generate each (tensor kind, type) once and reuse the bytes in every layer (fast path for the
-    multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged)."""
+    multi-GB benchmark model; the arithmetic and the bytes streamed per token are unchanged).
+    tied: no output.weight — the reader falls back to token_embd.weight (Llama-3.2; llama.cpp:6070-6076)."""
     rng = np.random.default_rng(seed)
     _cache = {}
 
@@ -277,8 +278,9 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
 
     w.add_tensor("token_embd.weight", [E, V], embd_type, random_kquant_tensor(embd_type, E, V, rng, amp=np.sqrt(E)))
     w.add_tensor("output_norm.weight", [E], F32, norm())
-    t = type_fn("output", 0)
-    w.add_tensor("output.weight", [E, V], t, random_kquant_tensor(t, E, V, rng, amp=3.0))
+    if not tied:
+        t = type_fn("output", 0)
+        w.add_tensor("output.weight", [E, V], t, random_kquant_tensor(t, E, V, rng, amp=3.0))
     if rope_freqs:
         ff = np.ones(hd // 2, np.float32)
         ff[hd // 4:] = 1.0 + 7.0 * np.arange(hd // 2 - hd // 4, dtype=np.float32) / (hd // 4)

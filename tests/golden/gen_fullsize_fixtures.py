@@ -7,7 +7,7 @@ numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture c
 prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
 logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
 
-    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift selfextend yarn
+    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift selfextend yarn l2_7b l32_3b
 """
 import hashlib
 import os
@@ -36,6 +36,11 @@ CONFIGS = {
     # Self-Extend (cpp/bridge.cpp:507-523 with ga_n = 2, ga_w = 16; ref_run's n_keep = -(100 ga_n + ga_w)): positions compressed window by
     # window, every cell its own rotation delta
     "selfextend": (dict(E=512, H=8, Hkv=2, L=3, F=768, V=512, theta=500000.0), 40, 60, 128),
+    # two more architectures at FULL size (not BASELINE configurations: the kernels' other shape classes).  Llama-2-7B Q4_K_M: no GQA, n_ff 11008
+    # (43 super-blocks: split-K with uneven shares per wave), SPM-sized vocabulary.  Llama-3.2-3B Q4_K_M: n_embd 3072 (12 super-blocks), three
+    # query heads per KV head, rope_freqs, and NO output.weight — lm_head runs on the Q6_K token_embd (tied embeddings, llama.cpp:6070-6076)
+    "l2_7b": (dict(E=4096, H=32, Hkv=32, L=32, F=11008, V=32000, theta=10000.0, n_ctx_train=4096), 64, 64, 256),
+    "l32_3b": (dict(E=3072, H=24, Hkv=8, L=28, F=8192, V=128256, theta=500000.0, rope_freqs=True, tied=True, embd_type=Q6), 64, 64, 256),
 }
 N_KEEP = {"shift": 8, "selfextend": -216}
 
