@@ -200,26 +200,28 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
                                                          float * x, int do_embed) {
     __shared__ int tok_s;
     if (threadIdx.x == 0) {
-        int step = st->step;
-        int tok;
-        const unsigned long long key = st->best_key;         // arg-max of the previous lm_head, 0 = none ran
-        if (key != 0ull) {
-            tok = (int) (0xffffffffu - (uint32_t) (key & 0xffffffffull));
-            out_tokens[st->n_out] = tok; st->n_out += 1;
-        } else tok = 0;
-        if (step < n_forced) tok = forced[step];
-        if (tok < 0 || tok >= V) tok = 0;
-        st->token = tok;
-        if (do_embed) {
-            st->pos = st->pos_base + step;
-            st->cell = st->cell_plus1 ? st->cell_plus1 - 1 + step : st->pos;
-            int n_kv = (st->pos + 1 + 31) / 32 * 32;
-            if (n_kv > st->n_ctx) n_kv = st->n_ctx;
-            st->n_kv = st->n_kv_fixed ? st->n_kv_fixed : n_kv;
-            st->step = step + 1;
+        bamd_step_state h = *st;                              // ONE round trip for the whole state (field by field: a dependent load each)
+        const int step = h.step;
+        const int ftok = step < n_forced ? forced[step] : 0;
+        int tok = 0;
+        if (h.best_key != 0ull) {                             // arg-max of the previous lm_head, 0 = none ran
+            tok = (int) (0xffffffffu - (uint32_t) (h.best_key & 0xffffffffull));
+            out_tokens[h.n_out] = tok; h.n_out += 1;
         }
-        if (do_embed) st->best_key = 0ull;                   // a flush-only call leaves the key for the next generate call
+        if (step < n_forced) tok = ftok;
+        if (tok < 0 || tok >= V) tok = 0;
         tok_s = tok;
+        h.token = tok;
+        if (do_embed) {
+            h.pos = h.pos_base + step;
+            h.cell = h.cell_plus1 ? h.cell_plus1 - 1 + step : h.pos;
+            int n_kv = (h.pos + 1 + 31) / 32 * 32;
+            if (n_kv > h.n_ctx) n_kv = h.n_ctx;
+            h.n_kv = h.n_kv_fixed ? h.n_kv_fixed : n_kv;
+            h.step = step + 1;
+            h.best_key = 0ull;                                // a flush-only call leaves the key for the next generate call
+        }
+        *st = h;
     }
     __syncthreads();
     if (!do_embed) return;
