@@ -50,6 +50,9 @@ def test_execution_modes_agree_at_full_size(bamd, model_path):
         ctx.close()
     bamd.set_prefill_batch(1)
     assert np.array_equal(bits(logits[1]), bits(logits[0])) and np.array_equal(bits(logits[2]), bits(logits[0]))
+    if os.environ.get("BAMD_ATTN_FUSED") == "0" or os.environ.get("BAMD_PREFILL_BATCH") == "0":
+        m.close()
+        return                                               # batched stage prefill is switched off by the environment (reports 'no batched kernels' by design)
     # two stages (16 + 16 layers) == one stage: batched prompt, then a decode step
     s0 = bamd.Model(model_path, 0, 0, 16, True, False); s1 = bamd.Model(model_path, 0, 16, 32, False, True)
     c0, c1 = bamd.Context(s0, 256), bamd.Context(s1, 256)

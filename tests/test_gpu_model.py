@@ -263,7 +263,10 @@ def test_baseline_config_shapes_vs_oracle(bamd, po, tmp_path, cfg):
 def test_stage_prefill_equals_single_stage(bamd, tmp_path):
     """batched prompt micro-batches through three virtual stages (hidden states [T][E] handed over as device buffers) == the
     single-stage batched prefill == token by token; then decode steps on top of the stage KV caches."""
+    import os
     import torch
+    if os.environ.get("BAMD_ATTN_FUSED") == "0" or os.environ.get("BAMD_PREFILL_BATCH") == "0":
+        pytest.skip("the batched prefill kernels are switched off by the environment: bamd_stage_prefill reports 'no batched kernels' by design")
     p = str(tmp_path / "syn4.gguf")
     gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=2, L=4, F=2048, V=512, seed=9)
     full = bamd.Model(p); cf = bamd.Context(full, 128)
