@@ -75,6 +75,7 @@ def test_gpus_split_rule():
         ub = lambda f: min(int(np.searchsorted(splits, np.float32(f), side="right")), dc - 1)   # upper_bound; f < 1 = splits[-1]
         return [ub(np.float32(i) / np.float32(act)) for i in range(n_layer)] + [ub(np.float32(act - 1) / np.float32(act))]
 
+    assert L.bamd_plan_stages_test(0, 100, 0, 0, 0, 1, np.zeros(1, np.int32).ctypes.data_as(C.c_void_p)) == 1     # a model without layers is refused
     cases = [(32, (100, 0, 0, 0), 1), (32, (17, 16, 0, 0), 2), (80, (11, 10, 10, 10), 4), (32, (2, 2, 0, 0), 1), (32, (0, 0, 40, 0), 2), (3, (1, 1, 1, 1), 4)]
     for _ in range(200):
         n_layer = int(rng.integers(1, 90)); dc = int(rng.integers(1, 5))
