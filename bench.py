@@ -233,14 +233,29 @@ def main():
                                           GBps=round(BK[k] / LK[k] / (t_ms * 1e-3) / 1e9, 1), share_of_step=round(t_ms * LK[k] / reps / step_ms, 4))
         dom = max((k for k in per_kind if k not in ("other",)), key=lambda k: per_kind[k]["share_of_step"])
         achieved = per_kind[dom]["GBps"]
-        traffic = None                                                   # HBM bytes per launch from the committed PMC pass, if any
+        # HBM bytes per launch of the dominant kernel, quoted from the NEWEST committed rocprofv3 PMC pass of this workload (profiles/r*_pmc_fetch_summary.json:
+        # FETCH_SIZE in its own pass, x 1024 x 2 per MI355X_MICROARCH.md).  The kernel is found by what it reads, not by a hard-coded template name: the
+        # mat-vec entry whose mean traffic is closest to this launch kind's algorithmic bytes, and it must lie within [0.95, 1.25] x those bytes — anything
+        # else means the summary is of another workload / kernel set, and the field stays null with the reason beside it.
+        traffic, traffic_source = None, None
         try:
-            if args.model == "8b":                                           # quoted from the committed PMC pass of this workload, not measured in this run
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_summary.json")))
-                names = {"gate_up": "matvec_fast_kernel<12, 0, 1, 2>", "lm_head": "matvec_fast_kernel<14, 0, 1, 3>"}
-                traffic = int(pm["per_kernel"][names[dom]]["mean_hbm_read_bytes"]) if dom in names and names[dom] in pm["per_kernel"] else int(pm["matvec_all"]["mean_hbm_read_bytes_per_launch"])
-        except Exception:
-            pass
+            if args.model == "8b":
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.json")))
+                if cands:
+                    pm = json.load(open(cands[-1]))
+                    want = per_kind[dom]["bytes_per_launch"]
+                    mvk = {k: v["mean_hbm_read_bytes"] for k, v in pm["per_kernel"].items() if k.startswith("matvec")}
+                    best = min(mvk, key=lambda k: abs(mvk[k] - want)) if mvk else None
+                    if best is not None and 0.95 * want <= mvk[best] <= 1.25 * want:
+                        traffic = int(mvk[best])
+                        traffic_source = "profiles/%s, kernel %s (committed rocprofv3 --pmc FETCH_SIZE pass of this workload; not measured in this run)" % (os.path.basename(cands[-1]), best)
+                    else:
+                        traffic_source = "no mat-vec kernel in profiles/%s reads within [0.95, 1.25] x %d B per launch (closest: %s = %s B)" % (os.path.basename(cands[-1]), want, best, mvk.get(best))
+                        sys.stderr.write("[bench] roofline.traffic left null: " + traffic_source + "\n")
+        except Exception as e:
+            traffic_source = "failed to read the committed PMC summary: %r" % (e,)
+            sys.stderr.write("[bench] roofline.traffic left null: " + traffic_source + "\n")
         n_kv_avg = N_PROMPT + warmup + steps / 2.0
         kv_bytes_per_pos = 2 * CFG["L"] * CFG["Hkv"] * (CFG["E"] // CFG["H"]) * 2
         bytes_per_token = m.weight_bytes + kv_bytes_per_pos * n_kv_avg
@@ -254,7 +269,7 @@ def main():
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
                         prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3), empty_event_pair_us=round(ev_empty_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                          traffic=traffic, traffic_source="profiles/r02_pmc_fetch_summary.json (committed rocprofv3 PMC pass of this workload; not measured in this run)",
+                          traffic=traffic, traffic_source=traffic_source,
                           kernel="%s: %s — the launch kind with the largest share of the step (%.1f %%)" % (dom, KERNEL_OF.get(dom, dom), 100.0 * per_kind[dom]["share_of_step"]),
                           bytes_per_launch=per_kind[dom]["bytes_per_launch"], us_per_launch=per_kind[dom]["us_per_launch"],
                           per_kind=per_kind,

@@ -132,6 +132,80 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
 }
 
 
+// ---- MODE A, gate/up launch with exactly SEVEN row-group pairs per 8-wave workgroup (n_ff = 7 x 8 x 8 x CUs: Llama-3-8B / Mistral-7B, 14336 rows on
+// 256 CUs).  One pair per wave leaves wave 7 idle: SIMD 3 streams 32 records where SIMDs 0-2 stream 64, and the launch is paced by the younger
+// waves 4-6 (timeline, round 2: waves 0-3 exit at 11.4 us, waves 4-6 at 13.8, wave 7 at 3.4).  Here waves 4-6 stop three quarters into their
+// gate row and their up row (super-blocks 0..CUT-1, CUT = 3 nb / 4), and wave 7 computes the TERMS {d, fs, dmin, pm} of the last quarter of those six rows
+// and parks them in LDS (the split-K kernels' mechanism); waves 4-6 then replay them IN ORDER behind their own chain steps: every SIMD streams
+// 56 records, and each lane's f32 chain is still the reference's sequential chain over super-blocks 0..nb-1 (ggml-quants.c:6937-6941, :6970).
+// HELPER = wave 7; otherwise wave 4 + j of the workgroup (its pair: row-group rg0).  LDS: park[3 pairs][gate | up][nb / 4][64 lanes] float4, flags[3].
+#define BAMD_GU7_PARK_BYTES(nb) ((size_t) 3 * 2 * ((nb) / 4) * 64 * 16)
+template <int TYPE, typename REC, int NBP, bool HELPER>
+__device__ __forceinline__ void stream_pair_short(const uint8_t * __restrict__ wG, const uint8_t * __restrict__ wU, int rg0, int rg_stride, int j,
+                                                  float * __restrict__ out, const ProArgs & pa, ActPro<true> & ap, float4 * park, int * flags, int nvalid) {
+    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
+    constexpr int NB = 16, Q = NB / 4, CUT = NB - Q, D = 8, NREC = HELPER ? 3 * 2 * Q : 2 * CUT;      // 24 records either way
+    static_assert(NREC % D == 0, "whole ring chunks");
+    const int lane = threadIdx.x & 63;
+    const bamd_rsrc rsG = weight_rsrc(wG), rsU = weight_rsrc(wU);
+    const int rgb = NB * RECB;
+    // record i of this wave's sequence (compile-time i): which matrix, which row-group, which super-block
+#define BAMD_GU7_UP(i_)  (HELPER ? (((i_) % (2 * Q)) / Q) == 1 : ((i_) / CUT) == 1)
+#define BAMD_GU7_SB(i_)  (HELPER ? CUT + ((i_) % Q) : (i_) % CUT)
+#define BAMD_GU7_OFF(i_) ((HELPER ? rg0 + ((i_) / (2 * Q)) * rg_stride : rg0) * rgb + BAMD_GU7_SB(i_) * RECB)
+    REC ring[D];
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) load_rec(ring[s], BAMD_GU7_UP(s) ? rsU : rsG, BAMD_GU7_OFF(s), lane);
+    TL_STAMP(pa.tl, 1);
+    auto second_half = [&]() {
+#pragma unroll
+        for (int s = D / 2; s < D; ++s) load_rec(ring[s], BAMD_GU7_UP(s) ? rsU : rsG, BAMD_GU7_OFF(s), lane);
+    };
+    BAMD_PRO_FINISH_NB_MID(ap, pa, second_half, NBP);
+    TL_STAMP(pa.tl, 2);
+    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
+    RowAcc Ag = { 0.f, 0.f }, Au = { 0.f, 0.f };
+#pragma unroll
+    for (int c = 0; c < NREC / D; ++c) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int i = c * D + s;
+            pin_rec(ring[s]);
+            const Terms T = block_terms(ring[s], BAMD_GU7_SB(i), lane, q8, S, yd);
+            if (HELPER) park[((i / (2 * Q)) * 2 + (BAMD_GU7_UP(i) ? 1 : 0)) * Q * 64 + (i % Q) * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+            else if (BAMD_GU7_UP(i)) chain_step<TYPE>(Au, T.d, T.fs, T.dmin, T.pm);
+            else chain_step<TYPE>(Ag, T.d, T.fs, T.dmin, T.pm);
+            if (i + D < NREC) load_rec(ring[s], BAMD_GU7_UP(i + D) ? rsU : rsG, BAMD_GU7_OFF(i + D), lane);
+            if (HELPER && (i % (2 * Q)) == 2 * Q - 1) {            // the six quarter-rows of one pair are parked: tell its wave
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(flags + i / (2 * Q), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == 0) TL_STAMP(pa.tl, 3);
+    }
+    TL_STAMP(pa.tl, 4);
+    if (!HELPER) {
+        while (__hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float4 * Pg = park + (j * 2 + 0) * Q * 64 + lane, * Pu = park + (j * 2 + 1) * Q * 64 + lane;
+        float4 tg[Q], tu[Q];
+#pragma unroll
+        for (int u = 0; u < Q; ++u) { tg[u] = Pg[u * 64]; tu[u] = Pu[u * 64]; }
+#pragma unroll
+        for (int u = 0; u < Q; ++u) chain_step<TYPE>(Ag, tg[u].x, tg[u].y, tg[u].z, tg[u].w);
+#pragma unroll
+        for (int u = 0; u < Q; ++u) chain_step<TYPE>(Au, tu[u].x, tu[u].y, tu[u].z, tu[u].w);
+        const float gate_val = finish_row<TYPE>(Ag), up_val = finish_row<TYPE>(Au);
+        const int row = rg0 * 8 + (lane >> 3);
+        if ((lane & 7) == 0 && row < nvalid) out[row] = v_silu(gate_val) * up_val;
+    }
+#undef BAMD_GU7_UP
+#undef BAMD_GU7_SB
+#undef BAMD_GU7_OFF
+}
+
+
 // ---- MODE B: split-K, one 8-wave workgroup per row-group ------------------------------------------------------
 // For matrices with few row-groups (wq/wk/wv/wo, ffn_down: 512..768 of them) one wave per row-group leaves the chip
 // short of bytes in flight.  Here the 8 waves of a workgroup share a row-group: wave w streams super-blocks

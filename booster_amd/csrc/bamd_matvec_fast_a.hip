@@ -65,6 +65,32 @@ __global__ void __launch_bounds__(512) matvec_fast_kernel(BAMD_LEAD_PARAMS, bamd
     TL_STAMP(a.tl, 7);
 }
 
+// gate/up launch with seven row-group pairs per workgroup (stream_pair_short): waves 0-3 stream a whole pair each, waves 4-6 three quarters of
+// theirs, wave 7 the last quarters of those three pairs.  K = 4096 (16 super-blocks), n_ff = 56 x grid.
+template <int TYPE, int NBP>
+__global__ void __launch_bounds__(512) matvec_gateup7_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+    BAMD_LEAD_TAKE(a);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TL_STAMP(a.tl, 0);
+    const int nb = a.K >> 8;
+    const ProArgs pa = carve_lds(a, smem);
+    ActPro<true> ap;
+    BAMD_PRO_ISSUE_NB(ap, pa, NBP);
+    const int wave = wave_id(), grid = (int) gridDim.x, b = (int) blockIdx.x;
+    float4 * park = (float4 *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double) + 16 * sizeof(unsigned long long));
+    int * flags = (int *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double) + 16 * sizeof(unsigned long long) + BAMD_GU7_PARK_BYTES(16));
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0;             // ordered before their first use by the prologue's workgroup barriers
+    typedef typename RecOf<TYPE>::type REC;
+    const uint8_t * wG = (const uint8_t *) a.seg[0].w, * wU = (const uint8_t *) a.seg[1].w;
+    const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
+    unsigned long long best = 0ull;
+    if (wave < 4) stream_segment<TYPE, REC, 8, BAMD_EPI_SILU_MUL, BAMD_PRO_NORM, true, NBP>(wG, wU, nb, b + grid * wave, 1, grid * 8, a.seg[0].out, a.res, pa, ap, false, true, best, nv);
+    else if (wave < 7) stream_pair_short<TYPE, REC, NBP, false>(wG, wU, b + grid * wave, grid, wave - 4, a.seg[0].out, pa, ap, park, flags, nv);
+    else stream_pair_short<TYPE, REC, NBP, true>(wG, wU, b + grid * 4, grid, 0, a.seg[0].out, pa, ap, park, flags, nv);
+    TL_STAMP(a.tl, 7);
+}
+static const bool g_gateup7 = [] { const char * e = getenv("BAMD_GATEUP7"); return !(e && e[0] == '0'); }();
+
 // mode B (split-K), one segment of one type, NBW = K / 2048 records per wave and row-group, M row-groups per batch
 
 // ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
@@ -97,6 +123,12 @@ bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t 
         if (t1 == t0 || nrg0 + (a.seg[1].nrows >> 3) > slots) return false;
     } else if (a.nseg != 1) return false;
     a.cnt_q = nrg0 / slots; a.cnt_r = nrg0 % slots;
+    if (g_gateup7 && pro == BAMD_PRO_NORM && epi == BAMD_EPI_SILU_MUL && nb == 16 && nrg0 == 7 * grid && (a.mode & 15) == 0) {
+        const size_t lds = act_lds_bytes(a.K) + BAMD_GU7_PARK_BYTES(16) + 16;
+#define BAMD_G7(T_) if (t0 == T_) { hipLaunchKernelGGL((matvec_gateup7_kernel<T_, 2>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
+        BAMD_G7(BAMD_Q4_K) BAMD_G7(BAMD_Q5_K) BAMD_G7(BAMD_Q6_K)
+#undef BAMD_G7
+    }
     if (pro == BAMD_PRO_NORM) {
         if (epi == BAMD_EPI_STORE)    return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_STORE>(a, t0, t1, grid, s);
         if (epi == BAMD_EPI_SILU_MUL) return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_SILU_MUL>(a, t0, 0, grid, s);

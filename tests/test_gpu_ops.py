@@ -90,7 +90,7 @@ def test_mul_mat_vec_norm_residual(bamd, po, t):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024)])
+@pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024), (4096, 14336)])   # 14336 rows on 256 CUs: seven row-group pairs per workgroup (matvec_gateup7_kernel)
 def test_ffn_gate_up(bamd, po, t, K, rows):
     rng = np.random.default_rng(5 * t + K)
     Wg = random_kquant_tensor(t, K, rows, rng, amp=4.0)
