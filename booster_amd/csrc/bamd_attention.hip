@@ -120,7 +120,18 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
     if (lane == 0) redd[wave] = sum;
     __syncthreads();
     double tot = 0.0; for (int w = 0; w < nw; ++w) tot += redd[w];
-    const float fs = (float) (1.0 / tot);
+    double rs = 1.0 / tot;
+    float fs = (float) rs;
+    if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) s[i] = v[k]; }
+        }
+        __syncthreads();
+        if (tid == 0) redd[0] = seq_expsum8(s, n_kv);
+        __syncthreads();
+        rs = 1.0 / redd[0]; fs = (float) rs;
+    }
     if (cached) {
 #pragma unroll
         for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) pr[vperm(i)] = v[k] * fs; }
@@ -312,7 +323,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     double tot = 0.0;
     for (int w = 0; w < 8; ++w) tot += redd[w];
-    const float fs = (float) (1.0 / tot);
+    double rs = 1.0 / tot;
+    float fs = (float) rs;
+    if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+        __syncthreads();
+        if (tid == 0) redd[0] = seq_expsum8(sc, n_kv);
+        __syncthreads();
+        rs = 1.0 / redd[0]; fs = (float) rs;
+    }
     for (int i = tid; i < n_kv; i += blockDim.x) pt[vperm(i)] = sc[i] * fs;
     // half-filled last block (n_kv % 64 == 32): p = 0 for the missing positions, so the chain steps there are exact no-ops
     for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) pt[vperm(i)] = 0.f;
@@ -448,7 +466,14 @@ __global__ void __launch_bounds__(512) attn_batch_kernel(bamd_attn_args a, int g
         const float * s_ = sc + (size_t) hh * ld; float * p_ = pt + (size_t) hh * ld;
         double tot = 0.0;
         for (int w = 0; w < 8; ++w) tot += redd[hh][w];
-        const float fs = (float) (1.0 / tot);
+        double rs = 1.0 / tot;
+        float fs = (float) rs;
+        if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {      // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+            __syncthreads();
+            if (tid == 0) redd[hh][0] = seq_expsum8(s_, n_kv);
+            __syncthreads();
+            rs = 1.0 / redd[hh][0]; fs = (float) rs;
+        }
         // one wave per 64-block: all 64 values are read before the permuted ones are written, so the block is permuted in place;
         // the idle half of a half-filled last block becomes zeros (exact no-ops in the chains)
         for (int i = tid; i < ((n_kv + 63) & ~63); i += blockDim.x) { const float val = i < n_kv ? s_[i] * fs : 0.f; p_[vperm(i)] = val; }

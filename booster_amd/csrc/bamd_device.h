@@ -9,9 +9,10 @@
 // sequential chains over super-blocks, the shape of each horizontal reduction tree) is the one the
 // reference's 256-bit code performs, with one wave lane standing for one SIMD lane.  Compiled with
 // -ffp-contract=off; fused multiply-adds are explicit fmaf().  Do NOT build with -ffast-math.
-// The only deliberate deviation: the two double-precision sums (RMSNorm sum of squares, softmax denominator)
-// are tree-reduced in a fixed order instead of sequentially; their result is rounded to f32 right after, so
-// this cannot be observed except with probability ~1e-8 per reduction.
+// The two double-precision sums (RMSNorm sum of squares, softmax denominator) are sequential in the reference and tree-reduced here;
+// both are rounded to f32 right after (mean, 1/sum), so the order can only show when the tree sum lies within the worst-case reordering
+// error of a rounding boundary of that f32.  f32_rounding_safe() checks exactly that; when it cannot rule a difference out (~1e-5 of the
+// reductions) ONE lane redoes the sum in the reference's order, so the result is the reference's in every case (tests/test_f64_order.py).
 //
 // Reference functions restated here (cpp/ = /root/reference/cpp):
 //   quantize_row_q8_K_ref            ggml/src/ggml-quants.c:3593-3630
@@ -137,6 +138,32 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 __device__ __forceinline__ double wave_sum_f64(double s) {                  // fixed order; wave-uniform result
     s += dpp_d<DPP_XOR1>(s); s += dpp_d<DPP_XOR2>(s); s += dpp_d<DPP_HALF_MIRROR>(s); s += dpp_d<DPP_MIRROR>(s);
     return ((readlane_d(s, 15) + readlane_d(s, 31)) + readlane_d(s, 47)) + readlane_d(s, 63);
+}
+
+// ---- the f64 sums of the reference are SEQUENTIAL (ggml.c:11874-11877 RMSNorm, :2619-2671 softmax); ours are trees ----------------------------
+// Both orders add the same n non-negative terms, so each of them is within (n - 1) u S of the exact sum (u = 2^-53) and they differ by less than
+// 2 n u S; a division / reciprocal adds u more on each side.  If every double within that relative distance of our value rounds to the SAME f32,
+// the reference's f32 is that one too.  Otherwise (the value sits next to a rounding boundary: ~1e-5 of the reductions at n = 4096) the caller
+// recomputes sequentially.  v > 0 finite: a zero or non-finite sum is the same in any order.
+#define BAMD_F64_GUARD_REL(n) ((2.0 * (double) (n) + 8.0) * 1.1102230246251565e-16)
+__device__ __forceinline__ bool f32_rounding_safe(double v, float f, double rel) {
+    const uint32_t fb = __float_as_uint(f);
+    if (!(v > 0.0) || fb == 0u || fb >= 0x7f800000u) return true;             // 0 / inf / nan: order-independent (non-negative terms); f32 underflow to 0: v tiny, far from use
+    const double fd = (double) f;
+    const double hi = 0.5 * (fd + (double) __uint_as_float(fb + 1u)), lo = 0.5 * (fd + (double) __uint_as_float(fb - 1u));   // the neighbouring rounding boundaries (exact in double)
+    const double d = v * rel;
+    return v + d < hi && v - d > lo;
+}
+// the reference's softmax denominator over exp values already stored at vals[0..n) (n % 8 == 0): 8-wide f32 partial sums in the AVX2 tree
+// ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), added to a double one after the other (ggml.c:2635-2644)
+__device__ __forceinline__ double seq_expsum8(const float * vals, int n) {
+    double s = 0.0;
+    for (int i = 0; i < n; i += 8) {
+        const float a0 = vals[i] + vals[i + 4], a1 = vals[i + 1] + vals[i + 5], a2 = vals[i + 2] + vals[i + 6], a3 = vals[i + 3] + vals[i + 7];
+        const float b0 = a0 + a2, b1 = a1 + a3;
+        s += (double) (b0 + b1);
+    }
+    return s;
 }
 
 // One wave quantises BATCH super-blocks at a time (independent dependency chains interleave); lane l holds the 4
@@ -266,7 +293,7 @@ struct ActPro {
         const int step = nwaves * BAMD_ACT_BATCH;
         float scale = 1.0f;
         if (NORM) {
-            // sum of squares in double (ggml.c:11874-11877), fixed tree order instead of the reference's sequential order
+            // sum of squares in double (ggml.c:11874-11877), fixed tree order; f32_rounding_safe() below decides whether the order can matter
             double s = 0.0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -288,7 +315,19 @@ struct ActPro {
             for (int w2 = 0; w2 < nwaves; ++w2) tot += red[w2];
             // sum / n in double (ggml.c:11879).  For n a power of two (4096, 8192) the quotient is an exact scaling, so the product with the
             // exact reciprocal is the same double — without the ~30 dependent f64 instructions of an IEEE division
-            const float mean = (K & (K - 1)) == 0 ? (float) (tot * (1.0 / (double) K)) : (float) (tot / (double) K);
+            double md = (K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K;
+            float mean = (float) md;
+            if (!f32_rounding_safe(md, mean, BAMD_F64_GUARD_REL(K))) {     // workgroup-uniform (every thread holds the same tot); rare
+                __syncthreads();                                            // everybody has read red[]
+                if (threadIdx.x == 0) {                                     // the reference's order, one lane (ggml.c:11874-11877)
+                    double sq = 0.0;
+                    for (int i = 0; i < K; ++i) { const float xv = x[i]; sq += (double) (xv * xv); }
+                    red[0] = sq;
+                }
+                __syncthreads();
+                md = red[0] / (double) K;
+                mean = (float) md;
+            }
             scale = 1.0f / sqrtf(mean + eps);
         } else mid();
         quantize_batch<NB>(scale, K, wave, q8, S, yd);

@@ -504,7 +504,22 @@ static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_ke
 //     llama_kv_cache_seq_rm (ctx, 0, n_keep, n_keep + n_discard);  llama_kv_cache_seq_add(ctx, 0, n_keep + n_discard, n_past, -n_discard);
 // after which cells and positions differ: freed cells are refilled in cell order (find_slot), the attention runs over CELLS (mask by the
 // position each holds), and the K rows of the moved cells are re-rotated by their delta before the next evaluation (K-shift).
+// the cells are back to "cell i holds position i" with nothing pending (e.g. after a plain truncation, seq_rm(n, -1)): stop tracking, so that
+// micro-batches, the device-side greedy loop and the single-launch attention are available again (llama_decode has no such modes to lose)
+static void kv_try_deactivate(bamd_context * c) {
+    bamd_context::Cells & k = c->cells;
+    if (!k.active || k.has_shift) return;
+    for (int i = 0; i < c->n_ctx; ++i) if (k.pos[(size_t) i] != (i < k.used ? i : -1)) return;
+    if (k.head != (k.used >= c->n_ctx ? 0 : k.used)) return;
+    k.active = false;
+    c->n_cached = k.used;
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+}
 static int kv_activate(bamd_context * c) {
+    // cell metadata is edited on the host and copied with blocking copies: nothing of this context may be in flight (the caller's stage
+    // streams are hipStreamNonBlocking, so the null-stream copies below would not wait for them)
+    HIPC(hipDeviceSynchronize());
     if (c->cells.active) return 0;
     bamd_context::Cells & k = c->cells;
     k.pos.assign((size_t) c->n_ctx, -1); k.delta.assign((size_t) c->n_ctx, 0);
@@ -535,6 +550,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_rm(bamd_contex
     }
     if (new_head != c->n_ctx && new_head < k.head) k.head = new_head;
     HIPC(hipMemcpy(c->cellpos, k.pos.data(), (size_t) c->n_ctx * 4, hipMemcpyHostToDevice));
+    kv_try_deactivate(c);
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_kv_seq_add(bamd_context * c, int p0, int p1, int delta) {   // llama_kv_cache_seq_add: llama.cpp:3268-3313

@@ -333,11 +333,9 @@ static void bpe_tokenize(const BamdVocab & v, const std::string & text, std::vec
             lt.assign(word, pt.lo(h), pt.hi(h) - pt.lo(h));
             auto it = v.token_to_id.find(lt);
             if (it != v.token_to_id.end()) { out.push_back(it->second); continue; }
-            for (size_t k = 0; k < lt.size(); ) {                // unknown piece: character by character, dropping what has no token
-                const size_t cl = std::min(lt.size() - k, utf8_len((unsigned char) lt[k]));
-                auto bt = v.token_to_id.find(lt.substr(k, cl));
-                if (bt != v.token_to_id.end()) out.push_back(bt->second);
-                k += cl;
+            for (size_t k = 0; k < lt.size(); ++k) {             // unknown piece: one raw BYTE of the byte-level text at a time (llama-vocab.cpp:575-584:
+                auto bt = v.token_to_id.find(lt.substr(k, 1));   // std::string(1, *j)), dropping what has no token — so the two-byte byte-level
+                if (bt != v.token_to_id.end()) out.push_back(bt->second);    // characters such as U+0120 never match there, as in the reference
             }
         }
     }

@@ -403,3 +403,20 @@ def synthetic_bpe_vocab(n_merges=300, seed=2, pre="llama-bpe"):
     n = len(toks)
     return dict(model="gpt2", pre=pre, tokens=toks, types=types, merges=merges, bos_token_id=n - 4, eos_token_id=n - 3,
                 add_bos_token=False)
+
+
+def synthetic_bpe_vocab_holes(n_merges=300, seed=2):
+    """An INCONSISTENT byte-level BPE vocabulary: every fourth merge's result is not a token (its text is replaced by a placeholder), and a few
+    byte symbols are missing too.  The reference then falls back to single raw bytes of the byte-level text and drops what has no token
+    (llama-vocab.cpp:575-584) — the path a well-formed vocabulary never takes."""
+    v = synthetic_bpe_vocab(n_merges=n_merges, seed=seed)
+    b2u = _bytes_to_unicode()
+    toks = list(v["tokens"])
+    for i in range(0, n_merges, 4):
+        toks[256 + i] = "<hole_%d>" % i
+    for ch in "zq":
+        toks[ord(ch)] = "<nobyte_%s>" % ch
+    toks[toks.index(b2u[ord("\n")])] = "<nobyte_nl>"
+    v["tokens"] = toks
+    return v
+

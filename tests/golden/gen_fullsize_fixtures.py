@@ -2,8 +2,8 @@
 """Full-size fixtures from the GENUINE reference (build container only; needs /root/reference and oracle/_ref/ref_run).
 
 For every BASELINE.json configuration the deterministic synthetic GGUF of that shape (booster_amd.gguf.write_synthetic_llama,
-numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture carries the file's size and a digest of its first
-64 MiB) is evaluated by the reference CPU path (oracle/_ref/ref_run -> llama_decode, cpp/src/llama.cpp:14537) on the synthetic
+numpy Generator seed 7 — the GPU box regenerates the same bytes; the fixture carries the file's size, a sha256 of its first 64 MiB and
+an xxh3-128 of the WHOLE file) is evaluated by the reference CPU path (oracle/_ref/ref_run -> llama_decode, cpp/src/llama.cpp:14537) on the synthetic
 prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
 logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
 
@@ -76,13 +76,45 @@ def ensure_model(cfg):
 
 
 def file_digest(p):
+    """(sha256 of the first 64 MiB, size) — the round-2 check, kept — see file_digest_full for the whole file"""
     h = hashlib.sha256()
     with open(p, "rb") as f:
         h.update(f.read(64 << 20))
     return h.hexdigest(), os.path.getsize(p)
 
 
+def file_digest_full(p):
+    """xxh3-128 of the WHOLE file (several GB/s: a 5 GB model in about a second): a generator drift in any tensor says "wrong file", not
+    "logits differ" """
+    import xxhash
+    h = xxhash.xxh3_128()
+    with open(p, "rb") as f:
+        while True:
+            b = f.read(64 << 20)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
+
+
+def refresh_digests(cfgs):
+    """rewrite the digest line of the committed side files from the GGUFs the reference evaluated (they are still in /dev/shm), without
+    re-running the reference:  python tests/golden/gen_fullsize_fixtures.py --digests [cfg ...]"""
+    for cfg in cfgs:
+        p = ensure_model(cfg)
+        side = os.path.join(ROOT, "tests", "golden", "fullsize_%s.bgld.txt" % cfg)
+        lines = open(side).read().splitlines()
+        dg, sz = file_digest(p)
+        old = dict(t.split("=", 1) for t in lines[-1].split() if "=" in t)
+        assert int(old["gguf_bytes"]) == sz and old["gguf_sha256_first64MiB"] == dg, "%s: the file in /dev/shm is not the one the fixture was recorded on" % cfg
+        lines[-1] = "gguf_bytes=%d gguf_sha256_first64MiB=%s gguf_xxh3_128=%s" % (sz, dg, file_digest_full(p))
+        open(side, "w").write("\n".join(lines) + "\n")
+        print(cfg, lines[-1], flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--digests":
+        return refresh_digests(sys.argv[2:] or list(CONFIGS))
     cfgs = sys.argv[1:] or list(CONFIGS)
     threads = int(os.environ.get("REF_THREADS", str(os.cpu_count() or 8)))
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_run")
@@ -96,7 +128,7 @@ def main():
         dg, sz = file_digest(p)
         line = r.stdout.decode().strip().splitlines()[-1]
         with open(out + ".txt", "w") as f:
-            f.write("%s\ngguf_bytes=%d gguf_sha256_first64MiB=%s\n" % (line, sz, dg))
+            f.write("%s\ngguf_bytes=%d gguf_sha256_first64MiB=%s gguf_xxh3_128=%s\n" % (line, sz, dg, file_digest_full(p)))
         print(cfg, line, "(%.0f s)" % (time.time() - t0), flush=True)
 
 

@@ -22,6 +22,9 @@ def strings(rnd):
             "café жж 中文 ok", "<|user|>hi</s> there<s>", "<|begin_of_text|>abc<|eot_id|>def <|start_header_id|>", "tab\there", "end ", " ",
             "100000 2 33 4444", "a'b'c''d", "éé's", "??!! ... --", "mixed123abc456", "\n", "", "ab<0x41>cd"]
     alphabet = "abcdeht  \n'.,!?019éж中"
+    base += ["the rain in the land is his", "zq zzz quiz\n\nnext", "tea tree street letter  settle"]
+    for _ in range(40):
+        base.append("".join(rnd.choice("etaoinshrdlu zq\n") for _ in range(rnd.randint(1, 40))))
     for _ in range(120):
         n = rnd.randint(1, 40)
         base.append("".join(rnd.choice(alphabet) for _ in range(n)))
@@ -31,7 +34,7 @@ def strings(rnd):
 def main():
     rnd = random.Random(9)
     out = {}
-    for name, vocab in (("spm", gguf.synthetic_spm_vocab()), ("bpe", gguf.synthetic_bpe_vocab())):
+    for name, vocab in (("spm", gguf.synthetic_spm_vocab()), ("bpe", gguf.synthetic_bpe_vocab()), ("bpe_holes", gguf.synthetic_bpe_vocab_holes())):
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, name + ".gguf")
             gguf.write_synthetic_llama(path, E=256, H=2, Hkv=1, L=1, F=256, V=len(vocab["tokens"]), seed=3, vocab=vocab)

@@ -1,8 +1,9 @@
-"""The ONE documented numerics deviation, pinned on a constructed worst case (tests/golden/f64_order_kat.npz,
-tools/f64_order_search.py): the double-precision sum of squares of RMSNorm is sequential in the reference (ggml.c:11874-11879) and a
-fixed tree on the GPU; both round the mean to f32 at once, so the results differ only when the two sums straddle a rounding boundary
-of the f32 mean — about 1e-8 per reduction on natural inputs (none in 2e5 random vectors here and in tools/f64_order_search.py).
-On this vector they do: the means differ by one ulp and 13 bytes of the quantised activations with them."""
+"""The reference's double-precision sums are SEQUENTIAL (RMSNorm sum of squares, ggml.c:11874-11879; softmax denominator, :2619-2671); the GPU
+reduces them as a fixed tree.  Both round to f32 at once (mean, 1 / sum), so the order shows only when the sum sits next to a rounding
+boundary of that f32.  Round 3 closed the hole: f32_rounding_safe (bamd_device.h) bounds the reordering error, and when it cannot rule a
+difference out one lane redoes the sum in the reference's order.  Pinned here on a CONSTRUCTED worst case (tests/golden/f64_order_kat.npz,
+tools/f64_order_search.py) on which the two orders do differ — the means by one f32 ulp, 13 bytes of the Q8_K activations with them — and on
+the guard's logic restated in numpy (it must fire on every vector on which the orders differ)."""
 import os
 import sys
 
@@ -30,14 +31,46 @@ def test_orders_differ_on_the_constructed_vector(kat, po):
     assert not np.array_equal(kat["q8k_seq"], kat["q8k_tree"])
 
 
+def test_guard_fires_on_the_constructed_vector_and_gives_the_sequential_mean(kat):
+    import f64_order_search as fs
+    m, fired = fs.guarded_mean32(fs.terms(kat["x"]))
+    assert fired and m.view(np.uint32) == kat["mean_seq"].view(np.uint32)
+
+
+def test_guard_never_misses(kat):
+    """property: whenever the two orders give different f32 means the guard has fired — on random vectors and on a walk of the constructed
+    vector's last element across the rounding boundary (where the orders disagree on a whole interval of steps)"""
+    import f64_order_search as fs
+    rng = np.random.default_rng(11)
+    fired = 0
+    for _ in range(1500):
+        x = (rng.standard_normal(fs.K) * np.exp(rng.standard_normal(fs.K) * 2.0)).astype(np.float32)
+        t = fs.terms(x)
+        m, f = fs.guarded_mean32(t)
+        fired += f
+        assert m.view(np.uint32) == fs.mean32(fs.sum_seq(t)).view(np.uint32)
+    assert fired < 15                                                   # ~1e-5 .. 1e-4 of natural reductions: the slow path stays rare
+    x = kat["x"].copy()
+    v0 = x[-1]
+    differ = 0
+    for k in range(-300, 300):
+        x[-1] = np.float32(v0 * np.float32(1.0 + k * 2.0 ** -9))
+        t = fs.terms(x)
+        m, f = fs.guarded_mean32(t)
+        a, b = fs.mean32(fs.sum_seq(t)), fs.mean32(fs.sum_tree(t))
+        differ += int(a.view(np.uint32) != b.view(np.uint32))
+        assert m.view(np.uint32) == a.view(np.uint32)
+    assert differ >= 1
+
+
 def test_random_vectors_agree():
     import f64_order_search as fs
     assert fs.random_trials(2000, np.random.default_rng(5)) == 0
 
 
 @pytest.mark.gpu
-def test_gpu_takes_the_tree_order_on_the_constructed_vector(kat, bamd):
-    """the GPU's result on the worst case: the tree-order mean — a KNOWN difference from the reference, kept visible here"""
+def test_gpu_equals_the_reference_on_the_constructed_vector(kat, bamd):
+    """the worst case through the HIP path: the guard sends it down the sequential order, so the bytes are the reference's"""
     got = bamd.op_quantize_q8_K(kat["x"], norm_w=np.ones(kat["x"].size, np.float32), eps=float(kat["eps"]))
-    assert np.array_equal(got, kat["q8k_tree"])
-    assert not np.array_equal(got, kat["q8k_seq"])
+    assert np.array_equal(got, kat["q8k_seq"])
+    assert not np.array_equal(got, kat["q8k_tree"])

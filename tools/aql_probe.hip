@@ -33,6 +33,7 @@ struct ChainArgs {
     int pre, post;                                 // chunks (8 KB per workgroup each) requested before / after the wait
     const unsigned * done_prev; unsigned * done_mine; unsigned target; int nshard;   // nshard 0: no flag wait (a kernel boundary orders us)
     int ashard;                                    // arrival counters of this kernel (0: none)
+    int delay_ticks;                               // emulated latency-bound work (100 MHz ticks) instead of streaming
     unsigned long long * stamps;                   // [256 workgroups][4]: entry, wait done, exit
     unsigned * err; float * sink;
 };
@@ -60,6 +61,7 @@ extern "C" __global__ void __launch_bounds__(512) chain_kernel(ChainArgs a) {
         __syncthreads();
     }
     if (tid == 0) a.stamps[wg * 4 + 1] = wall_clock64();
+    if (a.delay_ticks > 0) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < (unsigned long long) a.delay_ticks) __builtin_amdgcn_s_sleep(4); }
     // the whole 16 KB vector, coherently (sc1 loads: L1 bypassed; the producer wrote through)
     float s = 0.f;
 #pragma unroll
@@ -261,6 +263,82 @@ int main(int argc, char ** argv) {
         }
     }
 
+    // ---- attention || wo: a 32-workgroup latency-bound kernel (4.5 us) followed by a 224-workgroup kernel that streams 9.2 MB and needs ALL of
+    //      the first one's output: (a) both ordinary launches, (b) the second launched any-order: it requests its weights while the first runs,
+    //      then waits on the first one's arrival counter -----------------------------------------------------------------------------------
+    for (int rep = 0; rep < 2; ++rep) for (int co = 0; co < 2; ++co) {
+        reset(b);
+        const int NP = N / 2;
+        auto t0 = now();
+        for (int n = 0; n < NP; ++n) {
+            ChainArgs a = args_for(b, 2 * n, 0, 0, 0, slice); a.ashard = 1; a.delay_ticks = 450; a.nshard = 0;
+            hipLaunchKernelGGL(chain_kernel, dim3(32), dim3(512), lds, s, a);
+            ChainArgs w = args_for(b, 2 * n + 1, 5, 0, co ? 1 : 0, slice); w.ashard = 0; w.target = 32; w.nshard = co ? 1 : 0;
+            void * pa[1] = { &w };
+            CK(hipExtLaunchKernel((const void *) chain_kernel, dim3(224), dim3(512), pa, lds, s, nullptr, nullptr, co ? hipExtAnyOrderLaunch : 0));
+        }
+        CK(hipStreamSynchronize(s));
+        const double us = us_since(t0);
+        std::vector<unsigned long long> raw((size_t) N * 256 * 4);
+        CK(hipMemcpy(raw.data(), b.stamps, raw.size() * 8, hipMemcpyDeviceToHost));
+        unsigned err[2]; CK(hipMemcpy(err, b.err, 8, hipMemcpyDeviceToHost));
+        auto first_entry = [&](int n, int g) { unsigned long long e = ~0ull; for (int i = 0; i < g; ++i) e = std::min(e, raw[((size_t) n * 256 + i) * 4]); return e; };
+        auto last_exit = [&](int n, int g) { unsigned long long e = 0; for (int i = 0; i < g; ++i) e = std::max(e, raw[((size_t) n * 256 + i) * 4 + 2]); return e; };
+        double pair = 0, tailb = 0, ahead = 0;
+        for (int n = 1; n < NP; ++n) {
+            pair += (double) (first_entry(2 * n, 32) - first_entry(2 * n - 2, 32)) / 100.0;
+            tailb += (double) ((long long) last_exit(2 * n + 1, 224) - (long long) last_exit(2 * n, 32)) / 100.0;
+            ahead += (double) ((long long) last_exit(2 * n, 32) - (long long) first_entry(2 * n + 1, 224)) / 100.0;
+        }
+        printf("pair %-22s host %7.2f us/pair  device %7.2f us/pair  second kernel: enters %5.2f us before the first ends, exits %5.2f us after it  give-ups %u\n",
+               co ? "co-launched (any-order)" : "two ordinary launches", us / NP, pair / (NP - 1), ahead / (NP - 1), tailb / (NP - 1), err[0]);
+        fflush(stdout);
+    }
+
+    // ---- two HIP streams: per iteration  A (32 workgroups, 4.5 us latency-bound: "attention")  ->  B (224 workgroups, 9.2 MB: "wo")  ->  C (256
+    //      workgroups, 32 MB: "gate/up").  (a) one stream, three ordinary launches.  (b) A and C on stream 1, B on stream 2: B is released by an
+    //      event behind C of the previous iteration (so that it never takes CUs from C), requests its weights while A runs and waits on A's
+    //      counter; C follows A in stream order and waits on B's counters after requesting its first weights ------------------------------------
+    {
+        hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        const int NI = N / 3;
+        std::vector<hipEvent_t> evs(NI);
+        for (auto & e : evs) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (int rep = 0; rep < 2; ++rep) for (int co = 0; co < 2; ++co) {
+            reset(b);
+            auto t0 = now();
+            for (int n = 0; n < NI; ++n) {
+                ChainArgs a = args_for(b, 3 * n, 0, 0, 0, slice); a.ashard = 1; a.delay_ticks = 450; a.nshard = 0;
+                ChainArgs w = args_for(b, 3 * n + 1, 5, 0, 1, slice); w.ashard = 8; w.target = 32; w.nshard = co ? 1 : 0;     // arrives on 8 shards (28 each)
+                ChainArgs c = args_for(b, 3 * n + 2, 8, chunks - 8, 8, slice); c.ashard = 0; c.target = 28; c.nshard = co ? 8 : 0;
+                hipLaunchKernelGGL(chain_kernel, dim3(32), dim3(512), lds, s, a);
+                if (co) { if (n > 0) CK(hipStreamWaitEvent(s2, evs[n - 1], 0)); hipLaunchKernelGGL(chain_kernel, dim3(224), dim3(512), lds, s2, w); }
+                else hipLaunchKernelGGL(chain_kernel, dim3(224), dim3(512), lds, s, w);
+                hipLaunchKernelGGL(chain_kernel, dim3(256), dim3(512), lds, s, c);
+                if (co) CK(hipEventRecord(evs[n], s));
+            }
+            const double enq = us_since(t0);
+            CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+            const double us = us_since(t0);
+            std::vector<unsigned long long> raw((size_t) N * 256 * 4);
+            CK(hipMemcpy(raw.data(), b.stamps, raw.size() * 8, hipMemcpyDeviceToHost));
+            unsigned err[2]; CK(hipMemcpy(err, b.err, 8, hipMemcpyDeviceToHost));
+            auto first_entry = [&](int n, int g) { unsigned long long e = ~0ull; for (int i = 0; i < g; ++i) e = std::min(e, raw[((size_t) n * 256 + i) * 4]); return e; };
+            auto last_exit = [&](int n, int g) { unsigned long long e = 0; for (int i = 0; i < g; ++i) e = std::max(e, raw[((size_t) n * 256 + i) * 4 + 2]); return e; };
+            double it = 0, bA = 0, bx = 0, cx = 0, ce = 0;
+            for (int n = 1; n < NI; ++n) {
+                it += (double) (first_entry(3 * n, 32) - first_entry(3 * n - 3, 32)) / 100.0;
+                bA += (double) ((long long) first_entry(3 * n + 1, 224) - (long long) first_entry(3 * n, 32)) / 100.0;
+                bx += (double) ((long long) last_exit(3 * n + 1, 224) - (long long) last_exit(3 * n, 32)) / 100.0;
+                ce += (double) ((long long) first_entry(3 * n + 2, 256) - (long long) last_exit(3 * n, 32)) / 100.0;
+                cx += (double) ((long long) last_exit(3 * n + 2, 256) - (long long) last_exit(3 * n, 32)) / 100.0;
+            }
+            printf("triple %-26s host %7.2f us/iter (enqueue %5.2f)  device %7.2f us/iter; B enters %5.2f us after A's entry, exits %5.2f us after A's end; C enters %5.2f, exits %5.2f us after A's end; give-ups %u\n",
+                   co ? "two streams, soft edges" : "one stream, three launches", us / NI, enq / NI, it / (NI - 1), bA / (NI - 1), bx / (NI - 1), ce / (NI - 1), cx / (NI - 1), err[0]);
+            fflush(stdout);
+        }
+    }
+
     // ---- our own AQL queue ------------------------------------------------------------------------------------------------
     Hsa h; hsa_setup(h, hsaco);
     ChainArgs * karg = nullptr;
@@ -299,6 +377,59 @@ int main(int argc, char ** argv) {
         if (v >= 1) { printf("%s: TIMED OUT waiting for the completion signal\n", name); exit(2); }
         report(name, b, us, N);
     };
+    // ---- the pair experiment on our own queue: first kernel (32 workgroups, emulated latency-bound work) WITH the barrier bit, second (224
+    //      workgroups, 9.2 MB of weights, waits on the first one's counter) WITHOUT; the emulated work and the LDS request are varied to see
+    //      what the second kernel's entry is tied to ---------------------------------------------------------------------------------------
+    auto run_pair = [&](int delay, uint32_t lds_b, bool second_barrier) {
+        reset(b);
+        const int NP = N / 2;
+        for (int n = 0; n < NP; ++n) {
+            ChainArgs a = args_for(b, 2 * n, 0, 0, 0, slice); a.ashard = 1; a.delay_ticks = delay; a.nshard = 0;
+            ChainArgs w = args_for(b, 2 * n + 1, 5, 0, 1, slice); w.ashard = 0; w.target = 32; w.nshard = second_barrier ? 0 : 1;
+            memcpy((char *) karg + (size_t) (2 * n) * kstride, &a, sizeof a); memcpy((char *) karg + (size_t) (2 * n + 1) * kstride, &w, sizeof w);
+        }
+        CK(hipMemcpy(karg_dev, karg, (size_t) N * kstride, hipMemcpyHostToDevice)); CK(hipDeviceSynchronize());
+        hsa_signal_store_relaxed(h.done, 1);
+        const uint32_t mask = h.q->size - 1;
+        const uint64_t base = hsa_queue_add_write_index_relaxed(h.q, (uint64_t) (2 * NP));
+        while (base + 2 * NP - hsa_queue_load_read_index_scacquire(h.q) > h.q->size) { }
+        for (int n = 0; n < 2 * NP; ++n) {
+            hsa_kernel_dispatch_packet_t * p = (hsa_kernel_dispatch_packet_t *) h.q->base_address + ((base + n) & mask);
+            const bool first = (n & 1) == 0, lastp = n == 2 * NP - 1;
+            p->workgroup_size_x = 512; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
+            p->grid_size_x = (first ? 32 : 224) * 512; p->grid_size_y = 1; p->grid_size_z = 1;
+            p->private_segment_size = h.private_size; p->group_segment_size = h.group_size + lds_b;
+            p->kernel_object = h.kobj; p->kernarg_address = karg_dev + (size_t) n * kstride; p->reserved2 = 0;
+            p->completion_signal.handle = lastp ? h.done.handle : 0;
+            const bool bar = first || second_barrier || lastp;
+            const int sc = lastp ? 2 : 1;
+            const uint16_t header = (uint16_t) ((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((bar ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                                                (sc << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (sc << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+            __atomic_store_n((uint32_t *) p, (uint32_t) header | ((uint32_t) (1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16), __ATOMIC_RELEASE);
+        }
+        hsa_signal_store_screlease(h.q->doorbell_signal, (hsa_signal_value_t) (base + 2 * NP - 1));
+        if (hsa_signal_wait_scacquire(h.done, HSA_SIGNAL_CONDITION_LT, 1, 20ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) >= 1) { printf("pair: TIMED OUT\n"); exit(2); }
+        std::vector<unsigned long long> raw((size_t) N * 256 * 4);
+        CK(hipMemcpy(raw.data(), b.stamps, raw.size() * 8, hipMemcpyDeviceToHost));
+        unsigned err[2]; CK(hipMemcpy(err, b.err, 8, hipMemcpyDeviceToHost));
+        auto first_entry = [&](int n, int g) { unsigned long long e = ~0ull; for (int i = 0; i < g; ++i) e = std::min(e, raw[((size_t) n * 256 + i) * 4]); return e; };
+        auto last_entry = [&](int n, int g) { unsigned long long e = 0; for (int i = 0; i < g; ++i) e = std::max(e, raw[((size_t) n * 256 + i) * 4]); return e; };
+        auto last_exit = [&](int n, int g) { unsigned long long e = 0; for (int i = 0; i < g; ++i) e = std::max(e, raw[((size_t) n * 256 + i) * 4 + 2]); return e; };
+        double pair = 0, tailb = 0, e1 = 0, e2 = 0, alen = 0;
+        for (int n = 1; n < NP; ++n) {
+            pair += (double) (first_entry(2 * n, 32) - first_entry(2 * n - 2, 32)) / 100.0;
+            tailb += (double) ((long long) last_exit(2 * n + 1, 224) - (long long) last_exit(2 * n, 32)) / 100.0;
+            e1 += (double) ((long long) first_entry(2 * n + 1, 224) - (long long) first_entry(2 * n, 32)) / 100.0;
+            e2 += (double) ((long long) last_entry(2 * n + 1, 224) - (long long) first_entry(2 * n, 32)) / 100.0;
+            alen += (double) ((long long) last_exit(2 * n, 32) - (long long) first_entry(2 * n, 32)) / 100.0;
+        }
+        printf("aqlpair delay %4.1f us lds %3u KB %s: %6.2f us/pair; first kernel lasts %5.2f us; second enters %5.2f .. %5.2f us after the first's entry, exits %5.2f us after the first's end; give-ups %u\n",
+               delay / 100.0, lds_b >> 10, second_barrier ? "second WITH barrier bit   " : "second WITHOUT barrier bit", pair / (NP - 1), alen / (NP - 1), e1 / (NP - 1), e2 / (NP - 1), tailb / (NP - 1), err[0]);
+        fflush(stdout);
+    };
+    for (int rep = 0; rep < 2; ++rep) {
+        run_pair(450, 64 << 10, true); run_pair(450, 64 << 10, false); run_pair(900, 64 << 10, false); run_pair(450, 1 << 10, false); run_pair(900, 1 << 10, false);
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run_aql("aqlbar sys/sys hostargs", true, 2, 2, 8, 0, false);
         run_aql("aqlbar sys/sys", true, 2, 2, 8, 0);

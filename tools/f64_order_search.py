@@ -49,6 +49,29 @@ def mean32(s):
     return np.float32(s / K)
 
 
+def rounding_safe(v, rel):
+    """bamd_device.h f32_rounding_safe, restated: every double within v (1 +- rel) rounds to the same f32 as v"""
+    f = np.float32(v)
+    fb = int(f.view(np.uint32))
+    if not (v > 0.0) or fb == 0 or fb >= 0x7f800000:
+        return True
+    hi = 0.5 * (float(f) + float(np.uint32(fb + 1).view(np.float32)))
+    lo = 0.5 * (float(f) + float(np.uint32(fb - 1).view(np.float32)))
+    d = v * rel
+    return v + d < hi and v - d > lo
+
+
+GUARD_REL = (2.0 * K + 8.0) * 2.0 ** -53       # BAMD_F64_GUARD_REL(K)
+
+
+def guarded_mean32(t):
+    """what the GPU computes since round 3: the tree sum, unless its f32 mean could depend on the order — then the sequential sum"""
+    st = sum_tree(t)
+    if rounding_safe(st / K, GUARD_REL):
+        return mean32(st), False
+    return mean32(sum_seq(t)), True
+
+
 def random_trials(n, rng):
     diff = 0
     for _ in range(n):
