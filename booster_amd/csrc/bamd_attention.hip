@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
     double tot = 0.0; for (int w = 0; w < nw; ++w) tot += redd[w];
     double rs = 1.0 / tot;
     float fs = (float) rs;
-    if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+    if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
         if (cached) {
 #pragma unroll
             for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) s[i] = v[k]; }
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int w = 0; w < 8; ++w) tot += redd[w];
     double rs = 1.0 / tot;
     float fs = (float) rs;
-    if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+    if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
         __syncthreads();
         if (tid == 0) redd[0] = seq_expsum8(sc, n_kv);
         __syncthreads();
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(512) attn_batch_kernel(bamd_attn_args a, int g
         for (int w = 0; w < 8; ++w) tot += redd[hh][w];
         double rs = 1.0 / tot;
         float fs = (float) rs;
-        if (!f32_rounding_safe(rs, fs, BAMD_F64_GUARD_REL(n_kv / 8))) {      // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+        if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {      // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
             __syncthreads();
             if (tid == 0) redd[hh][0] = seq_expsum8(s_, n_kv);
             __syncthreads();

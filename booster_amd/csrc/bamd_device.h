@@ -145,14 +145,15 @@ __device__ __forceinline__ double wave_sum_f64(double s) {                  // f
 // 2 n u S; a division / reciprocal adds u more on each side.  If every double within that relative distance of our value rounds to the SAME f32,
 // the reference's f32 is that one too.  Otherwise (the value sits next to a rounding boundary: ~1e-5 of the reductions at n = 4096) the caller
 // recomputes sequentially.  v > 0 finite: a zero or non-finite sum is the same in any order.
-#define BAMD_F64_GUARD_REL(n) ((2.0 * (double) (n) + 8.0) * 1.1102230246251565e-16)
-__device__ __forceinline__ bool f32_rounding_safe(double v, float f, double rel) {
-    const uint32_t fb = __float_as_uint(f);
-    if (!(v > 0.0) || fb == 0u || fb >= 0x7f800000u) return true;             // 0 / inf / nan: order-independent (non-negative terms); f32 underflow to 0: v tiny, far from use
-    const double fd = (double) f;
-    const double hi = 0.5 * (fd + (double) __uint_as_float(fb + 1u)), lo = 0.5 * (fd + (double) __uint_as_float(fb - 1u));   // the neighbouring rounding boundaries (exact in double)
-    const double d = v * rel;
-    return v + d < hi && v - d > lo;
+// In integer terms: a double rounds to f32 by its low 29 mantissa bits D (the boundary is D = 2^28), and a relative distance of (2 n + 8) u is
+// at most 2 n + 8 units of D: safe iff |D - 2^28| > 2 n + 8 (and the value is in the f32 normal range; anything else takes the slow path).
+#define BAMD_F64_GUARD_ULPS(n) (2 * (n) + 8)
+__device__ __forceinline__ bool f32_rounding_safe(double v, int ulps) {
+    if (v == 0.0) return true;                                              // the same in any order (non-negative terms)
+    const uint32_t hi = (uint32_t) __double2hiint(v), lo = (uint32_t) __double2loint(v);
+    const uint32_t ex = (hi >> 20) & 0x7ffu;                                // sign bit is 0: sums of squares / of exponentials
+    const int dist = (int) (lo & 0x1fffffffu) - 0x10000000;
+    return ex >= 1023u - 126u && ex <= 1023u + 127u && (dist < 0 ? -dist : dist) > ulps;
 }
 // the reference's softmax denominator over exp values already stored at vals[0..n) (n % 8 == 0): 8-wide f32 partial sums in the AVX2 tree
 // ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), added to a double one after the other (ggml.c:2635-2644)
@@ -317,7 +318,7 @@ struct ActPro {
             // exact reciprocal is the same double — without the ~30 dependent f64 instructions of an IEEE division
             double md = (K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K;
             float mean = (float) md;
-            if (!f32_rounding_safe(md, mean, BAMD_F64_GUARD_REL(K))) {     // workgroup-uniform (every thread holds the same tot); rare
+            if (!f32_rounding_safe(md, BAMD_F64_GUARD_ULPS(K))) {     // workgroup-uniform (every thread holds the same tot); rare
                 __syncthreads();                                            // everybody has read red[]
                 if (threadIdx.x == 0) {                                     // the reference's order, one lane (ggml.c:11874-11877)
                     double sq = 0.0;

@@ -49,25 +49,24 @@ def mean32(s):
     return np.float32(s / K)
 
 
-def rounding_safe(v, rel):
-    """bamd_device.h f32_rounding_safe, restated: every double within v (1 +- rel) rounds to the same f32 as v"""
-    f = np.float32(v)
-    fb = int(f.view(np.uint32))
-    if not (v > 0.0) or fb == 0 or fb >= 0x7f800000:
+def rounding_safe(v, ulps):
+    """bamd_device.h f32_rounding_safe, restated: a double rounds to f32 by its low 29 mantissa bits D (boundary D = 2^28); a relative
+    reordering error of (2 n + 8) 2^-53 moves D by at most 2 n + 8, so the f32 cannot depend on the order when |D - 2^28| > 2 n + 8"""
+    if v == 0.0:
         return True
-    hi = 0.5 * (float(f) + float(np.uint32(fb + 1).view(np.float32)))
-    lo = 0.5 * (float(f) + float(np.uint32(fb - 1).view(np.float32)))
-    d = v * rel
-    return v + d < hi and v - d > lo
+    bits = int(np.float64(v).view(np.uint64))
+    ex = (bits >> 52) & 0x7ff
+    dist = (bits & 0x1fffffff) - 0x10000000
+    return 1023 - 126 <= ex <= 1023 + 127 and abs(dist) > ulps
 
 
-GUARD_REL = (2.0 * K + 8.0) * 2.0 ** -53       # BAMD_F64_GUARD_REL(K)
+GUARD_ULPS = 2 * K + 8                         # BAMD_F64_GUARD_ULPS(K)
 
 
 def guarded_mean32(t):
     """what the GPU computes since round 3: the tree sum, unless its f32 mean could depend on the order — then the sequential sum"""
     st = sum_tree(t)
-    if rounding_safe(st / K, GUARD_REL):
+    if rounding_safe(st / K, GUARD_ULPS):
         return mean32(st), False
     return mean32(sum_seq(t)), True
 
