@@ -205,7 +205,8 @@ def main():
         KINDS = ["qkv", "attention", "other", "wo", "gate_up", "ffn_down", "lm_head"]
         KERNEL_OF = {"qkv": "matvec_split_fast_kernel / matvec_split_mixed_kernel (fused QKV, RMSNorm prologue)", "wo": "matvec_split_fast_kernel (wo, +residual)",
                      "gate_up": "matvec_fast_kernel<Q4_K, RMSNorm prologue, silu(gate)*up epilogue> (ffn_gate + ffn_up)", "ffn_down": "matvec_split_fast_kernel (ffn_down, +residual)",
-                     "lm_head": "matvec_fast_kernel<Q6_K, arg-max epilogue> (output)", "attention": "attn_fused_kernel"}
+                     "lm_head": "matvec_fast_kernel<Q6_K, arg-max epilogue> (output)", "attention": "attn_fused_kernel",
+                     "attention+wo": "attn_wo_kernel (single-launch attention on H CUs, wo + residual on the others)"}
         LK, MSK, BK = np.zeros(7), np.zeros(7), np.zeros(7)
         ev_over = []
         reps = 4
@@ -231,6 +232,8 @@ def main():
                 t_ms = max(MSK[k] / LK[k] - ev_overhead_ms, 1e-6)
                 per_kind[KINDS[k]] = dict(launches_per_token=int(LK[k] / reps), us_per_launch=round(t_ms * 1e3, 3), bytes_per_launch=int(BK[k] / LK[k]),
                                           GBps=round(BK[k] / LK[k] / (t_ms * 1e-3) / 1e9, 1), share_of_step=round(t_ms * LK[k] / reps / step_ms, 4))
+        if "wo" not in per_kind and "attention" in per_kind:             # attention and wo share a launch (bamd_colaunch.hip): its bytes are wo's weights
+            per_kind = {("attention+wo" if k == "attention" else k): v for k, v in per_kind.items()}
         dom = max((k for k in per_kind if k not in ("other",)), key=lambda k: per_kind[k]["share_of_step"])
         achieved = per_kind[dom]["GBps"]
         # HBM bytes per launch of the dominant kernel, quoted from the NEWEST committed rocprofv3 PMC pass of this workload (profiles/r*_pmc_fetch_summary.json:

@@ -518,6 +518,85 @@ __device__ __forceinline__ Terms block_terms(const RecQ6K & R, int ci, int lane,
     return T;
 }
 
+// ---- block_terms in two halves: what depends on the weight record only (PreTerms, computed while a co-launched workgroup waits for its
+//      activations: bamd_colaunch.hip) and the rest.  Same operations on the same values as block_terms above, in the same order per result.
+template <int TYPE> struct PreTerms;
+template <> struct PreTerms<BAMD_Q4_K> {
+    uint32_t wq[8], sc03, sc47; int ma, mb; float dh, dminh;
+    __device__ __forceinline__ void prep(const RecQ4K & R, int lane) {
+        const int l = lane & 3;
+        dh = h2f(R.hd.x & 0xffffu); dminh = h2f(R.hd.x >> 16);
+        uint32_t mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+        wq[0] = R.qs.x & 0x0f0f0f0fu; wq[1] = (R.qs.x >> 4) & 0x0f0f0f0fu; wq[2] = R.qs.y & 0x0f0f0f0fu; wq[3] = (R.qs.y >> 4) & 0x0f0f0f0fu;
+        wq[4] = R.qs.z & 0x0f0f0f0fu; wq[5] = (R.qs.z >> 4) & 0x0f0f0f0fu; wq[6] = R.qs.w & 0x0f0f0f0fu; wq[7] = (R.qs.w >> 4) & 0x0f0f0f0fu;
+        const uint32_t mw = (l < 2) ? mn03 : mn47;
+        const int sh = (l & 1) * 16;
+        ma = (int) ((mw >> sh) & 0xffu); mb = (int) ((mw >> (sh + 8)) & 0xffu);
+    }
+    __device__ __forceinline__ Terms finish(int ci, int lane, const uint32_t * q8, const int * S, const float * yd) const {
+        const int e = lane & 7, l = e & 3;
+        const float ydv = yd[ci];
+        Terms T;
+        T.d = ydv * dh; T.dmin = (-ydv) * dminh;
+        const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+        const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        T.fs = (float) dotscale8<false>(wq, aq, sc03, sc47);
+        const int2 sp = *(const int2 *) (S + ci * 8 + 2 * l);
+        T.pm = (float) (mul24(ma, sp.x) + mul24(mb, sp.y));
+        return T;
+    }
+};
+template <> struct PreTerms<BAMD_Q5_K> {
+    uint32_t wq[8], sc03, sc47; int me; float dh, dminh;
+    __device__ __forceinline__ void prep(const RecQ5K & R, int lane) {
+        const int e = lane & 7;
+        dh = h2f(R.hd.x & 0xffffu); dminh = h2f(R.hd.x >> 16);
+        uint32_t mn03, mn47; unpack_k4(R.hd, sc03, sc47, mn03, mn47);
+        const uint32_t qh = R.qh;
+#define Q5(w, shift, c) ((((w) >> (shift)) & 0x0f0f0f0fu) | (((qh >> (c)) & 0x01010101u) << 4))
+        wq[0] = Q5(R.qs.x, 0, 0); wq[1] = Q5(R.qs.x, 4, 1); wq[2] = Q5(R.qs.y, 0, 2); wq[3] = Q5(R.qs.y, 4, 3);
+        wq[4] = Q5(R.qs.z, 0, 4); wq[5] = Q5(R.qs.z, 4, 5); wq[6] = Q5(R.qs.w, 0, 6); wq[7] = Q5(R.qs.w, 4, 7);
+#undef Q5
+        const uint32_t mw = (e < 4) ? mn03 : mn47;
+        me = (int) ((mw >> (8 * (e & 3))) & 0xffu);
+    }
+    __device__ __forceinline__ Terms finish(int ci, int lane, const uint32_t * q8, const int * S, const float * yd) const {
+        const int e = lane & 7;
+        const float ydv = yd[ci];
+        Terms T;
+        T.d = ydv * dh; T.dmin = (-ydv) * dminh;
+        const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+        const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        T.fs = (float) dotscale8<false>(wq, aq, sc03, sc47);
+        T.pm = (float) group8_sum(mul24(me, S[ci * 8 + e]));
+        return T;
+    }
+};
+template <> struct PreTerms<BAMD_Q6_K> {
+    uint32_t wq[8], s0, s1; float dh;
+    __device__ __forceinline__ void prep(const RecQ6K & R, int lane) {
+        (void) lane;
+        dh = h2f(R.d); s0 = R.sc.x; s1 = R.sc.y;
+#define Q6(lo, hb) ((((lo) | ((hb) << 4)) + 0x60606060u) ^ 0x80808080u)
+        const uint32_t A0 = R.ql.x, B0 = R.ql.y, h0 = R.qh.x, A1 = R.ql.z, B1 = R.ql.w, h1 = R.qh.y;
+        wq[0] = Q6(A0 & 0x0f0f0f0fu, h0 & 0x03030303u); wq[1] = Q6(B0 & 0x0f0f0f0fu, (h0 >> 2) & 0x03030303u);
+        wq[2] = Q6((A0 >> 4) & 0x0f0f0f0fu, (h0 >> 4) & 0x03030303u); wq[3] = Q6((B0 >> 4) & 0x0f0f0f0fu, (h0 >> 6) & 0x03030303u);
+        wq[4] = Q6(A1 & 0x0f0f0f0fu, h1 & 0x03030303u); wq[5] = Q6(B1 & 0x0f0f0f0fu, (h1 >> 2) & 0x03030303u);
+        wq[6] = Q6((A1 >> 4) & 0x0f0f0f0fu, (h1 >> 4) & 0x03030303u); wq[7] = Q6((B1 >> 4) & 0x0f0f0f0fu, (h1 >> 6) & 0x03030303u);
+#undef Q6
+    }
+    __device__ __forceinline__ Terms finish(int ci, int lane, const uint32_t * q8, const int * S, const float * yd) const {
+        (void) S;
+        const int e = lane & 7;
+        Terms T;
+        T.d = yd[ci] * dh; T.dmin = 0.f; T.pm = 0.f;
+        const uint4 a0 = *(const uint4 *) (q8 + ci * 64 + e * 8), a1 = *(const uint4 *) (q8 + ci * 64 + e * 8 + 4);
+        const uint32_t aq[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        T.fs = (float) dotscale8<true>(wq, aq, s0, s1);
+        return T;
+    }
+};
+
 // one step of the reference's per-lane f32 chains (the ONLY place their order is defined)
 template <int TYPE>
 __device__ __forceinline__ void chain_step(RowAcc & A, float d, float fs, float dmin, float pm) {

@@ -132,6 +132,9 @@ struct bamd_context {
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr; int graph_fused = -1;
+    unsigned long long * co_gran = nullptr;   // co-launch granules [H * hd] {value, tag} + give-up counter behind them (bamd_colaunch.hip), zero-initialised
+    uint32_t * co_err = nullptr;
+    int host_serial = 0;             // host calls that set the device state so far (bamd_step_state.serial)
     // KV cell metadata (llama_kv_cache cells: pos / delta / head / used, llama.cpp:2700-2760) — inactive (cell i holds position i, nothing to
     // track) until the first bamd_kv_seq_rm / bamd_kv_seq_add
     struct Cells { bool active = false, has_shift = false; std::vector<int32_t> pos, delta; int head = 0, used = 0; } cells;
@@ -370,8 +373,12 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
         dev_alloc(c->allocs, (void **) &c->logits, (size_t) m->V * 4) || dev_alloc(c->allocs, (void **) &c->st, sizeof(bamd_step_state))) return 1;
     c->k = c->q + m->E; c->v = c->k + Ekv;                           // q | k | v contiguous: rows of the fused QKV mat-vec
     HIPC(hipMemsetAsync(c->st, 0, sizeof(bamd_step_state), c->stream));
+    if (dev_alloc(c->allocs, (void **) &c->co_gran, (size_t) m->H * m->hd * 8 + 64)) return 1;
+    HIPC(hipMemsetAsync(c->co_gran, 0, (size_t) m->H * m->hd * 8 + 64, c->stream));
+    c->co_err = (uint32_t *) (c->co_gran + (size_t) m->H * m->hd);
     HIPC(hipMemsetAsync(c->logits, 0, (size_t) m->V * 4, c->stream));
-    HIPC(hipHostMalloc((void **) &c->logits_host, (size_t) m->V * 4));
+    HIPC(hipHostMalloc((void **) &c->logits_host, (size_t) m->V * 4 + 16));     // + the co-launch give-up counter, read back with the logits
+    memset(c->logits_host + m->V, 0, 16);
     c->forced_cap = 4096; c->out_cap = n_ctx + 8;
     if (dev_alloc(c->allocs, (void **) &c->forced, (size_t) c->forced_cap * 4) || dev_alloc(c->allocs, (void **) &c->out_tokens, (size_t) c->out_cap * 4)) return 1;
     HIPC(hipStreamSynchronize(c->stream));
@@ -410,6 +417,7 @@ struct StepTimer {                 // optional per-launch HIP-event timing (bamd
     // c: 0 mat-vec, 1 attention, 2 other; k: which launch of the layer (0 qkv, 1 attention, 2 other, 3 wo, 4 gate/up, 5 ffn_down, 6 lm_head)
     void begin(hipStream_t s, int c, double b, int k = -1) { if (!on) return; hipEvent_t a; hipEventCreate(&a); hipEventRecord(a, s); ev.push_back(a); cls.push_back(c); kind.push_back(k < 0 ? c : k); bytes.push_back(b); }
     void end(hipStream_t s) { if (!on) return; hipEvent_t b; hipEventCreate(&b); hipEventRecord(b, s); ev.push_back(b); }
+    void cancel() { if (!on) return; hipEventDestroy(ev.back()); ev.pop_back(); cls.pop_back(); kind.pop_back(); bytes.pop_back(); }   // the launch behind begin() did not happen
 };
 
 static unsigned long long * tl_next(bamd_context * c) {
@@ -447,19 +455,33 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
-        if (tm) tm->begin(s, 1, 0.0);
         // single-launch kernel below 448 positions, three kernels (scores | softmax | P.V) above (attn_fused_for)
-        t.tl = tl_next(c);
         t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances
         t.cellpos = c->cells.active ? c->cellpos : nullptr;
-        if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
-        if (tm) tm->end(s);
         // 3. x2 = x + Wo . Q8_K(att)                                        (llama.cpp:8294-8303, :8864)
         memset(&a, 0, sizeof a);
-        seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x; a.tl = tl_next(c);
-        if (tm) tm->begin(s, 0, (double) ly.wo.bytes, 3);
-        bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
-        if (tm) tm->end(s);
+        seg_of(a.seg[0], ly.wo, c->x2); a.nseg = 1; a.x = c->att; a.K = m->E; a.res = c->x;
+        // 2 + 3 in ONE launch when the attention takes its single-launch kernel and the wo shape has a co-launch instance: the wo workgroups
+        // fetch their weights on the CUs the attention leaves idle (bamd_colaunch.hip)
+        bool co = false;
+        if (attn_fused_for(c, pos_hi) && !prefill_mode) {
+            unsigned long long * tl = tl_next(c);
+            t.tl = tl; a.tl = tl;
+            if (tm) tm->begin(s, 1, (double) ly.wo.bytes);
+            co = bamd_launch_attn_wo(t, gq, a, m->n_cu, c->co_gran, (int) (il & 255), c->co_err, s) == 0;
+            if (tm) { if (co) tm->end(s); else tm->cancel(); }
+            if (!co && tl) c->tl_slot--;
+        }
+        if (!co) {
+            if (tm) tm->begin(s, 1, 0.0);
+            t.tl = tl_next(c);
+            if (bamd_launch_attention(t, gq, attn_fused_for(c, pos_hi) ? tiles : -tiles, s)) return fail("attention launch: unsupported head configuration");
+            if (tm) tm->end(s);
+            a.tl = tl_next(c);
+            if (tm) tm->begin(s, 0, (double) ly.wo.bytes, 3);
+            bamd_launch_matvec(a, BAMD_PRO_PLAIN, BAMD_EPI_ADD, m->n_cu, s);
+            if (tm) tm->end(s);
+        }
         // 4. h = silu(Wg . a) * (Wu . a),  a = Q8_K(rms_norm(x2) * ffn_norm)  (llama.cpp:8869-8885)
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wg, c->h); seg_of(a.seg[1], ly.wu, c->h); a.nseg = 2; a.x = c->x2; a.normw = ly.ffn_norm; a.eps = m->eps; a.K = m->E; a.tl = tl_next(c);
@@ -490,7 +512,7 @@ static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStrea
 
 static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_key) {
     bamd_step_state h; memset(&h, 0, sizeof h);
-    h.pos_base = pos_base; h.n_ctx = c->n_ctx;
+    h.pos_base = pos_base; h.n_ctx = c->n_ctx; h.serial = (c->host_serial = (c->host_serial + 1) & 0xfff);
     if (keep_key) {
         // keep best_key (the arg-max of the previous lm_head): rewrite only the leading fields
         HIPC(hipMemcpyAsync(c->st, &h, offsetof(bamd_step_state, best_key), hipMemcpyHostToDevice, s));
@@ -747,6 +769,11 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
     return 0;
 }
 
+// a wo workgroup of a co-launch (bamd_colaunch.hip) that never saw the attention role's flags gave up instead of hanging: the results are void
+static int co_gave_up(bamd_context * c) {
+    uint32_t n; memcpy(&n, c->logits_host + c->m->V, 4);
+    return n ? fail("co-launched attention + wo: a workgroup gave up waiting for the attention role (results invalid)") : 0;
+}
 extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past) {
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) { fail("bamd_decode needs a stage that owns embedding and output"); return 1; }
@@ -787,8 +814,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     }
     c->logits_host_valid = c->logits_readback;
     if (c->logits_readback && hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
+    if (hipMemcpyAsync(c->logits_host + m->V, c->co_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H co-launch status"); return 1; }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
+    if (co_gave_up(c)) return 1;
     return 0;
 }
 // a micro-batch of 2..512 prompt tokens through ONE layer-split stage (bamd_stage_step's batched counterpart): tokens (host) on the
@@ -911,8 +940,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(out_tokens, c->out_tokens, (size_t) (n_steps + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPC(hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(c->logits_host + m->V, c->co_err, 4, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     c->logits_host_valid = true;
+    if (co_gave_up(c)) return 1;
     if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, ev.a, ev.b));
     return 0;
 }
@@ -925,7 +956,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
     // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
-    bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx;
+    bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx; h.serial = (c->host_serial = (c->host_serial + 1) & 0xfff);
     int attn_hi = pos;                                   // what decides single-launch vs three-launch attention
     if (c->cells.active) {
         if (prefill_mode) return fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call");

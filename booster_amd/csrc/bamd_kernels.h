@@ -18,6 +18,7 @@ struct bamd_step_state {
                                    // llama_kv_cache_find_slot picks (llama.cpp:3028-3127)
     int32_t cell_plus1;            // host: cell of step 0 + 1 (0 = cells follow positions)
     int32_t n_kv_fixed;            // host: padded KV length of this step when cells no longer follow positions (0 = from pos)
+    int32_t serial;                // host: 12-bit counter of the host calls that set this state (tag of the co-launch flag words, bamd_colaunch.hip)
     unsigned long long best_key;   // arg-max key of the last lm_head (0 = none)
 };
 
@@ -71,6 +72,10 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s);
 int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);
+// single-launch attention and the wo projection (+ residual) behind it in ONE launch (bamd_colaunch.hip); gran: [H * hd] zero-initialised 8-byte
+// granules of the context (the attention output travels through them), il: layer index (part of the tag), err: give-up counter.
+// 1 = this shape has no co-launch kernel: issue the two launches
+int  bamd_launch_attn_wo(const bamd_attn_args & t, int gq, const bamd_mv_args & wo, int n_cu, unsigned long long * gran, int il, uint32_t * err, hipStream_t s);
 // K-shift (build_k_shift, llama.cpp:8482-8512 -> ggml_compute_forward_rope_f16, ggml.c:14169-14290): every cell's K row re-rotated in place by
 // the cos / sin row tab[tab_of_cell[cell]] (row 0 = delta 0); kc chain-major f16 [n_cells][Hkv*hd]
 void bamd_launch_k_shift(unsigned short * kc, int n_cells, int Hkv, int hd, const int32_t * tab_of_cell, const float * tab, hipStream_t s);

@@ -317,9 +317,30 @@ int main(int argc, char ** argv) {
                 hipLaunchKernelGGL(chain_kernel, dim3(256), dim3(512), lds, s, c);
                 if (co) CK(hipEventRecord(evs[n], s));
             }
-            const double enq = us_since(t0);
+            double enq = us_since(t0);
             CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
-            const double us = us_since(t0);
+            double us = us_since(t0);
+            if (rep == 1) {          // second repetition: the same schedule captured into ONE hipGraph (fork / join by events) and replayed
+                reset(b);
+                hipGraph_t g; hipGraphExec_t ge; hipEvent_t ef, ej; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int n = 0; n < NI; ++n) {
+                    ChainArgs a = args_for(b, 3 * n, 0, 0, 0, slice); a.ashard = 1; a.delay_ticks = 450; a.nshard = 0;
+                    ChainArgs w = args_for(b, 3 * n + 1, 5, 0, 1, slice); w.ashard = 8; w.target = 32; w.nshard = co ? 1 : 0;
+                    ChainArgs c = args_for(b, 3 * n + 2, 8, chunks - 8, 8, slice); c.ashard = 0; c.target = 28; c.nshard = co ? 8 : 0;
+                    if (co) { CK(hipEventRecord(ef, s)); CK(hipStreamWaitEvent(s2, ef, 0)); }      // fork: B depends on what precedes A (the previous C), not on A
+                    hipLaunchKernelGGL(chain_kernel, dim3(32), dim3(512), lds, s, a);
+                    hipLaunchKernelGGL(chain_kernel, dim3(224), dim3(512), lds, co ? s2 : s, w);
+                    if (co) { CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s, ej, 0)); }      // join: C depends on A (stream order) and on B
+                    hipLaunchKernelGGL(chain_kernel, dim3(256), dim3(512), lds, s, c);
+                }
+                CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                t0 = now();
+                CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+                us = us_since(t0); enq = 0;
+                (void) hipGraphExecDestroy(ge); (void) hipGraphDestroy(g);
+                printf("(captured into one hipGraph) ");
+            }
             std::vector<unsigned long long> raw((size_t) N * 256 * 4);
             CK(hipMemcpy(raw.data(), b.stamps, raw.size() * 8, hipMemcpyDeviceToHost));
             unsigned err[2]; CK(hipMemcpy(err, b.err, 8, hipMemcpyDeviceToHost));

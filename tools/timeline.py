@@ -7,7 +7,8 @@ Every launch of the captured step graph writes the device wall clock (100 MHz) a
 workgroup (bamd_device.h TL_STAMP).  Phases — mat-vec mode A (one wave per row-group): 0 entry, 1 ring requests issued, 2 activation
 prologue done, 3 first chunk consumed, 4 last chunk consumed, 7 exit.  Mode B (split-K): 0 entry, 1 ring issued, 2 prologue done,
 3 terms of the first batch parked, 4 past the barrier, 5 first chain done, 7 exit.  Attention: 0 entry, 1 RoPE + KV store, 2 scores,
-3 softmax, 7 exit.  Reported per launch kind (median over the layers): first entry -> {median, last} workgroup at each phase, in µs,
+3 softmax, 7 exit.  Co-launched attention + wo (bamd_colaunch.hip): the attention role as above; the wo role 0 entry, 1 ring issued, 2 flags seen,
+3 terms parked, 4 past the barrier, 5 chain done, 7 exit — both relative to the launch's first entry.  Reported per launch kind (median over the layers): first entry -> {median, last} workgroup at each phase, in µs,
 the gap from the previous launch's last exit to this launch's first entry, and the launch's span.
 """
 import json
@@ -20,30 +21,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def reduce_one(full_u64, t0=None, prev_end=None):
+    """one launch (or the workgroups of one role of it): u64 [workgroups][24] -> dict; t0: time origin (default: its own first entry)"""
+    full = full_u64.astype(np.float64)
+    full[full == 0] = np.nan
+    a = full[:, :16].reshape(-1, 2, 8).copy()
+    if not np.all(np.isnan(full[:, 16:24])):
+        with np.errstate(all="ignore"):
+            a[:, 0, 7] = np.nanmax(full[:, 16:24], axis=1)            # exit: the LAST wave of the workgroup
+    if np.all(np.isnan(a[:, :, 0])):
+        return None
+    first = np.nanmin(a[:, :, 0])
+    if t0 is None:
+        t0 = first
+    end = np.nanmax(a[:, :, 7])
+    r = dict(start=first, end=end, span_us=(end - t0) / 100.0, entry_skew_us=(np.nanmax(a[:, :, 0]) - first) / 100.0,
+             gap_us=None if prev_end is None else (first - prev_end) / 100.0, n_wg=int(np.sum(~np.isnan(a[:, 0, 0]))))
+    for ph in range(1, 8):
+        col = a[:, :, ph]
+        if np.all(np.isnan(col)):
+            continue
+        r["p%d_med" % ph] = (np.nanmedian(col) - t0) / 100.0
+        r["p%d_max" % ph] = (np.nanmax(col) - t0) / 100.0
+        r["p%d_min" % ph] = (np.nanmin(col) - t0) / 100.0
+    return r
+
+
 def reduce_timeline(tl, L):
     """tl: u64 [launches][512][24] -> list of dicts per launch"""
     rows = []
     prev_end = None
     for i in range(tl.shape[0]):
-        full = tl[i].astype(np.float64)
-        full[full == 0] = np.nan
-        a = full[:, :16].reshape(-1, 2, 8).copy()
-        a[:, 0, 7] = np.nanmax(full[:, 16:24], axis=1) if not np.all(np.isnan(full[:, 16:24])) else a[:, 0, 7]   # exit: the LAST wave of the workgroup
-        if np.all(np.isnan(a[:, :, 0])):
-            rows.append(None); continue
-        t0 = np.nanmin(a[:, :, 0])
-        end = np.nanmax(a[:, :, 7])
-        r = dict(start=t0, end=end, span_us=(end - t0) / 100.0, entry_skew_us=(np.nanmax(a[:, :, 0]) - t0) / 100.0,
-                 gap_us=None if prev_end is None else (t0 - prev_end) / 100.0, n_wg=int(np.sum(~np.isnan(a[:, 0, 0]))))
-        for ph in range(1, 8):
-            col = a[:, :, ph]
-            if np.all(np.isnan(col)):
-                continue
-            r["p%d_med" % ph] = (np.nanmedian(col) - t0) / 100.0
-            r["p%d_max" % ph] = (np.nanmax(col) - t0) / 100.0
-            r["p%d_min" % ph] = (np.nanmin(col) - t0) / 100.0
+        r = reduce_one(tl[i], None, prev_end)
         rows.append(r)
-        prev_end = end
+        if r is not None:
+            prev_end = r["end"]
     return rows
 
 
@@ -61,19 +73,28 @@ def main():
     tl = ctx.timeline_step(pos, replays=4)
     L = m.n_layer
     rows = reduce_timeline(tl, L)
-    names = ["qkv", "attention", "wo", "gate_up", "down"]
+    n_valid = sum(r is not None for r in rows)
+    per = (n_valid - 1) // L                                  # launches per layer: 5, or 4 when attention and wo share a launch (bamd_colaunch.hip)
+    names = ["qkv", "attention", "wo", "gate_up", "down"] if per == 5 else ["qkv", "attn+wo", "gate_up", "down"]
+    H = 32
     kinds = {}
     for i, r in enumerate(rows):
         if r is None:
             continue
-        if i == 5 * L:
+        if i == per * L:
             k = "lm_head"
         else:
-            il, j = divmod(i, 5)
+            il, j = divmod(i, per)
             k = names[j]
-            if j in (0, 4):                                   # layers with a Q6_K attn_v / ffn_down stream more bytes
+            if names[j] in ("qkv", "down"):                   # layers with a Q6_K attn_v / ffn_down stream more bytes
                 from booster_amd.gguf import q4_k_m_type, Q6_K
                 k += "_q6k" if q4_k_m_type("ffn_down", il, L) == Q6_K else "_q4k"
+            if names[j] == "attn+wo":                         # the two roles of the co-launch, both against the launch's first entry
+                ra, rw = reduce_one(tl[i][:H], r["start"]), reduce_one(tl[i][H:], r["start"])
+                if ra is not None:
+                    kinds.setdefault("  role attention", []).append(ra)
+                if rw is not None:
+                    kinds.setdefault("  role wo", []).append(rw)
         kinds.setdefault(k, []).append(r)
     out = {}
     keys = ["gap_us", "span_us", "entry_skew_us"] + ["p%d_%s" % (p, s) for p in range(1, 8) for s in ("min", "med", "max")]
@@ -92,7 +113,7 @@ def main():
     for i in range(tl.shape[0]):
         if rows[i] is None:
             continue
-        k = "lm_head" if i == 5 * L else names[i % 5]
+        k = "lm_head" if i == per * L else names[i % per]
         full = tl[i].astype(np.float64); full[full == 0] = np.nan
         if np.all(np.isnan(full[:, 16:24])):
             continue
