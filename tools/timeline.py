@@ -74,8 +74,12 @@ def main():
     L = m.n_layer
     rows = reduce_timeline(tl, L)
     n_valid = sum(r is not None for r in rows)
-    per = (n_valid - 1) // L                                  # launches per layer: 5, or 4 when attention and wo share a launch (bamd_colaunch.hip)
-    names = ["qkv", "attention", "wo", "gate_up", "down"] if per == 5 else ["qkv", "attn+wo", "gate_up", "down"]
+    per = (n_valid - 1) // L                                  # launches per layer: 5, fewer when roles share a launch (bamd_colaunch.hip)
+    co_attn = os.environ.get("BAMD_COLAUNCH", "1") != "0"
+    co_ffn = co_attn and os.environ.get("BAMD_COLAUNCH_FFN", "1") != "0"
+    names = ["qkv"] + (["attn+wo"] if co_attn else ["attention", "wo"]) + (["gu+down"] if co_ffn else ["gate_up", "down"])
+    if len(names) != per:
+        names = ["qkv", "attention", "wo", "gate_up", "down"] if per == 5 else ["launch%d" % i for i in range(per)]
     H = 32
     kinds = {}
     for i, r in enumerate(rows):
@@ -89,12 +93,13 @@ def main():
             if names[j] in ("qkv", "down"):                   # layers with a Q6_K attn_v / ffn_down stream more bytes
                 from booster_amd.gguf import q4_k_m_type, Q6_K
                 k += "_q6k" if q4_k_m_type("ffn_down", il, L) == Q6_K else "_q4k"
-            if names[j] == "attn+wo":                         # the two roles of the co-launch, both against the launch's first entry
-                ra, rw = reduce_one(tl[i][:H], r["start"]), reduce_one(tl[i][H:], r["start"])
+            if names[j] in ("attn+wo", "gu+down"):            # the two roles of a shared launch, both against the launch's first entry
+                cut, ra_n, rw_n = (H, "  role attention", "  role wo") if names[j] == "attn+wo" else (256, "  role gate_up", "  role down")
+                ra, rw = reduce_one(tl[i][:cut], r["start"]), reduce_one(tl[i][cut:], r["start"])
                 if ra is not None:
-                    kinds.setdefault("  role attention", []).append(ra)
+                    kinds.setdefault(ra_n, []).append(ra)
                 if rw is not None:
-                    kinds.setdefault("  role wo", []).append(rw)
+                    kinds.setdefault(rw_n, []).append(rw)
         kinds.setdefault(k, []).append(r)
     out = {}
     keys = ["gap_us", "span_us", "entry_skew_us"] + ["p%d_%s" % (p, s) for p in range(1, 8) for s in ("min", "med", "max")]
