@@ -7,7 +7,7 @@ an xxh3-128 of the WHOLE file) is evaluated by the reference CPU path (oracle/_r
 prompt tok[i] = (7919 i + 13) mod V, greedy.  What is committed is DATA ONLY: arg-max tokens, 32 probe logits per step, the top
 logit and a 64-bit digest of all logits per step (tests/golden/fullsize_<cfg>.bgld, a few KB each).
 
-    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage m7q6k_8k shift selfextend yarn l2_7b l32_3b
+    python tests/golden/gen_fullsize_fixtures.py [cfg ...]      cfg in: 8b 8b_prefill2048 70b_stage 70b_full m7q6k_8k shift selfextend yarn l2_7b l32_3b
 """
 import hashlib
 import os
@@ -26,6 +26,9 @@ CONFIGS = {
     "8b_prefill2048": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, theta=500000.0), 2048, 8, 4096),
     # one pipeline stage of Llama-3-70B Q4_K_M (the last: 10 layers + output layer), 70B widths, Q5_K attn_v outside the "more bits" layers
     "70b_stage": (dict(E=8192, H=64, Hkv=8, L=10, F=28672, V=128256, theta=500000.0, type_fn="70b"), 8, 16, 256),
+    # config 4 at FULL depth: the whole Llama-3-70B Q4_K_M (80 layers, 41.9 GB of weights, attn_v Q5_K / Q6_K) — the N = 1 point of the layer split; the file is
+    # the one `bench.py --model 70b` writes
+    "70b_full": (dict(E=8192, H=64, Hkv=8, L=80, F=28672, V=128256, theta=500000.0, type_fn="70b_full"), 16, 8, 64),
     "m7q6k_8k": (dict(E=4096, H=32, Hkv=8, L=32, F=14336, V=32000, theta=10000.0, type_fn="q6k", embd_type=Q6), 8064, 16, 8192),
     # generation past n_ctx with Booster's context shift (cpp/bridge.cpp:487-503; ref_run's n_keep argument).  A small GQA model,
     # n_ctx 96, 150 generated tokens: three shifts, holes refilled in cell order, K rows re-rotated in place three times over
@@ -48,6 +51,8 @@ N_KEEP = {"shift": 8, "selfextend": -216}
 def type_fn_of(tag, L):
     if tag == "q6k":
         return lambda name, il: gguf.Q6_K
+    if tag == "70b_full":
+        return lambda name, il: gguf.q4_k_m_type_70b(name, il, L)
     if tag == "70b":
         # Q4_K_M recipe of an 80-layer model seen from its LAST stage (layers 70..79): attn_v Q6_K in the "more bits" layers, else Q5_K
         def f(name, il):
@@ -62,6 +67,8 @@ def type_fn_of(tag, L):
 def model_path(cfg, d="/dev/shm"):
     if cfg.startswith("8b"):
         return os.path.join(d, "bamd_llama3_8b_q4_k_m_synth.gguf")      # the file bench.py and tests/test_gpu_fullsize.py use
+    if cfg == "70b_full":
+        return os.path.join(d, "bamd_llama3_70b_q4_k_m_synth.gguf")     # the file `bench.py --model 70b` uses
     return os.path.join(d, "bamd_fx_%s.gguf" % cfg)
 
 
