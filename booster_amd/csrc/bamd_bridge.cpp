@@ -34,8 +34,11 @@ struct JanusParams { int32_t janus = 1, depth = 200; float scale = 0.96f, hi = 0
 
 // one layer-split stage: its slice of the model on one device, the context's own (non-blocking) stream as the stage stream, the
 // hand-off buffer the previous stage writes over xGMI, and the event that orders the neighbours behind this stage's work
+// hand-off buffers and events come in PAIRS, used alternately by consecutive evaluations (parity of Pod::seq): stage s may start on
+// micro-batch k + 1 while stage s + 1 still reads micro-batch k from the other buffer — the prompt pipelines across the stages the way the
+// reference's scheduler does with its input copies (GGML_SCHED_MAX_COPIES, cpp/ggml/src/ggml-backend.c:1030, :1751-1844)
 struct Stage {
-    bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in = nullptr; hipEvent_t done = nullptr;
+    bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in[2] = { nullptr, nullptr }; hipEvent_t done[2] = { nullptr, nullptr };
     void * stream() const { return bamd_context_stream(ctx); }
 };
 
@@ -43,6 +46,7 @@ struct Pod {
     std::vector<Stage> stages;
     BamdVocab vocab;
     int n_ctx = 0, n_predict = 0, n_batch = 512, n_vocab = 0, n_embd = 0;
+    unsigned seq = 0;                            // evaluations handed through the stages so far (parity picks the hand-off buffer / event)
     JanusParams jp;
     std::vector<float> scales, types;            // per-vocab Janus tables (cpp/janus.cpp:36-37 keeps them global)
     bool janus_ready = false;
@@ -371,7 +375,9 @@ int gpu_weights(int gpu1, int gpu2, int gpu3, int gpu4, int * w) {
     return n > 0 ? n : 4;
 }
 
-int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // llama_decode for one micro-batch (<= 512 tokens)
+// need_logits = false (a prompt micro-batch that is not the last one before sampling): nothing is read back and the host does not wait — the
+// next micro-batch is enqueued behind this one and the stages overlap; the next call that does need the logits waits for everything
+int pod_decode(Pod & p, const int * tokens, int n, int n_past, bool need_logits = true) {          // llama_decode for one micro-batch (<= 512 tokens)
     const auto t0 = std::chrono::steady_clock::now();
     if (p.stages.size() == 1) {
         if (bamd_decode(p.stages[0].ctx, tokens, n, n_past)) return 1;
@@ -379,42 +385,49 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past) {          // lla
     } else {
         // prompt micro-batches go through every stage as ONE batch (hidden state [n][n_embd] handed to the next device); single tokens,
         // and shapes without batched kernels, step token by token
-        // Stream-ordered hand-off, no host synchronisation per hop: stage s works on its own stream, behind the event of stage s-1 (whose
-        // work ends with the peer write of the hidden state into this stage's hand-off buffer) and behind the previous event of stage
-        // s+1 (which must be done with ITS hand-off buffer before this stage overwrites it).  A single decoded token therefore crosses
-        // the devices as one chain of device-side dependencies — each stage replaying its captured graph — and the host waits once, at
-        // the end (llama_decode's own synchronisation point).
-        auto ordered = [&](size_t s) -> int {
+        // Stream-ordered hand-off, no host synchronisation per hop: stage s works on its own stream, behind the event of stage s-1 for THIS
+        // evaluation (whose work ends with the peer write of the hidden state into this stage's hand-off buffer of this parity) and behind
+        // the event of stage s+1 for the evaluation before last (which read the buffer of this parity that this stage is about to
+        // overwrite).  A single decoded token therefore crosses the devices as one chain of device-side dependencies — each stage
+        // replaying its captured graph — and the host waits once, at the end (llama_decode's own synchronisation point).
+        auto ordered = [&](size_t s, int par) -> int {
             Stage & st = p.stages[s];
             if (hipSetDevice(st.device) != hipSuccess) return 1;
-            if (s > 0 && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s - 1].done, 0) != hipSuccess) return 1;
-            if (s + 1 < p.stages.size() && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s + 1].done, 0) != hipSuccess) return 1;   // never recorded yet: no-op
+            if (s > 0 && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s - 1].done[par], 0) != hipSuccess) return 1;
+            if (s + 1 < p.stages.size() && hipStreamWaitEvent((hipStream_t) st.stream(), p.stages[s + 1].done[par], 0) != hipSuccess) return 1;   // never recorded yet: no-op
             return 0;
         };
-        auto stamp = [&](size_t s) -> int { return hipEventRecord(p.stages[s].done, (hipStream_t) p.stages[s].stream()) != hipSuccess; };
+        auto stamp = [&](size_t s, int par) -> int { return hipEventRecord(p.stages[s].done[par], (hipStream_t) p.stages[s].stream()) != hipSuccess; };
         bool batched = n > 1 && n <= 512;
-        for (size_t s = 0; s < p.stages.size() && batched; ++s) {
-            Stage & st = p.stages[s];
-            const bool last = s + 1 == p.stages.size();
-            void * hout = last ? nullptr : p.stages[s + 1].hidden_in;
-            if (ordered(s)) return 1;
-            const int rc = bamd_stage_prefill(st.ctx, s == 0 ? tokens : nullptr, n, n_past, st.hidden_in, hout, last ? 1 : 0, st.stream());
-            if (rc == 2 && s == 0) { batched = false; break; }            // no batched kernels for this model: per-token path below
-            if (rc || stamp(s)) return 1;
+        if (batched) {
+            const int par = (int) (p.seq & 1u);
+            for (size_t s = 0; s < p.stages.size() && batched; ++s) {
+                Stage & st = p.stages[s];
+                const bool last = s + 1 == p.stages.size();
+                void * hout = last ? nullptr : p.stages[s + 1].hidden_in[par];
+                if (ordered(s, par)) return 1;
+                const int rc = bamd_stage_prefill(st.ctx, s == 0 ? tokens : nullptr, n, n_past, st.hidden_in[par], hout, last && need_logits ? 1 : 0, st.stream());
+                if (rc == 2 && s == 0) { batched = false; break; }            // no batched kernels for this model: per-token path below
+                if (rc || stamp(s, par)) return 1;
+            }
+            if (batched) p.seq += 1;
         }
         const int prefill = n > 1;
         for (int t = 0; t < n && !batched; ++t) {
+            const int par = (int) (p.seq & 1u);
             for (size_t s = 0; s < p.stages.size(); ++s) {
                 Stage & st = p.stages[s];
                 const bool last = s + 1 == p.stages.size();
-                void * hout = last ? nullptr : p.stages[s + 1].hidden_in;       // lives on the NEXT device; peer write
-                if (ordered(s)) return 1;
-                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in, hout, last && t == n - 1, prefill, st.stream())) return 1;
-                if (stamp(s)) return 1;
+                void * hout = last ? nullptr : p.stages[s + 1].hidden_in[par];       // lives on the NEXT device; peer write
+                if (ordered(s, par)) return 1;
+                if (bamd_stage_step(st.ctx, tokens[t], nullptr, n_past + t, st.hidden_in[par], hout, last && t == n - 1 && need_logits, prefill, st.stream())) return 1;
+                if (stamp(s, par)) return 1;
             }
+            p.seq += 1;
         }
         Stage & lst = p.stages.back();
-        if (!p.gpu_sampler) {
+        if (!need_logits) { }                      // nothing to wait for: the next evaluation queues behind this one on every stage
+        else if (!p.gpu_sampler) {
             const float * lg = bamd_stage_get_logits(lst.ctx, lst.stream());      // synchronises the last stage's stream: everything before it is done
             if (!lg) return 1;
             memcpy(p.logits.data(), lg, (size_t) p.n_vocab * 4);
@@ -432,8 +445,7 @@ void pod_free(Pod * p) {
     if (!p) return;
     for (auto & s : p->stages) {
         hipSetDevice(s.device);
-        if (s.done) hipEventDestroy(s.done);
-        if (s.hidden_in) hipFree(s.hidden_in);
+        for (int k = 0; k < 2; ++k) { if (s.done[k]) hipEventDestroy(s.done[k]); if (s.hidden_in[k]) hipFree(s.hidden_in[k]); }
         if (s.ctx) bamd_context_free(s.ctx);
         if (s.model) bamd_model_free(s.model);
     }
@@ -490,10 +502,10 @@ static void * init_context_impl(int idx, char * modelName, int batch_size, int g
         ref.ctx = bamd_context_new(ref.model, n_ctx);
         if (!ref.ctx) { fprintf(stderr, "initContext: error: failed to create context: %s\n", bamd_last_error()); return nullptr; }
         hipSetDevice(ref.device);
-        if (hipEventCreateWithFlags(&ref.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&ref.done[k], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (!first) {
             hipSetDevice(ref.device);
-            if (hipMalloc(&ref.hidden_in, (size_t) 512 * pod->n_embd * 4) != hipSuccess) return nullptr;     // one prompt micro-batch of hidden states
+            for (int k = 0; k < 2; ++k) if (hipMalloc(&ref.hidden_in[k], (size_t) 512 * pod->n_embd * 4) != hipSuccess) return nullptr;     // a prompt micro-batch of hidden states, twice
             // let the producer's device write the hand-off buffer directly over xGMI (the reference: cudaDeviceEnablePeerAccess, ggml-cuda.cu:1304)
             const int prev = pod->stages[s - 1].device;
             if (prev != ref.device) { int can = 0; hipDeviceCanAccessPeer(&can, prev, ref.device); if (can) { hipSetDevice(prev); hipDeviceEnablePeerAccess(ref.device, 0); } }
@@ -557,7 +569,9 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
                 int n_eval = std::min((int) embd.size() - i, p.n_batch);
                 for (int u = 0; u < n_eval; u += 512) {                      // llama_decode's n_ubatch = 512 micro-batches (llama.cpp:14615)
                     const int nu = std::min(512, n_eval - u);
-                    if (pod_decode(p, &embd[(size_t) (i + u)], nu, n_past + u)) return 1;
+                    // the logits are sampled from only once the whole prompt is in (below): earlier micro-batches are not waited for
+                    const bool need = (int) embd_inp.size() <= n_consumed && i + u + nu >= (int) embd.size();
+                    if (pod_decode(p, &embd[(size_t) (i + u)], nu, n_past + u, need)) return 1;
                 }
                 n_past += n_eval;
             }

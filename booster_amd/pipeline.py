@@ -22,11 +22,42 @@ def split_layers(n_layer, n_stage):
     return list(zip([0] + cuts[:-1], cuts))
 
 
-def split_layers_balanced(n_layer, n_stage, head_cost=1.35):
-    """`gpus:` weights chosen so that stage TIMES are even: the last stage also runs output_norm + lm_head, which costs about
-    `head_cost` layers of decode time on the 8B shape (431 MB of Q6_K against ~146-161 MB per layer)."""
+# decode-time model of a launch sequence on the MI355X: weights stream at ~6.2 TB/s inside a launch, lm_head (one long launch) at
+# ~6.4 TB/s, and every layer pays ~21 us that no byte explains (five dependent launches: boundary, first requests, chain tail; attention latency).
+# Checked against the measured launch times: 8B 44.3 us per layer / 67 us lm_head, 70B 107 / 133.
+STREAM_BPS, HEAD_BPS, LAYER_FIXED_S, HEAD_FIXED_S = 6.2e12, 6.4e12, 21e-6, 2e-6
+
+
+def head_cost_layers(layer_bytes, head_bytes):
+    """how many layers of decode time output_norm + lm_head cost on a model whose layers stream `layer_bytes` and whose output matrix is `head_bytes`"""
+    return (head_bytes / HEAD_BPS + HEAD_FIXED_S) / (layer_bytes / STREAM_BPS + LAYER_FIXED_S)
+
+
+def model_bytes(path):
+    """(mean bytes of a layer's matrices, bytes of the output matrix) from the GGUF tensor table (the tied-embedding fallback included)"""
+    from .gguf import GGUFReader
+    r = GGUFReader(path)
+    layer, n_layer, head = 0, 0, 0
+    for name, t in r.tensors.items():
+        nb = len(t["data"])
+        if name.startswith("blk.") and name.endswith(".weight") and "norm" not in name:
+            layer += nb
+            n_layer = max(n_layer, int(name.split(".")[1]) + 1)
+        elif name == "output.weight":
+            head = nb
+    if head == 0 and "token_embd.weight" in r.tensors:
+        head = len(r.tensors["token_embd.weight"]["data"])
+    return layer / max(n_layer, 1), head
+
+
+def split_layers_balanced(n_layer, n_stage, head_cost=None, path=None):
+    """`gpus:` weights chosen so that stage TIMES are even: the last stage also runs output_norm + lm_head, which costs `head_cost` layers of
+    decode time — from the model's own bytes (path: its GGUF) through head_cost_layers: ~1.5 layers on the 8B shape (431 MB of Q6_K against
+    ~146-161 MB per layer), ~1.3 on the 70B shape (862 MB against 524 MB per layer)."""
     if n_stage == 1:
         return [(0, n_layer)]
+    if head_cost is None:
+        head_cost = head_cost_layers(*model_bytes(path)) if path else 1.4
     target = (n_layer + head_cost) / n_stage
     cuts = [int(round(target * (i + 1))) for i in range(n_stage - 1)] + [n_layer]
     for i in range(n_stage - 1):                     # strictly increasing, at least one layer per stage (also the last one)
@@ -165,7 +196,7 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
     stages (the stages work one after another, so it does not grow with N — Booster's `gpus:` split buys capacity, not batch-1 speed);
     the throughput with N independent sequences in flight (Booster's pods keeping every stage busy) is reported beside it."""
     import booster_amd
-    ranges = split_layers_balanced(cfg["L"], N)
+    ranges = split_layers_balanced(cfg["L"], N, path=path)
     stage = HipStage(booster_amd, torch, path, local, ranges[rank], rank == 0, rank == N - 1, n_ctx, N)
     dist.barrier()
     # untimed: every sequence through the prompt and `warmup` + 1 decode steps.  All sequences are identical, so the token fed at

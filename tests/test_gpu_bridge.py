@@ -168,6 +168,27 @@ def test_device_sampler_fallbacks(lib, bamd, tmp_path):
     assert counts[1] >= 3 and counts[0] >= 3            # the crowded cases went through the host path, the others stayed on the device
 
 
+def test_long_prompt_pipelines_through_three_stages(lib, bamd, tmp_path, monkeypatch):
+    """a prompt of five micro-batches (> 2048 tokens, n_batch 512) through three layer-split stages: the micro-batches are enqueued
+    back to back — double-buffered hand-off, no host wait until the logits are needed (GGML_SCHED_MAX_COPIES, ggml-backend.c:1030) — and
+    the text must be the one the single-stage pod produces (Janus hi = lo = 1: arg-max, deterministic)"""
+    path, vocab = make_model(tmp_path, "bridge_long.gguf")
+    prompt = (b"the cat sat on the hat and the hen ate the ham " * 120)[:2900]
+    texts = []
+    for pod, gpus in ((0, None), (1, "1,1,2")):            # (pods 0 and 1 of the earlier tests are replaced)
+        if gpus:
+            monkeypatch.setenv("BOOSTER_GPUS", gpus)
+            if bamd.device_count() < 3:
+                monkeypatch.setenv("BAMD_VIRTUAL_DEVICES", "3")
+        ctx = lib.initContext(*ctx_args(pod, path, (100, 0, 0, 0), 4096, 12))
+        assert ctx
+        job = ("long-%d" % pod).encode()
+        n = lib.doInference(pod, ctx, job, b"", prompt)
+        assert n > 2048 + 1, "the prompt must span at least five micro-batches (%d evaluations)" % n
+        texts.append((n, lib.status(job)))
+    assert texts[0] == texts[1]
+
+
 @pytest.mark.parametrize("split", ["one stage", "three stages"])
 def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
     """the nine cgo symbols replayed against the transcript recorded from the GENUINE reference bridge

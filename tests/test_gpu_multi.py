@@ -80,3 +80,24 @@ def test_pipeline_ranks_rccl(bamd, tmp_path, world, n_seq):
     assert len(fed) == n_seq
     for f in fed:
         assert [int(t) for t in f] == want, "layer split over RCCL differs from the single-GPU greedy tokens"
+
+
+@pytest.mark.parametrize("model", ["8b", "70b"])
+def test_bench_pipeline_smoke_on_one_gpu(model):
+    """`bench.py --gpus 1 --pipeline-smoke [--model 70b]`: the N > 1 leg of the bench — layer-split stage object, hipGraph stage steps,
+    the grouped send / recv rounds on an RCCL process group — driven end to end by a single rank, so that the code the driver runs on its
+    8-GPU node is exercised on every one-GPU box.  The JSON line must carry the BASELINE metric, a positive value and the stage roofline."""
+    import json
+    import subprocess
+    if model == "70b":
+        st = os.statvfs("/dev/shm") if os.path.isdir("/dev/shm") else None
+        if st is None or (st.f_bavail * st.f_frsize < (46 << 30) and not os.path.exists("/dev/shm/bamd_llama3_70b_q4_k_m_synth.gguf.done")):
+            pytest.skip("no room for the 42 GB synthetic Llama-3-70B GGUF")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pipeline-smoke", "--model", model, "--steps", "8", "--warmup", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["metric"].startswith("decode tokens/sec") and line["value"] > 0 and line["n_gpus"] == 1
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1

@@ -100,3 +100,6 @@ def test_split_layers():
         b = pipeline.split_layers_balanced(L, n)
         assert len(b) == n and b[0][0] == 0 and b[-1][1] == L and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(y > x for x, y in b)
     assert pipeline.split_layers_balanced(32, 8)[-1] == (29, 32)           # the stage that also runs lm_head gets fewer layers
+    # the head's cost comes from the model's own bytes: ~1.5 layers of decode time at the 8B widths, ~1.3 at the 70B widths
+    assert 1.4 < pipeline.head_cost_layers(144.5e6, 430.9e6) < 1.65 and 1.15 < pipeline.head_cost_layers(524.6e6, 861.9e6) < 1.4
+    assert pipeline.split_layers_balanced(80, 8, head_cost=pipeline.head_cost_layers(524.6e6, 861.9e6))[-1] == (71, 80)
