@@ -746,7 +746,7 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = 1;
-        t.batch = 1; t.ld_qkv = ldq; t.ld_out = E; t.lds_ld = attn_lds_ld(c, n_past + T - 1);
+        t.batch = 1; t.ld_qkv = ldq; t.ld_out = E; t.lds_ld = attn_lds_ld(c, n_past + T - 1); t.batch_pos0p1 = n_past + 1;
         if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
         // x2 = x + Wo . att
         bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, c->bblob16, s);
