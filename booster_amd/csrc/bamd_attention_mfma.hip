@@ -14,7 +14,8 @@
 // One workgroup = one KV head x 16 (token, query head) columns (16 / gq tokens x the gq heads that share the KV head): every K row and V^T row
 // fetched serves 16 columns, the matrix pipe does the multiply-adds (the VALU kernel, attn_batch_kernel, spent ~3 vector instructions per
 // multiply-add and was 55 % of a long prompt), and the workgroup -> KV head mapping keeps one head's K / V in one XCD's L2.
-// head_dim 128; up to BAMD_AM_MAXPOS cached positions (the score / probability rows of the 16 columns live in LDS); other shapes: attn_batch_kernel.
+// head_dim 128; the score / probability rows of the 16 columns live in LDS up to BAMD_AM_MAXPOS cached positions, in a global scratch block beyond (LONG);
+// other shapes: attn_batch_kernel.
 #include "bamd_device.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -23,6 +24,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define BAMD_AM_VBYTES (8 * 16 * BAMD_AM_VROW) /* one staged block per wave */
 #define BAMD_AM_RBYTES 1024                    /* column maxima per wave + 1 / sum per column */
 #define BAMD_AM_MAXPOS 2176                    /* 64 B of LDS per position: 136 KB + q + V stage + reduction scratch <= 160 KB */
+#define BAMD_AM_CHUNK 1024                     /* LONG: positions staged through LDS at a time in pass 3 (64 KB) */
 #ifndef BAMD_AM_KD
 #define BAMD_AM_KD 2                           /* tiles of 16 K rows in flight per wave (pass 1) */
 #endif
@@ -38,7 +40,10 @@ __device__ __forceinline__ int am_sidx(int p, int n) {
 __device__ __forceinline__ float h2f_lo(uint32_t w) { return __half2float(__ushort_as_half((unsigned short) (w & 0xffffu))); }
 __device__ __forceinline__ float h2f_hi(uint32_t w) { return __half2float(__ushort_as_half((unsigned short) (w >> 16))); }
 
-template <int GQ>
+// LONG: more positions than the LDS holds rows for — the scores / exp values of the 16 columns live in a global scratch block of this workgroup
+// ([16 columns][ld] f32: written by pass 1, exponentiated in place by pass 2) and pass 3 walks them in chunks of BAMD_AM_CHUNK positions staged
+// through LDS; the P.V chains simply continue from chunk to chunk.
+template <int GQ, bool LONG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_batch_mfma_kernel(bamd_attn_args a, int T, int dbg_exit) {
     constexpr int hd = 128, L = 16, TT = 16 / GQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -47,6 +52,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     float * cmaxs = (float *) (smem + BAMD_AM_QBYTES + BAMD_AM_VBYTES);        // [8 waves][16 columns] score maxima; fsv [16]: 1 / sum of every column
     float * fsv = cmaxs + 128;
     float * S = (float *) (smem + BAMD_AM_QBYTES + BAMD_AM_VBYTES + BAMD_AM_RBYTES);   // [positions][16]: scores, then exp values (the probabilities are formed in pass 3)
+    const int sld = a.lds_ld ? a.lds_ld : a.n_ctx;                              // LONG: floats per column of this workgroup's scratch block
+    float * scr = LONG ? a.batch_scratch + (size_t) blockIdx.x * 16 * sld : nullptr;
     const bamd_step_state * st = a.st;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int hk = (int) blockIdx.x % Hkv, tile = (int) blockIdx.x / Hkv;      // consecutive workgroups: different KV heads (= different XCDs for Hkv = 8)
@@ -122,13 +129,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const f32x4_t t0_ = Se[0] + Se[4], t1_ = Se[1] + Se[5], t2_ = Se[2] + Se[6], t3_ = Se[3] + Se[7];
                     const f32x4_t u0 = t0_ + t1_, u2 = t2_ + t3_;
                     const f32x4_t sc = u0 + u2;
+                    float vv[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int p = pt * 16 + 4 * kq + r;                    // D layout: register r of lane l = row 4 (l / 16) + r, column l % 16
                         const float v = p <= pcol ? sc[r] : -INFINITY;         // KQ_mask (llama.cpp:14152-14200)
-                        S[am_sidx(p, mrow)] = v;
+                        if (!LONG) S[am_sidx(p, mrow)] = v;
+                        vv[r] = v;
                         cmax = v > cmax ? v : cmax;
                     }
+                    if (LONG) *(float4 *) (scr + (size_t) mrow * sld + pt * 16 + 4 * kq) = make_float4(vv[0], vv[1], vv[2], vv[3]);   // four consecutive positions of column mrow
                 }
                 kload(ring[d], pt + 8 * BAMD_AM_KD);
             }
@@ -157,10 +167,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int w2 = 1; w2 < 8; ++w2) { const float o = cmaxs[w2 * 16 + n]; smax = o > smax ? o : smax; }
         const float mx = smax * scale;                                         // max_i (s_i * scale): the product is monotonic in s (scale > 0)
         double sum = 0.0;
+        float * colv = LONG ? scr + (size_t) n * sld : nullptr;
         for (int p = pl; p < npos; p += 32) {                                  // npos % 64 == 0: every 8-lane group is all-active
-            const float w = S[am_sidx(p, n)] * scale;
+            const float w = (LONG ? colv[p] : S[am_sidx(p, n)]) * scale;
             const float val = v_expf(w - mx);
-            S[am_sidx(p, n)] = val;
+            if (LONG) colv[p] = val; else S[am_sidx(p, n)] = val;
             const float c = hsum8_tinyblas(val);                               // the reference's 8-wide partial sum (same tree shape), valid in lane & 7 == 0
             if ((lane & 7) == 0) sum += (double) c;
         }
@@ -170,10 +181,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         double rs = 1.0 / tot;
         if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(npos / 8))) {           // uniform per half-wave; rare
             double sq = 0.0;
+            if (LONG) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }   // the half-wave's own stores, then lane 0's loads
             if (pl == 0) {
                 for (int p = 0; p < npos; p += 8) {
-                    const float v0 = S[am_sidx(p, n)], v1 = S[am_sidx(p + 1, n)], v2 = S[am_sidx(p + 2, n)], v3 = S[am_sidx(p + 3, n)];
-                    const float v4 = S[am_sidx(p + 4, n)], v5 = S[am_sidx(p + 5, n)], v6 = S[am_sidx(p + 6, n)], v7 = S[am_sidx(p + 7, n)];
+                    float v0, v1, v2, v3, v4, v5, v6, v7;
+                    if (LONG) { v0 = colv[p]; v1 = colv[p + 1]; v2 = colv[p + 2]; v3 = colv[p + 3]; v4 = colv[p + 4]; v5 = colv[p + 5]; v6 = colv[p + 6]; v7 = colv[p + 7]; }
+                    else { v0 = S[am_sidx(p, n)]; v1 = S[am_sidx(p + 1, n)]; v2 = S[am_sidx(p + 2, n)]; v3 = S[am_sidx(p + 3, n)];
+                           v4 = S[am_sidx(p + 4, n)]; v5 = S[am_sidx(p + 5, n)]; v6 = S[am_sidx(p + 6, n)]; v7 = S[am_sidx(p + 7, n)]; }
                     const float a0 = v0 + v4, a1 = v1 + v5, a2 = v2 + v6, a3 = v3 + v7;
                     const float b0 = a0 + a2, b1 = a1 + a3;
                     sq += (double) (b0 + b1);
@@ -199,12 +213,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int e = 0; e < 8; ++e) acc[e] = (f32x4_t) { 0.f, 0.f, 0.f, 0.f };
 #define BAMD_AM_VSTEP(A_, B_, b_) do { \
             const int b = (b_), bc = b; \
-            if (b < nblk) {                                                    /* wave-uniform; no request inside */ \
+            if (b < cb1) {                                                     /* wave-uniform; no request inside */ \
                 /* (DS operations of one wave execute in order: these stores land behind the previous block's reads) */ \
                 *(uint4 *) (vs + srow * BAMD_AM_VROW + sby) = A_; \
                 *(uint4 *) (vs + (srow + 8) * BAMD_AM_VROW + sby) = B_; \
                 const unsigned short * vr = (const unsigned short *) (vs + mrow * BAMD_AM_VROW) + kq;   /* A[m = mrow][k = kq]: V^T[d][64 b + 8 (l0 + kq) + e] sits at 8 e + l0 + kq */ \
-                const float * Sb = S + bc * 64 * 16; const float fsb = fs; \
+                const float * Sb = S + (bc - cb0) * 64 * 16; const float fsb = fs; \
                 _Pragma("unroll") for (int l0 = 0; l0 < 8; l0 += 4) { \
                     _Pragma("unroll") for (int e = 0; e < 8; ++e) { \
                         const float av = __half2float(__ushort_as_half(vr[8 * e + l0])); \
@@ -214,8 +228,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 } \
             } \
             BAMD_AM_VLOAD(A_, B_, b + 4); } while (0)
-        for (int b0 = 0; b0 < nblk; b0 += 4) {
-            BAMD_AM_VSTEP(va0, vb0, b0); BAMD_AM_VSTEP(va1, vb1, b0 + 1); BAMD_AM_VSTEP(va2, vb2, b0 + 2); BAMD_AM_VSTEP(va3, vb3, b0 + 3);
+        for (int cb0 = 0; cb0 < nblk; cb0 += (LONG ? BAMD_AM_CHUNK / 64 : nblk)) {     // !LONG: one turn, everything is in LDS already
+            const int cb1 = LONG ? (cb0 + BAMD_AM_CHUNK / 64 < nblk ? cb0 + BAMD_AM_CHUNK / 64 : nblk) : nblk;
+            if (LONG) {
+                if (cb0) __syncthreads();                                      // every wave is done with the previous chunk
+                const int cn = (cb1 - cb0) * 64;                               // positions of this chunk: column n = tid / 32 walks them 32 at a time (coalesced), stores them swizzled
+                const float * src = scr + (size_t) (tid >> 5) * sld + cb0 * 64;
+                for (int p = tid & 31; p < cn; p += 32) S[am_sidx(p, tid >> 5)] = src[p];
+                __syncthreads();
+            }
+            for (int b0 = cb0; b0 < cb1; b0 += 4) {                            // (chunks hold a multiple of four blocks, except possibly the last)
+                BAMD_AM_VSTEP(va0, vb0, b0); BAMD_AM_VSTEP(va1, vb1, b0 + 1); BAMD_AM_VSTEP(va2, vb2, b0 + 2); BAMD_AM_VSTEP(va3, vb3, b0 + 3);
+            }
         }
 #undef BAMD_AM_VSTEP
 #undef BAMD_AM_VLOAD
@@ -232,22 +256,32 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // 0 = launched (after the KV store); 1 = shape not covered: the caller takes attn_batch_kernel
+size_t bamd_attention_batch_mfma_scratch(int Hkv, int gq, int T, int ld) {       // bytes of a.batch_scratch a micro-batch of T tokens needs when ld > BAMD_AM_MAXPOS (else 0)
+    if (ld <= BAMD_AM_MAXPOS || (gq != 1 && gq != 2 && gq != 4 && gq != 8 && gq != 16)) return 0;
+    const int tt = 16 / gq;
+    return (size_t) Hkv * ((T + tt - 1) / tt) * 16 * (size_t) ld * 4;
+}
 int bamd_launch_attention_batch_mfma(const bamd_attn_args & a, int gq, int T, hipStream_t s) {
     static const bool on = [] { const char * e = getenv("BAMD_ATTN_MFMA"); return !(e && e[0] == '0'); }();
     if (!on || a.hd != 128 || !a.batch || T < 2) return 1;
     if (gq != 1 && gq != 2 && gq != 4 && gq != 8 && gq != 16) return 1;
     const int npos = a.lds_ld ? a.lds_ld : a.n_ctx;                            // the caller's bound on the padded sequence length of this micro-batch (multiple of 64)
-    if ((npos & 63) || npos > BAMD_AM_MAXPOS || npos > a.n_ctx) return 1;
+    if ((npos & 63) || npos > a.n_ctx) return 1;
+    const bool lng = npos > BAMD_AM_MAXPOS;
+    if (lng && !a.batch_scratch) return 1;
     static const int dbg = [] { const char * e = getenv("BAMD_AM_EXIT"); return e ? atoi(e) : 0; }();     // timing experiments only: leave the kernel after phase 1 / 2 / 3
-    const size_t lds = BAMD_AM_QBYTES + BAMD_AM_VBYTES + BAMD_AM_RBYTES + (size_t) npos * 64;
+    const size_t lds = BAMD_AM_QBYTES + BAMD_AM_VBYTES + BAMD_AM_RBYTES + (size_t) (lng ? BAMD_AM_CHUNK : npos) * 64;
     const int tt = 16 / gq;
     const dim3 grid(a.Hkv * ((T + tt - 1) / tt)), block(512);
+#define BAMD_AM_GO(GQ_) do { if (lng) hipLaunchKernelGGL((attn_batch_mfma_kernel<GQ_, true>), grid, block, lds, s, a, T, dbg); \
+                             else     hipLaunchKernelGGL((attn_batch_mfma_kernel<GQ_, false>), grid, block, lds, s, a, T, dbg); } while (0)
     switch (gq) {
-        case 1: hipLaunchKernelGGL((attn_batch_mfma_kernel<1>), grid, block, lds, s, a, T, dbg); break;
-        case 2: hipLaunchKernelGGL((attn_batch_mfma_kernel<2>), grid, block, lds, s, a, T, dbg); break;
-        case 4: hipLaunchKernelGGL((attn_batch_mfma_kernel<4>), grid, block, lds, s, a, T, dbg); break;
-        case 8: hipLaunchKernelGGL((attn_batch_mfma_kernel<8>), grid, block, lds, s, a, T, dbg); break;
-        default: hipLaunchKernelGGL((attn_batch_mfma_kernel<16>), grid, block, lds, s, a, T, dbg); break;
+        case 1: BAMD_AM_GO(1); break;
+        case 2: BAMD_AM_GO(2); break;
+        case 4: BAMD_AM_GO(4); break;
+        case 8: BAMD_AM_GO(8); break;
+        default: BAMD_AM_GO(16); break;
     }
+#undef BAMD_AM_GO
     return 0;
 }

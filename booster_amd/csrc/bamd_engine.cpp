@@ -148,6 +148,7 @@ struct bamd_context {
     // phase-stamp blocks (bamd_timeline_step, BAMD_TIMING builds): one block of BAMD_TL_SLOT_WORDS u64 per launch
     unsigned long long * tl_base = nullptr; int tl_slot = 0, tl_cap = 0;
     int bcap = 0;
+    float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0;   // score rows of the matrix-core prefill attention beyond 2176 positions (grow-only)
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
@@ -397,6 +398,7 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
     if (c->logits_host) hipHostFree(c->logits_host);
+    if (c->attn_bscr) hipFree(c->attn_bscr);
     if (c->samp_pen_host) hipHostFree(c->samp_pen_host);
     if (c->samp_out_host) hipHostFree(c->samp_out_host);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -747,6 +749,17 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = 1;
         t.batch = 1; t.ld_qkv = ldq; t.ld_out = E; t.lds_ld = attn_lds_ld(c, n_past + T - 1); t.batch_pos0p1 = n_past + 1;
+        {
+            const size_t need = m->hd == 128 ? bamd_attention_batch_mfma_scratch(m->Hkv, gq, T, t.lds_ld) : 0;
+            if (need > c->attn_bscr_bytes) {                                   // (freed with the context; replaced only while nothing of this context is in flight: stream order)
+                HIPC(hipStreamSynchronize(s));
+                if (c->attn_bscr) hipFree(c->attn_bscr);
+                c->attn_bscr = nullptr; c->attn_bscr_bytes = 0;
+                HIPC(hipMalloc((void **) &c->attn_bscr, need));
+                c->attn_bscr_bytes = need;
+            }
+            t.batch_scratch = need ? c->attn_bscr : nullptr;
+        }
         if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
         // x2 = x + Wo . att
         bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, c->bblob16, s);

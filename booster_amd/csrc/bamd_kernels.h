@@ -47,6 +47,7 @@ struct bamd_attn_args {
     float kq_scale;
     int prefill_mode;              // 1: KQ with the T>1 semantics of the reference (q -> f16, ggml_vec_dot_f16)
     int batch, ld_qkv, ld_out;     // batched prefill: q/k/v and out are [T][ld_*] f32, token = blockIdx.y, position st->pos + token
+    float * batch_scratch;         // batched prefill, more than 2176 positions: score rows of the matrix-core kernel (bamd_attention_batch_mfma_scratch bytes)
     int batch_pos0p1;              // batched prefill: the position of token 0, plus one (= st->pos + 1, known to the host: the matrix-core kernel takes it from here
                                    // and starts its requests without a dependent load of the device state); 0 = read st->pos
     int lds_ld;                    // single-launch / batched kernels: floats per score / probability row in LDS — a multiple of 64 that bounds the padded
@@ -93,5 +94,6 @@ int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStre
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported
 int  bamd_launch_attention_batch_mfma(const bamd_attn_args & a, int gq, int T, hipStream_t s);   // the same on the matrix cores (after the KV store); 1 = shape not covered
+size_t bamd_attention_batch_mfma_scratch(int Hkv, int gq, int T, int ld);                         // bytes of a.batch_scratch it needs for sequences of up to ld positions (0: none)
 void bamd_launch_sampler_shortlist(float * logits, const bamd_logit_penalty * pen, int n_pen, const uint8_t * halve_class, int halve,
                                    const float * cutoff_of, int V, bamd_shortlist_head * head, int32_t * ids, float * vals, int cap, hipStream_t s);
