@@ -76,8 +76,7 @@ def main():
     n_valid = sum(r is not None for r in rows)
     per = (n_valid - 1) // L                                  # launches per layer: 5, fewer when roles share a launch (bamd_colaunch.hip)
     co_attn = os.environ.get("BAMD_COLAUNCH", "1") != "0"
-    co_ffn = co_attn and os.environ.get("BAMD_COLAUNCH_FFN", "1") != "0"
-    names = ["qkv"] + (["attn+wo"] if co_attn else ["attention", "wo"]) + (["gu+down"] if co_ffn else ["gate_up", "down"])
+    names = ["qkv"] + (["attn+wo"] if co_attn else ["attention", "wo"]) + ["gate_up", "down"]
     if len(names) != per:
         names = ["qkv", "attention", "wo", "gate_up", "down"] if per == 5 else ["launch%d" % i for i in range(per)]
     H = 32
@@ -93,8 +92,8 @@ def main():
             if names[j] in ("qkv", "down"):                   # layers with a Q6_K attn_v / ffn_down stream more bytes
                 from booster_amd.gguf import q4_k_m_type, Q6_K
                 k += "_q6k" if q4_k_m_type("ffn_down", il, L) == Q6_K else "_q4k"
-            if names[j] in ("attn+wo", "gu+down"):            # the two roles of a shared launch, both against the launch's first entry
-                cut, ra_n, rw_n = (H, "  role attention", "  role wo") if names[j] == "attn+wo" else (256, "  role gate_up", "  role down")
+            if names[j] == "attn+wo":                         # the two roles of the shared launch, both against the launch's first entry
+                cut, ra_n, rw_n = H, "  role attention", "  role wo"
                 ra, rw = reduce_one(tl[i][:cut], r["start"]), reduce_one(tl[i][cut:], r["start"])
                 if ra is not None:
                     kinds.setdefault(ra_n, []).append(ra)
