@@ -63,11 +63,17 @@ struct Pod {
 // hold it for as long as the job exists (Go copies it at once, but the contract must not depend on that): a buffer is never freed or
 // moved — when the text outgrows it, a buffer of twice the capacity takes over and the old one stays behind (retired memory <= the
 // final text).  Appending inside a buffer keeps every reader's view NUL-terminated: the new terminator is written first, then the
-// piece from its last byte to its first, which overwrites the old terminator last.
+// piece from its last byte to its first, which overwrites the old terminator last.  That ordering is what an UNLOCKED reader (Go's
+// C.GoString on the pointer status() returned) relies on: it holds on x86-64, whose stores become visible in program order (the only host the
+// MI355X platform ships with; the reference hands out std::string::c_str() of a string it keeps appending to, with no ordering at all).
+// Growth: a job keeps <= 2x its text; the table itself is bounded — beyond BAMD_MAX_JOBS entries the oldest FINISHED jobs are dropped, 1/4 of the
+// table at a time (their status() pointers die with them: a server that polls a job it started tens of thousands of jobs ago gets "").
+#define BAMD_MAX_JOBS 65536
 struct Job {
     std::vector<std::unique_ptr<char[]>> bufs;
     char * cur_buf = nullptr; size_t cap = 0, len = 0;
     int64_t prompt_eval = 0, timing = 0, prompt_tokens = 0; uint32_t seed = 0;
+    bool finished = false; uint64_t serial = 0;  // set when doInference returns / insertion order (retirement of old jobs)
     const char * c_str() { if (!cur_buf) grow(64); return cur_buf; }
     void grow(size_t need) {
         size_t ncap = cap ? cap : 64; while (ncap < need) ncap *= 2;
@@ -89,6 +95,16 @@ struct Job {
 
 std::mutex g_mu;
 std::unordered_map<std::string, Job> g_jobs;
+uint64_t g_job_serial = 0;
+// call with g_mu held, before a job starts: keeps the table bounded
+void retire_old_jobs() {
+    if (g_jobs.size() < BAMD_MAX_JOBS) return;
+    std::vector<std::pair<uint64_t, std::string>> done;
+    for (auto & kv : g_jobs) if (kv.second.finished) done.push_back({ kv.second.serial, kv.first });
+    std::sort(done.begin(), done.end());
+    const size_t n = std::min(done.size(), (size_t) BAMD_MAX_JOBS / 4);
+    for (size_t i = 0; i < n; ++i) g_jobs.erase(done[i].second);
+}
 Pod * g_pods[8] = { nullptr };
 std::string g_debug;
 bool dbg(const char * what) { return g_debug.find(what) != std::string::npos; }
@@ -540,7 +556,7 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
     if (!p.janus_ready) { init_janus(p); upload_sampler_tables(p); }                                       // the reference rebuilds (and leaks) the tables per request
     const uint32_t seed = (uint32_t) time(nullptr);
     p.rng.seed(seed);                                                        // llama_set_rng_seed
-    { std::lock_guard<std::mutex> lk(g_mu); g_jobs[job].seed = seed; }
+    { std::lock_guard<std::mutex> lk(g_mu); retire_old_jobs(); Job & nj = g_jobs[job]; nj.seed = seed; nj.finished = false; nj.serial = ++g_job_serial; }
     if (p.vocab.type == BAMD_VOCAB_NONE) { fprintf(stderr, "doInference: model has no tokenizer (tokenizer.ggml.model = no_vocab)\n"); return 1; }
     const std::vector<int> embd_inp = p.vocab.tokenize(text, false, true);
     if (dbg("tokenizer")) { fprintf(stderr, "TOKENS: ["); for (int t : embd_inp) fprintf(stderr, " %d,", t); fprintf(stderr, " ]\n"); }
@@ -601,13 +617,17 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
     Job & j = g_jobs[job];
     j.prompt_eval = p.n_p_eval ? (int64_t) (p.t_p_eval_ms / (double) p.n_p_eval) : 0;
     j.timing = p.n_eval ? (int64_t) (p.t_eval_ms / (double) p.n_eval) : 0;
+    j.finished = true;
     return p.n_p_eval + p.n_eval;
 }
 
 BAMD_API int64_t doInference(int idx, void * ctx, char * jobID, char * sessionID, char * prompt) {
     (void) sessionID;
-    try { return do_inference_impl(idx, ctx, jobID, prompt); }
-    catch (const std::exception & e) { fprintf(stderr, "doInference: %s\n", e.what()); return 1; }
+    int64_t rc;
+    try { rc = do_inference_impl(idx, ctx, jobID, prompt); }
+    catch (const std::exception & e) { fprintf(stderr, "doInference: %s\n", e.what()); rc = 1; }
+    if (jobID) { std::lock_guard<std::mutex> lk(g_mu); auto it = g_jobs.find(jobID); if (it != g_jobs.end()) it->second.finished = true; }   // (also on the early-return paths)
+    return rc;
 }
 
 BAMD_API void stopInference(int idx) {
