@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
             }
             if (e == 0 && i < n_kv) {
 #pragma unroll
-                for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + i] = sc[j][g];
+                for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + vperm(i)] = sc[j][g];     // V^T position order (the softmax passes read 16 bytes at a time)
             }
         }
         if (tile0 + BAMD_QK_NT * (int) gridDim.y < tiles) BAMD_QK_PREFETCH(tile0 + BAMD_QK_NT * (int) gridDim.y);   // (n_ctx > 64 x BAMD_QK_NT x gridDim.y only)
@@ -73,7 +73,18 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 #undef BAMD_QK_PREFETCH
 }
 
-// softmax over n_kv scores of one head: grid (H), block 256.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
+// seq_expsum8 over values stored in the V^T position order (position i + j, i % 8 == 0, sits at (i & ~63) + 8 j + ((i & 63) >> 3))
+__device__ __forceinline__ double seq_expsum8_vt(const float * v, int n) {
+    double sq = 0.0;
+    for (int i = 0; i < n; i += 8) {
+        const float * q = v + (i & ~63) + ((i & 63) >> 3);
+        const float a0 = q[0] + q[32], a1 = q[8] + q[40], a2 = q[16] + q[48], a3 = q[24] + q[56];
+        const float b0 = a0 + a2, b1 = a1 + a3;
+        sq += (double) (b0 + b1);
+    }
+    return sq;
+}
+// softmax over n_kv scores of one head (stored in the V^T position order by attn_qk_kernel): grid (H), block 1024.  ggml.c:13682-13778 + :2619-2671 (AVX2 branch).
 // Probabilities are written back in the V^T position order (vperm) so the P.V lanes read them contiguously.
 #define BAMD_SM_R 8                      /* values per thread kept in registers: one pass over global memory up to n_kv = 8192 */
 __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
@@ -91,8 +102,8 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
     float mx = -INFINITY;
     if (cached) {
 #pragma unroll
-        for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; v[k] = i < n_kv ? s[i] * scale : -INFINITY; mx = v[k] > mx ? v[k] : mx; }
-    } else for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s[i] * scale; mx = w > mx ? w : mx; }
+        for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; v[k] = i < n_kv ? s[vperm(i)] * scale : -INFINITY; mx = v[k] > mx ? v[k] : mx; }
+    } else for (int i = tid; i < n_kv; i += blockDim.x) { const float w = s[vperm(i)] * scale; mx = w > mx ? w : mx; }
     for (int o = 32; o; o >>= 1) { const float om = __shfl_xor(mx, o); mx = om > mx ? om : mx; }
     if (lane == 0) redf[wave] = mx;
     __syncthreads();
@@ -110,9 +121,9 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
             }
         }
     } else for (int i = tid; i < n_kv; i += blockDim.x) {
-        const float w = s[i] * scale;
+        const float w = s[vperm(i)] * scale;
         const float val = v_expf(w - mx);
-        s[i] = val;                                              // same index this thread just read: no hazard
+        s[vperm(i)] = val;                                              // same index this thread just read: no hazard
         const float c = hsum8_tinyblas(val);
         if ((lane & 7) == 0) sum += (double) c;
     }
@@ -125,17 +136,17 @@ __global__ void __launch_bounds__(1024) attn_softmax_kernel(bamd_attn_args a) {
     if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
         if (cached) {
 #pragma unroll
-            for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) s[i] = v[k]; }
+            for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) s[vperm(i)] = v[k]; }
         }
         __syncthreads();
-        if (tid == 0) redd[0] = seq_expsum8(s, n_kv);
+        if (tid == 0) redd[0] = seq_expsum8_vt(s, n_kv);
         __syncthreads();
         rs = 1.0 / redd[0]; fs = (float) rs;
     }
     if (cached) {
 #pragma unroll
         for (int k = 0; k < BAMD_SM_R; ++k) { const int i = tid + k * blockDim.x; if (i < n_kv) pr[vperm(i)] = v[k] * fs; }
-    } else for (int i = tid; i < n_kv; i += blockDim.x) pr[vperm(i)] = s[i] * fs;
+    } else for (int i = tid; i < n_kv; i += blockDim.x) pr[vperm(i)] = s[vperm(i)] * fs;
 }
 // P.V: grid (H, hd/8), block 64: lane = d_local*8 + e carries the tinyBLAS chain Cv[e] of output (h, d).  sgemm.cpp:405-431 with
 // A = V^T rows (f16), B = p (f32).  The chain over positions is sequential per lane, but the loads are not: BAMD_PV_U blocks of 64
@@ -194,6 +205,178 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
 #undef BAMD_PV_TAIL
     const float v = hsum8_tinyblas(acc);
     if (e == 0) a.out[(size_t) h * hd + d] = v;
+}
+
+// softmax + P.V in ONE launch (long contexts, after attn_qk_kernel): grid (Hkv, hd/8, Z), block 1024; a workgroup serves NH query heads of one
+// KV head (NH * Z = gq) and 8 rows of V^T.  All sixteen waves turn the NH score rows into probabilities IN LDS (scaled score -> exponential ->
+// probability, in the V^T position order the scores arrive in), every workgroup for itself: hd/8 workgroups repeat the same rows, which is cheaper
+// than a launch of its own (attn_softmax_kernel: one workgroup per head, 9.2 us per layer, 224 CUs idle).  A wave of this chip issues one vector
+// instruction per ~4.2 ns (tools/chain_probe.hip: 10 clocks, dependent or not; a SIMD reaches its rate only with four or more waves), so the softmax
+// passes are written for few instructions per element — 16-byte LDS / global accesses in LDS order, thread = (block of 64 positions, SIMD lane j,
+// half) so that the reference's 8-wide partial sums are DPP sums over lane bits 0..2 — and run on 16 waves.
+// Then wave g < NH carries the tinyBLAS chains of head g exactly as attn_pv_kernel does — lane = (d, e), sequential over positions: 5.2 ns per
+// dependent step, 1000 steps at 8000 positions, the floor of this path — with nothing but the chain on its vector pipe: probabilities from LDS
+// (two ds_read_b128 per block of 64 positions, three blocks ahead), V^T from a register ring of BAMD_SPV_R blocks (requested R blocks = ~1 us
+// ahead of their turn: attn_pv_kernel's two sets of 8 were 64 steps ahead and every set waited out most of a memory latency) through buffer
+// loads whose block offset is an immediate (no address arithmetic; the descriptor's bound makes requests past the cache return 0).
+// The ring is first filled before the softmax passes.  Same values, same order as the two kernels it replaces (tests).
+#define BAMD_SPV_R 20
+#define BAMD_SPV_SLACK 1024                 /* bytes of LDS past the rows: the chain wave's look-ahead reads up to three blocks past the last one */
+#define BAMD_SPV_LDS_MAX (152 * 1024)
+template <int NH>
+__global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq, uint32_t vc_bytes) {
+    extern __shared__ __attribute__((aligned(16))) float spv_p[];          // [NH][n_ctx] (+ slack)
+    __shared__ float redf[NH][16];
+    __shared__ double redd[NH][16];
+    const bamd_step_state * st = a.st;
+    const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
+    const int hk = blockIdx.x, h0 = hk * gq + (int) blockIdx.z * NH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions and possibly half a block (attn_pv_kernel)
+    const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
+    const int d = blockIdx.y * 8 + (lane >> 3);
+    const bamd_rsrc vr = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) a.vc), 0, (int) vc_bytes, 0x00020000);
+    const uint32_t voff = (uint32_t) (((size_t) (hk * hd + d) * n_ctx + e * 8) * 2);
+    uint4 ring[BAMD_SPV_R];
+#define BAMD_SPV_VLOAD(blk_) ({ const u32x4_t t_ = __builtin_amdgcn_raw_buffer_load_b128(vr, (int) voff, (blk_) * 128, 0); make_uint4(t_.x, t_.y, t_.z, t_.w); })
+    if (wave < NH) {
+#pragma unroll
+        for (int u = 0; u < BAMD_SPV_R; ++u) ring[u] = BAMD_SPV_VLOAD(u);
+    }
+    // ---- softmax of the NH rows: ggml.c:13682-13778 + :2619-2671 (AVX2 branch), as attn_softmax_kernel.  Thread = (block B0 + 64 k, lane j of the
+    //      reference's 8-wide vector, half lh): the four floats at [64 B + 8 j + 4 lh ..] of a row = positions 64 B + 8 (4 lh + c) + j, c = 0..3 ----
+    const int B0 = tid >> 4, foff = (tid & 7) * 8 + ((tid >> 3) & 1) * 4, lh = (tid >> 3) & 1;
+#define BAMD_SPV_VALID(B_) ((B_) < nfull || ((B_) == nfull && half && lh == 0))
+    const float scale = a.kq_scale;
+    float mx[NH];
+#pragma unroll
+    for (int g = 0; g < NH; ++g) mx[g] = -INFINITY;
+    for (int B = B0; B <= last; B += 128) {                      // two blocks per thread and head requested together
+        float4 w[NH][2];
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int Bk = B + 64 * k;
+                w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
+            }
+#pragma unroll
+        for (int g = 0; g < NH; ++g)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int Bk = B + 64 * k;
+                if (BAMD_SPV_VALID(Bk)) {
+                    float4 v = w[g][k];
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    float m = mx[g];
+                    m = v.x > m ? v.x : m; m = v.y > m ? v.y : m; m = v.z > m ? v.z : m; m = v.w > m ? v.w : m;
+                    mx[g] = m;
+                    *(float4 *) (spv_p + g * n_ctx + Bk * 64 + foff) = v;
+                }
+            }
+    }
+#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 1
+    return;
+#endif
+#pragma unroll
+    for (int g = 0; g < NH; ++g) {
+        float m = mx[g];
+        for (int o = 32; o; o >>= 1) { const float om = __shfl_xor(m, o); m = om > m ? om : m; }
+        if (lane == 0) redf[g][wave] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NH; ++g) {
+        float m = redf[g][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = redf[g][w] > m ? redf[g][w] : m;
+        double sm = 0.0;
+        for (int B = B0; B <= last; B += 64) {                   // (8-lane groups j = 0..7 are all-valid or all-idle)
+            if (BAMD_SPV_VALID(B)) {
+                float4 * pp = (float4 *) (spv_p + g * n_ctx + B * 64 + foff);
+                float4 v = *pp;
+                v.x = v_expf(v.x - m); v.y = v_expf(v.y - m); v.z = v_expf(v.z - m); v.w = v_expf(v.w - m);
+                *pp = v;
+                // the reference's 8-wide partial sums (same tree shape), one per c: positions 64 B + 8 (4 lh + c) + 0..7
+                const float c0 = hsum8_tinyblas(v.x), c1 = hsum8_tinyblas(v.y), c2 = hsum8_tinyblas(v.z), c3 = hsum8_tinyblas(v.w);
+                if ((lane & 7) == 0) { sm += (double) c0; sm += (double) c1; sm += (double) c2; sm += (double) c3; }
+            }
+        }
+        sm = wave_sum_f64(sm);
+        if (lane == 0) redd[g][wave] = sm;
+    }
+    __syncthreads();
+#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 2
+    return;
+#endif
+#pragma unroll
+    for (int g = 0; g < NH; ++g) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += redd[g][w];
+        double rs = 1.0 / tot;
+        if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
+            __syncthreads();                                     // (the exponentials of the other threads; redd read by all)
+            if (tid == 0) redd[g][0] = seq_expsum8_vt(spv_p + g * n_ctx, n_kv);
+            __syncthreads();
+            rs = 1.0 / redd[g][0];
+            __syncthreads();
+        }
+        const float fs = (float) rs;
+        float * pr = a.probs + (size_t) (h0 + g) * n_ctx;
+        for (int B = B0; B <= last; B += 64) {
+            if (BAMD_SPV_VALID(B)) {
+                float4 * pp = (float4 *) (spv_p + g * n_ctx + B * 64 + foff);
+                float4 v = *pp;
+                v.x *= fs; v.y *= fs; v.z *= fs; v.w *= fs;
+                *pp = v;
+                if (blockIdx.y == 0) *(float4 *) (pr + B * 64 + foff) = v;      // the probability rows, once per head (bamd_op_attention hands them to the tests)
+            }
+        }
+    }
+    __syncthreads();
+#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 3
+    return;
+#endif
+#undef BAMD_SPV_VALID
+    if (wave >= NH) return;
+    // ---- P.V: lane = d_local*8 + e carries the chain Cv[e] of output (h0 + wave, d) — sgemm.cpp:405-431, attn_pv_kernel ----
+    const float * pw = spv_p + wave * n_ctx + e * 8;
+    float acc = 0.f;
+    // probabilities of a block: two ds_read_b128, issued three blocks ahead of their chain steps (four register slots; BAMD_SPV_R % 4 == 0 keeps
+    // slot = block & 3 across turns).  A scheduling barrier after every block: left alone, the scheduler hoists LDS reads and V^T requests across the
+    // whole unrolled turn until the register file overflows.
+    float4 pa[4], pb[4];
+#define BAMD_SPV_PREAD(slot_, blk_) do { pa[slot_] = *(const float4 *) (pw + (blk_) * 64); pb[slot_] = *(const float4 *) (pw + (blk_) * 64 + 4); } while (0)
+#define BAMD_SPV_STEPS(V_, u_, n_) do { \
+        const uint32_t w[4] = { V_[u_].x, V_[u_].y, V_[u_].z, V_[u_].w }; \
+        const float pv[8] = { pa[(u_) & 3].x, pa[(u_) & 3].y, pa[(u_) & 3].z, pa[(u_) & 3].w, pb[(u_) & 3].x, pb[(u_) & 3].y, pb[(u_) & 3].z, pb[(u_) & 3].w }; \
+        _Pragma("unroll") for (int k = 0; k < (n_); ++k) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); } while (0)
+    BAMD_SPV_PREAD(0, 0); BAMD_SPV_PREAD(1, 1); BAMD_SPV_PREAD(2, 2);
+    int base = 0;
+    for (; base + BAMD_SPV_R <= nfull; base += BAMD_SPV_R) {     // whole turns of the ring: full blocks only
+#pragma unroll
+        for (int u = 0; u < BAMD_SPV_R; ++u) {
+            BAMD_SPV_PREAD((u + 3) & 3, base + u + 3);
+            BAMD_SPV_STEPS(ring, u, 8);
+            ring[u] = BAMD_SPV_VLOAD(base + BAMD_SPV_R + u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < BAMD_SPV_R; ++u) {                       // what is left of the last turn (wave-uniform branches)
+        const int blk = base + u;
+        if (blk + 3 <= last) BAMD_SPV_PREAD((u + 3) & 3, blk + 3);
+        if (blk < nfull) BAMD_SPV_STEPS(ring, u, 8);
+        else if (blk == nfull && half) BAMD_SPV_STEPS(ring, u, 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef BAMD_SPV_PREAD
+#undef BAMD_SPV_VLOAD
+#undef BAMD_SPV_STEPS
+    const float v = hsum8_tinyblas(acc);
+    if (e == 0) a.out[(size_t) (h0 + wave) * hd + d] = v;
 }
 
 #include "bamd_attn_fused.h"
@@ -408,6 +591,17 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     return 0;
 }
 
+static const bool g_attn_spv = [] { const char * e = getenv("BAMD_ATTN_SPV"); return !(e && e[0] == '0'); }();
+// softmax + P.V in one launch when the probability rows of a workgroup fit in LDS; false = the caller launches attn_softmax_kernel + attn_pv_kernel
+template <int G> static bool spv_launch(const bamd_attn_args & a, hipStream_t s) {
+    constexpr int Z = (G & 1) ? 1 : 2, NH = G / Z;              // even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128)
+    if (NH != 1 && NH != 2 && NH != 4) return false;
+    const size_t lds = (size_t) NH * a.n_ctx * 4 + BAMD_SPV_SLACK, vcb = (size_t) a.Hkv * a.hd * a.n_ctx * 2;
+    if (!g_attn_spv || lds > BAMD_SPV_LDS_MAX || vcb > 0x7fffffffu) return false;
+    hipLaunchKernelGGL((attn_spv_kernel<(NH == 1 || NH == 2 || NH == 4) ? NH : 1>), dim3(a.Hkv, a.hd / 8, Z), dim3(1024), lds, s, a, G, (uint32_t) vcb);
+    return true;
+}
+
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq < 1 || gq > 8) return 1;
@@ -434,6 +628,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
             case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3, false>), g1, dim3(512), 0, s, a); break; \
             default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, false>), g1, dim3(512), 0, s, a); break; \
         } \
+        if (spv_launch<G>(a, s)) break; \
         hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
         if ((G & 1) == 0) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2)), 0, s, a, gq); /* even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128) */ \
         else hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \

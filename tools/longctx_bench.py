@@ -1,5 +1,5 @@
 """Decode rate at long context (BASELINE config 5 shape of the problem): 8B synthetic GGUF, n_ctx 8192, prompt of n tokens through the
-batched prefill, then greedy decode steps with n_kv ~ n (three-kernel attention path).  usage: longctx_bench.py [n_prompt=7936] (GPU box)"""
+batched prefill, then greedy decode steps with n_kv ~ n (three-kernel attention path).  usage: longctx_bench.py [n_prompt=7936] [n_ctx=8192] (GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 7936
 path = "/dev/shm/bamd_prefill_8b.gguf"
 if not os.path.exists(path):
     gguf.write_synthetic_llama(path, E=4096, H=32, Hkv=8, L=32, F=14336, V=128256, seed=7, reuse_layers=True)
-m = b.Model(path); ctx = b.Context(m, 8192)
+n_ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+m = b.Model(path); ctx = b.Context(m, n_ctx)
 toks = [(7919 * i + 13) % 128256 for i in range(n)]
 t0 = time.perf_counter()
 for i in range(0, n, 512):
