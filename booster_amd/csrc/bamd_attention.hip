@@ -229,11 +229,9 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
     __shared__ float redf[NH][16];
     __shared__ double redd[NH][16];
     const bamd_step_state * st = a.st;
-    const int n_kv = st->n_kv, n_ctx = a.n_ctx, hd = a.hd;
+    const int n_ctx = a.n_ctx, hd = a.hd;
     const int hk = blockIdx.x, h0 = hk * gq + (int) blockIdx.z * NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
-    // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions and possibly half a block (attn_pv_kernel)
-    const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
     const int d = blockIdx.y * 8 + (lane >> 3);
     const bamd_rsrc vr = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) a.vc), 0, (int) vc_bytes, 0x00020000);
     const uint32_t voff = (uint32_t) (((size_t) (hk * hd + d) * n_ctx + e * 8) * 2);
@@ -251,6 +249,21 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
     float mx[NH];
 #pragma unroll
     for (int g = 0; g < NH; ++g) mx[g] = -INFINITY;
+    // the first two blocks per thread and head are requested before n_kv is known (it arrives by a dependent load: st -> n_kv): any block of the row
+    // is readable memory, what lies past n_kv is masked below
+    const int nblk_row = n_ctx >> 6;
+    float4 w0[NH][2];
+#pragma unroll
+    for (int g = 0; g < NH; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int Bk = B0 + 64 * k;
+            w0[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (Bk < nblk_row) w0[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
+        }
+    const int n_kv = st->n_kv;
+    // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions and possibly half a block (attn_pv_kernel)
+    const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
     for (int B = B0; B <= last; B += 128) {                      // two blocks per thread and head requested together
         float4 w[NH][2];
 #pragma unroll
@@ -258,8 +271,11 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int Bk = B + 64 * k;
-                w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
+                w[g][k] = w0[g][k];
+                if (B != B0) {
+                    w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
+                }
             }
 #pragma unroll
         for (int g = 0; g < NH; ++g)
@@ -276,9 +292,6 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
                 }
             }
     }
-#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 1
-    return;
-#endif
 #pragma unroll
     for (int g = 0; g < NH; ++g) {
         float m = mx[g];
@@ -307,9 +320,6 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
         if (lane == 0) redd[g][wave] = sm;
     }
     __syncthreads();
-#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 2
-    return;
-#endif
 #pragma unroll
     for (int g = 0; g < NH; ++g) {
         double tot = 0.0;
@@ -336,9 +346,6 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
         }
     }
     __syncthreads();
-#if defined(BAMD_SPV_EXIT) && BAMD_SPV_EXIT == 3
-    return;
-#endif
 #undef BAMD_SPV_VALID
     if (wave >= NH) return;
     // ---- P.V: lane = d_local*8 + e carries the chain Cv[e] of output (h0 + wave, d) — sgemm.cpp:405-431, attn_pv_kernel ----
@@ -593,15 +600,19 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
 
 static const bool g_attn_spv = [] { const char * e = getenv("BAMD_ATTN_SPV"); return !(e && e[0] == '0'); }();
 // softmax + P.V in one launch when the probability rows of a workgroup fit in LDS; false = the caller launches attn_softmax_kernel + attn_pv_kernel
-template <int G> static bool spv_launch(const bamd_attn_args & a, hipStream_t s) {
+template <int G> static bool spv_ok(const bamd_attn_args & a) {
     constexpr int Z = (G & 1) ? 1 : 2, NH = G / Z;              // even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128)
     if (NH != 1 && NH != 2 && NH != 4) return false;
     const size_t lds = (size_t) NH * a.n_ctx * 4 + BAMD_SPV_SLACK, vcb = (size_t) a.Hkv * a.hd * a.n_ctx * 2;
-    if (!g_attn_spv || lds > BAMD_SPV_LDS_MAX || vcb > 0x7fffffffu) return false;
+    return g_attn_spv && lds <= BAMD_SPV_LDS_MAX && vcb <= 0x7fffffffu;
+}
+template <int G> static bool spv_launch(const bamd_attn_args & a, hipStream_t s) {
+    constexpr int Z = (G & 1) ? 1 : 2, NH = G / Z;
+    if (!spv_ok<G>(a)) return false;
+    const size_t lds = (size_t) NH * a.n_ctx * 4 + BAMD_SPV_SLACK, vcb = (size_t) a.Hkv * a.hd * a.n_ctx * 2;
     hipLaunchKernelGGL((attn_spv_kernel<(NH == 1 || NH == 2 || NH == 4) ? NH : 1>), dim3(a.Hkv, a.hd / 8, Z), dim3(1024), lds, s, a, G, (uint32_t) vcb);
     return true;
 }
-
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq < 1 || gq > 8) return 1;

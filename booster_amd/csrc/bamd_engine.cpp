@@ -439,7 +439,8 @@ static int attn_lds_ld(const bamd_context * c, int pos_hi) { return std::min((po
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
     bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
-    const int tiles = std::min(std::max(c->n_ctx / 64, 1), 32);
+    static const int qk_tiles = [] { const char * e = getenv("BAMD_QK_TILES"); return e ? atoi(e) : 64; }();   // score-kernel workgroups per KV head: 64 = two per CU at Hkv = 8 (16 waves per CU: 2.066 -> 2.038 ms/token at 8000 positions; 128: 2.13)
+    const int tiles = std::min(std::max(c->n_ctx / 64, 1), qk_tiles);
     for (size_t il = 0; il < m->layers.size(); ++il) {
         const DevLayer & ly = m->layers[il];
         bamd_mv_args a; memset(&a, 0, sizeof a);
@@ -1300,7 +1301,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     a.probs = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
     if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.probs || !a.out) return fail("device alloc/copy failed");
     a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx_pad; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;
-    { const int tiles = std::min(std::max(n_ctx / 64, 1), 32);
+    { const int tiles = std::min(std::max(n_ctx / 64, 1), 64);
       if (bamd_launch_attention(a, H / Hkv, split_path ? -tiles : tiles, nullptr)) return fail("unsupported head configuration"); }
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
