@@ -174,7 +174,14 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 //     super-block ahead), transposes them into the MFMA A layout through a private, padded LDS tile, and lanes 0..15 unpack the
 //     16 row headers ONCE (d, dmin, scales, mins as i16 pairs) into LDS for the other lanes;
 //   - 8 (e) x 2 (token tiles) MFMAs; chains, min terms (v_dot2_i32_i16) and the final trees on the VALU.
+#ifndef BAMD_MMA_NT
 #define BAMD_MMA_NT 2
+#endif
+#if BAMD_MMA_NT == 1
+#define BAMD_MMA_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define BAMD_MMA_OCC
+#endif
 #ifndef BAMD_MMA_NTLOADS
 #define BAMD_MMA_NTLOADS 0                                                       /* weight loads of the MFMA kernels: default cache policy — the 16 token tiles of a row block re-read
                                                                                     the same records through L2 (nt: 246 vs 253 TFLOP/s at 512 tokens) */
@@ -195,7 +202,7 @@ template <typename T> __device__ __forceinline__ T ldw(const uint8_t * rec, uint
 // and the product takes one more packed instruction; the min terms follow ggml_vec_dot_q5_K_q8_K: ONE float per row,
 // summs = summs + dmin * (float) sum_j m_j S_j (multiply, then add: ggml-quants.c:7515-7518), added after the hsum tree.
 template <int EPI, bool Q5>
-__global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
+__global__ void __launch_bounds__(512) BAMD_MMA_OCC matmul_mfma_q4k_kernel(bamd_mma_args a) {
     constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K, HDRO = Q5 ? 1280u : 1024u;      // bamd_record_bytes; header {d|dmin, sc[0..3], sc[4..7], mn[0..3]} + mn[4..7] at HDRO + 128
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -216,18 +223,18 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
     // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
     // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
-    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q;
+    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q, second = BAMD_MMA_TOK * BAMD_B16_Q >= 1024 || tid + 512 < BAMD_MMA_TOK * BAMD_B16_Q;
     auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
         const int tok = idx / BAMD_B16_Q, q = idx - tok * BAMD_B16_Q;
         const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
         return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
-    const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
+    const uint32_t ssrc0 = stage_src(tid), ssrc1 = second ? stage_src(tid + 512) : stage_src(tid), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
     uint32_t ysrc;
     { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
 #define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
         unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
-        lds_dma16(sb_ + ssrc0, st_); lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
+        lds_dma16(sb_ + ssrc0, st_); if (second) lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
         if (third) lds_dma16(sb_ + ssrc2, st_ + 1024 * 16); \
         if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
             lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
@@ -332,6 +339,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
             const _Float16 s_lo = (_Float16) (float) (scw & 0xffu), s_hi = (_Float16) (float) ((scw >> 8) & 0xffu);
             const h2_t slo2 = { s_lo, s_lo }, shi2 = { s_hi, s_hi };
             const h2_t nlo2 = { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo }, nhi2 = { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi };
+            const h2_t shi16 = { (_Float16) 0.0625f * s_hi, (_Float16) 0.0625f * s_hi }, nhi16 = { (_Float16) -64.f * s_hi, (_Float16) -64.f * s_hi };
             const uint32_t * wrow = wl + (m >> 3) * 288 + (m & 7) * 36 + g;
             // software pipeline over e, written out: the LDS operands of e + 2 are requested at the top of iteration e and the MFMA results
             // of e - 1 are folded into the chains in iteration e; a scheduling barrier per iteration keeps that order (left alone, the
@@ -353,7 +361,8 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                     for (int n = 0; n < BAMD_MMA_NT; ++n) Bq[(e + 2) % 3][n] = BAMD_LDB(e + 2, n);
                 }
                 const uint32_t wq = Wq[e % 3];
-                uint32_t lo = wq & 0x0f0f0f0fu, hi = (wq >> 4) & 0x0f0f0f0fu;
+                // Q4_K: the high nibbles stay where they are (16 n in the f16 image: the scale operand below is s / 16, exact) — one shift less per e
+                uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;
                 if (Q5) {                                    // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
                     const uint32_t qh = qht[(m >> 3) * 72 + (m & 7) * 9 + e];
                     lo |= ((qh >> (2 * g)) & 0x01010101u) << 4; hi |= ((qh >> (2 * g + 1)) & 0x01010101u) << 4;
@@ -367,7 +376,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
                     a0 = (c0.h - k1024) * slo2; a1 = (c1.h - k1024) * slo2; a2 = (c2.h - k1024) * shi2; a3 = (c3.h - k1024) * shi2;
                 } else {
                     a0 = __builtin_elementwise_fma(c0.h, slo2, nlo2); a1 = __builtin_elementwise_fma(c1.h, slo2, nlo2);
-                    a2 = __builtin_elementwise_fma(c2.h, shi2, nhi2); a3 = __builtin_elementwise_fma(c3.h, shi2, nhi2);
+                    a2 = __builtin_elementwise_fma(c2.h, shi16, nhi16); a3 = __builtin_elementwise_fma(c3.h, shi16, nhi16);   // (1024 + 16 n) s/16 - 64 s = n s
                 }
                 const bamd_h8 av = { a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y };
                 bamd_f4 si[BAMD_MMA_NT];
@@ -447,14 +456,16 @@ __global__ void __launch_bounds__(512) matmul_mfma_q4k_kernel(bamd_mma_args a) {
     }
 }
 // ---- Q6_K x Q8_K on the matrix cores, exact: same skeleton as matmul_mfma_q4k_kernel -----------------------------------------
-// scale (int8) x (q6 - 32) reaches 4096 in magnitude: not every such integer is an f16.  With u = q6 in [0, 63]:
-//   q6 - 32 = 2 (u >> 1) - 32 + (u & 1) = 2 vh + vl,  vh = (u >> 1) - 16 in [-16, 15],  vl = u & 1,
-// so A_h = scale * vh (|.| <= 2048) and A_l = scale * vl (|.| <= 128) are exact f16, TWO MFMAs per e give S_h, S_l (< 2^24), and
-// isum = 2 S_h + S_l (< 2^24) is exact as fmaf(2, S_h, S_l).  Scales are per 16 elements: for SIMD lane e the sub-block c uses
-// scales[2c + (e >= 4)] (ggml-quants.c:8145-8216); no min terms.  Wave-stream Q6_K record: bamd_formats.h.
+// scale (int8) x (q6 - 32) reaches 4096 in magnitude: not every such integer is an f16.  The SCALE is split, sc = 16 s_h + s_l with
+// s_l = sc & 15 in [0, 15] and s_h = sc >> 4 in [-8, 7]: A_1 = s_h * v (|.| <= 256) and A_2 = s_l * v (<= 480), v = q6 - 32, are exact f16,
+// TWO MFMAs per e give S_1, S_2 (< 2^24), and isum = 16 S_1 + S_2 (|isum| <= 32 x 128 x 32 x 127 < 2^24) is exact as fmaf(16, S_1, S_2).
+// Both fragments come from ONE f16 image of the quants, c = 1024 + q6 (byte permute), as fma(c, s, -1056 s) = (q6 - 32) s: the products and the
+// constants 1056 s are exact, the fma rounds once and its result is representable.  (The first form split the VALUE, q6 - 32 = 2 vh + vl: a
+// second f16 image for the low bit and 50 instead of 32 vector instructions per e.)  Scales are per 16 elements: for SIMD lane e the sub-block c
+// uses scales[2c + (e >= 4)] (ggml-quants.c:8145-8216); no min terms.  Wave-stream Q6_K record: bamd_formats.h.
 #define BAMD_MMA6_WAVE_LDS ((2 * 288 + 2 * 144 + 16 * 8) * 4)                    /* ql tile + qh tile + row headers */
 template <int EPI>
-__global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
+__global__ void __launch_bounds__(512) BAMD_MMA_OCC matmul_mfma_q6k_kernel(bamd_mma_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -473,19 +484,19 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
     // copies of super-block ci+1 are issued at the top of iteration ci into the buffer every wave left at the previous barrier, and
     // the barrier at the end of the iteration (vmcnt(0) inside) publishes them.  (An indexed register array as the staging buffer is
     // placed in scratch memory by the compiler, with a full s_waitcnt after every load: +20 % kernel time.)
-    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q;
+    const bool third = tid + 1024 < BAMD_MMA_TOK * BAMD_B16_Q, second = BAMD_MMA_TOK * BAMD_B16_Q >= 1024 || tid + 512 < BAMD_MMA_TOK * BAMD_B16_Q;
     auto stage_src = [&](int idx) {                           // 32-bit byte offsets into the blob (T <= 512 tokens: a few MB)
         const int tok = idx / BAMD_B16_Q, q = idx - tok * BAMD_B16_Q;
         const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1;
         return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16);
     };
-    const uint32_t ssrc0 = stage_src(tid), ssrc1 = stage_src(tid + 512), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
+    const uint32_t ssrc0 = stage_src(tid), ssrc1 = second ? stage_src(tid + 512) : stage_src(tid), ssrc2 = third ? stage_src(tid + 1024) : ssrc1;
     uint32_t ysrc;
     { const int tk = tid & (BAMD_MMA_TOK - 1); const int tg = t0 + tk < a.T ? t0 + tk : a.T - 1; ysrc = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
 #undef BAMD_STAGE_ISSUE
 #define BAMD_STAGE_ISSUE(ci_, buf_) do { const uint8_t * sb_ = a.blob16 + (size_t) (ci_) * BAMD_B16_REC; \
         unsigned char * st_ = stage + (size_t) (buf_) * BAMD_MMA_STAGE + (size_t) (wave * 64) * 16; \
-        lds_dma16(sb_ + ssrc0, st_); lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
+        lds_dma16(sb_ + ssrc0, st_); if (second) lds_dma16(sb_ + ssrc1, st_ + 512 * 16); \
         if (third) lds_dma16(sb_ + ssrc2, st_ + 1024 * 16); \
         if (tid < BAMD_MMA_TOK)                       /* the 32 block scales d_y: 4 bytes per lane, lanes 0..31 of wave 0 */ \
             lds_dma4(a.blob16 + ysrc + (size_t) (ci_) * 4, stage + (size_t) (buf_) * BAMD_MMA_STAGE + BAMD_MMA_TOK * BAMD_B16_REC); } while (0)
@@ -536,16 +547,17 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
             }
         }
         {
-            // int8 scales of sub-blocks c = 2g, 2g+1 for the two e-halves: header byte hi*8 + c
-            h2_t sA[2], sB[2];
+            // int8 scales of sub-blocks c = 2g, 2g+1 for the two e-halves (header byte hi*8 + c), split 16 s_h + s_l; with each the constant -1056 s
+            h2_t sAh[2], sAl[2], sBh[2], sBl[2], nAh[2], nAl[2], nBh[2], nBl[2];
+            const h2_t k1056 = { (_Float16) -1056.f, (_Float16) -1056.f };
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi) {
                 const uint32_t w = hl[m * 8 + hi * 2 + (g >> 1)] >> (16 * (g & 1));
-                const _Float16 s0 = (_Float16) (float) (int) (int8_t) (w & 0xffu), s1 = (_Float16) (float) (int) (int8_t) ((w >> 8) & 0xffu);
-                sA[hi] = (h2_t) { s0, s0 }; sB[hi] = (h2_t) { s1, s1 };
+                const int s0 = (int) (int8_t) (w & 0xffu), s1 = (int) (int8_t) ((w >> 8) & 0xffu);
+                const _Float16 s0h = (_Float16) (float) (s0 >> 4), s0l = (_Float16) (float) (s0 & 15), s1h = (_Float16) (float) (s1 >> 4), s1l = (_Float16) (float) (s1 & 15);
+                sAh[hi] = (h2_t) { s0h, s0h }; sAl[hi] = (h2_t) { s0l, s0l }; sBh[hi] = (h2_t) { s1h, s1h }; sBl[hi] = (h2_t) { s1l, s1l };
+                nAh[hi] = k1056 * sAh[hi]; nAl[hi] = k1056 * sAl[hi]; nBh[hi] = k1056 * sBh[hi]; nBl[hi] = k1056 * sBl[hi];
             }
-            const h2_t k1040 = { (_Float16) 1040.f, (_Float16) 1040.f };
-            const us2_t one16 = { 0x3c00, 0x3c00 };
             const int sh = 4 * (g & 1);
             const uint32_t * wq = wl + (m >> 3) * 288 + (m & 7) * 36 + 2 * (g >> 1);
             const uint32_t * hq = ql2 + (m >> 3) * 144 + (m & 7) * 18 + (g >> 1);
@@ -553,18 +565,18 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
             for (int e = 0; e < 8; ++e) {
                 const uint2 ab = *(const uint2 *) (wq + e * 4);
                 const uint32_t h = hq[e * 2];
-                const uint32_t uA = ((ab.x >> sh) & 0x0f0f0f0fu) | (((h >> sh) & 0x03030303u) << 4);          // q6 of sub-block 2g, chunk e
-                const uint32_t uB = ((ab.y >> sh) & 0x0f0f0f0fu) | (((h >> (sh + 2)) & 0x03030303u) << 4);    // sub-block 2g + 1
-                const uint32_t hA = (uA >> 1) & 0x1f1f1f1fu, hB = (uB >> 1) & 0x1f1f1f1fu, lA = uA & 0x01010101u, lB = uB & 0x01010101u;
-                const h2_t sa = sA[e >> 2], sb = sB[e >> 2];
-                union { uint32_t u; h2_t h; us2_t s; } c0, c1, c2, c3, d0, d1, d2, d3;
-                c0.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, hA, 0x04030402u);
-                c2.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hB, 0x04030402u);
-                d0.u = __builtin_amdgcn_perm(0u, lA, 0x0c010c00u); d1.u = __builtin_amdgcn_perm(0u, lA, 0x0c030c02u);   // 0 / 1 as u16 pairs
-                d2.u = __builtin_amdgcn_perm(0u, lB, 0x0c010c00u); d3.u = __builtin_amdgcn_perm(0u, lB, 0x0c030c02u);
-                d0.s = d0.s * one16; d1.s = d1.s * one16; d2.s = d2.s * one16; d3.s = d3.s * one16;                       // -> f16 0.0 / 1.0
-                const h2_t ah0 = (c0.h - k1040) * sa, ah1 = (c1.h - k1040) * sa, ah2 = (c2.h - k1040) * sb, ah3 = (c3.h - k1040) * sb;   // exact, |.| <= 2048
-                const h2_t al0 = d0.h * sa, al1 = d1.h * sa, al2 = d2.h * sb, al3 = d3.h * sb;
+                // the two high bits of a quant sit at bits sh, sh + 1 (sub-block 2g) / sh + 2, sh + 3 (2g + 1) of their byte of h and belong at bits 4, 5:
+                // a ROTATION of the dword by 4 - sh / 2 - sh (what wraps around lands outside the mask 0x30 of every byte), then one and-or
+                const uint32_t uA = (__builtin_amdgcn_alignbit(h, h, (uint32_t) (28 + sh) & 31u) & 0x30303030u) | ((ab.x >> sh) & 0x0f0f0f0fu);      // q6 of sub-block 2g, chunk e
+                const uint32_t uB = (__builtin_amdgcn_alignbit(h, h, (uint32_t) (30 + sh) & 31u) & 0x30303030u) | ((ab.y >> sh) & 0x0f0f0f0fu);      // sub-block 2g + 1
+                union { uint32_t u; h2_t h; } c0, c1, c2, c3;
+                c0.u = __builtin_amdgcn_perm(0x64646464u, uA, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, uA, 0x04030402u);   // 1024 + q6
+                c2.u = __builtin_amdgcn_perm(0x64646464u, uB, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, uB, 0x04030402u);
+                const int eh = e >> 2;
+                const h2_t ah0 = __builtin_elementwise_fma(c0.h, sAh[eh], nAh[eh]), ah1 = __builtin_elementwise_fma(c1.h, sAh[eh], nAh[eh]);
+                const h2_t ah2 = __builtin_elementwise_fma(c2.h, sBh[eh], nBh[eh]), ah3 = __builtin_elementwise_fma(c3.h, sBh[eh], nBh[eh]);
+                const h2_t al0 = __builtin_elementwise_fma(c0.h, sAl[eh], nAl[eh]), al1 = __builtin_elementwise_fma(c1.h, sAl[eh], nAl[eh]);
+                const h2_t al2 = __builtin_elementwise_fma(c2.h, sBl[eh], nBl[eh]), al3 = __builtin_elementwise_fma(c3.h, sBl[eh], nBl[eh]);
                 const bamd_h8 avh = { ah0.x, ah0.y, ah1.x, ah1.y, ah2.x, ah2.y, ah3.x, ah3.y };
                 const bamd_h8 avl = { al0.x, al0.y, al1.x, al1.y, al2.x, al2.y, al3.x, al3.y };
 #pragma unroll
@@ -574,7 +586,7 @@ __global__ void __launch_bounds__(512) matmul_mfma_q6k_kernel(bamd_mma_args a) {
                     const bamd_f4 sh_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bv, z, 0, 0, 0);
                     const bamd_f4 sl_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bv, z, 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], fmaf(2.0f, sh_[i], sl_[i]), acc[n][e][i]);
+                    for (int i = 0; i < 4; ++i) acc[n][e][i] = fmaf(D[n][i], fmaf(16.0f, sh_[i], sl_[i]), acc[n][e][i]);
                 }
             }
         }
