@@ -149,6 +149,9 @@ __device__ __forceinline__ double wave_sum_f64(double s) {                  // f
 // at most 2 n + 8 units of D: safe iff |D - 2^28| > 2 n + 8 (and the value is in the f32 normal range; anything else takes the slow path).
 #define BAMD_F64_GUARD_ULPS(n) (2 * (n) + 8)
 __device__ __forceinline__ bool f32_rounding_safe(double v, int ulps) {
+#ifdef BAMD_NO_F64_GUARD                                                     /* experiment builds: shows that the constructed worst cases of tests/test_f64_order.py need the guard */
+    return true;
+#endif
     if (v == 0.0) return true;                                              // the same in any order (non-negative terms)
     const uint32_t hi = (uint32_t) __double2hiint(v), lo = (uint32_t) __double2loint(v);
     const uint32_t ex = (hi >> 20) & 0x7ffu;                                // sign bit is 0: sums of squares / of exponentials
