@@ -249,33 +249,18 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
     float mx[NH];
 #pragma unroll
     for (int g = 0; g < NH; ++g) mx[g] = -INFINITY;
-    // the first two blocks per thread and head are requested before n_kv is known (it arrives by a dependent load: st -> n_kv): any block of the row
-    // is readable memory, what lies past n_kv is masked below
-    const int nblk_row = n_ctx >> 6;
-    float4 w0[NH][2];
-#pragma unroll
-    for (int g = 0; g < NH; ++g)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int Bk = B0 + 64 * k;
-            w0[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            if (Bk < nblk_row) w0[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
-        }
     const int n_kv = st->n_kv;
     // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions and possibly half a block (attn_pv_kernel)
     const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
-    for (int B = B0; B <= last; B += 128) {                      // two blocks per thread and head requested together
+    for (int B = B0; B <= last; B += 128) {                      // two blocks per thread and head requested together (one latency, not four)
         float4 w[NH][2];
 #pragma unroll
         for (int g = 0; g < NH; ++g)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int Bk = B + 64 * k;
-                w[g][k] = w0[g][k];
-                if (B != B0) {
-                    w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
-                }
+                w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
             }
 #pragma unroll
         for (int g = 0; g < NH; ++g)
@@ -359,7 +344,7 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
 #define BAMD_SPV_STEPS(V_, u_, n_) do { \
         const uint32_t w[4] = { V_[u_].x, V_[u_].y, V_[u_].z, V_[u_].w }; \
         const float pv[8] = { pa[(u_) & 3].x, pa[(u_) & 3].y, pa[(u_) & 3].z, pa[(u_) & 3].w, pb[(u_) & 3].x, pb[(u_) & 3].y, pb[(u_) & 3].z, pb[(u_) & 3].w }; \
-        _Pragma("unroll") for (int k = 0; k < (n_); ++k) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); } while (0)
+        acc = fma_mix_chain<n_>(acc, w, pv); } while (0)
     BAMD_SPV_PREAD(0, 0); BAMD_SPV_PREAD(1, 1); BAMD_SPV_PREAD(2, 2);
     int base = 0;
     for (; base + BAMD_SPV_R <= nfull; base += BAMD_SPV_R) {     // whole turns of the ring: full blocks only

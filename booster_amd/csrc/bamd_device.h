@@ -746,6 +746,31 @@ __device__ __forceinline__ void fma_mix8(float (&a4)[4], const uint32_t (&k)[4],
         : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3])
         : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
 }
+// N (4 or 8) steps of ONE sequential chain acc = fmaf((float) v_u, p_u, acc) over the halves of w (element u = low / high half of word u >> 1): the
+// tinyBLAS P.V step.  Inline asm because hipcc puts an s_nop behind every dependent v_fma_mix_f32 whose f16 operand is selected by op_sel_hi (it
+// takes that modifier bit for a write to the high half of the destination); a dependent vector instruction issues ~12 clocks after its producer
+// on this chip anyway, and chains of 4096 such steps give the same bits with and without the wait state (tools/chain_probe.hip).
+template <int N>
+__device__ __forceinline__ float fma_mix_chain(float acc, const uint32_t (&w)[4], const float (&p)[8]) {
+    static_assert(N == 4 || N == 8, "half a block or a block");
+    if (N == 4)
+        asm("v_fma_mix_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %1, %4, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "+v"(acc) : "v"(w[0]), "v"(w[1]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+    else                                                       // one block: a single wait for its operands in front of it
+        asm("v_fma_mix_f32 %0, %1, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %1, %6, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, %7, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, %8, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %3, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %3, %10, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %4, %11, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %4, %12, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "+v"(acc) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+    return acc;
+}
 // dot of up to 32 steps for lane e: k8 = this lane's L halves of the K row (L <= 32), q = this lane's L floats / halves
 template <bool PREFILL>
 __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const float * qf, const unsigned short * qh) {

@@ -174,7 +174,7 @@ __device__ __forceinline__ void unpack_k4_(uint32_t u0, uint32_t u1, uint32_t u2
 //     super-block ahead), transposes them into the MFMA A layout through a private, padded LDS tile, and lanes 0..15 unpack the
 //     16 row headers ONCE (d, dmin, scales, mins as i16 pairs) into LDS for the other lanes;
 //   - 8 (e) x 2 (token tiles) MFMAs; chains, min terms (v_dot2_i32_i16) and the final trees on the VALU.
-#ifndef BAMD_MMA_NT
+#ifndef BAMD_MMA_NT                                  /* -DBAMD_MMA_NT=1: one 16-token tile per wave at <= 128 VGPRs, two workgroups per CU — the occupancy experiment of DESIGN 7b */
 #define BAMD_MMA_NT 2
 #endif
 #if BAMD_MMA_NT == 1

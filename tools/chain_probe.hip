@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #define N_STEPS (1 << 20)
 template <int MODE>
 __global__ void __launch_bounds__(512) chain(float * out, const uint32_t * in, int n) {
@@ -66,6 +67,18 @@ int main() {
         if (t == 64) { run<0>("v_fma_f32 dependent", 64, out, in); run<1>("v_fma_mix_f32 dependent", 64, out, in); run<3>("v_fma_mix_f32 + s_nop", 64, out, in); run<2>("v_fma_f32 two chains (per pair/2)", 64, out, in); }
         if (t == 256) { run<0>("v_fma_f32 dependent", 256, out, in); run<1>("v_fma_mix_f32 dependent", 256, out, in); }
         if (t == 512) { run<0>("v_fma_f32 dependent", 512, out, in); run<1>("v_fma_mix_f32 dependent", 512, out, in); }
+    }
+    {   // does a dependent v_fma_mix_f32 need the wait state hipcc puts behind it?  The same chains with and without s_nop, on random operands
+        uint32_t hr[256]; uint32_t sd = 99u;
+        for (int i = 0; i < 192; ++i) { sd = sd * 1664525u + 1013904223u; const uint32_t a = 0x3000u + ((sd >> 8) & 0x0fffu), b = 0xb000u + ((sd >> 20) & 0x0fffu); hr[i] = a | (b << 16); }
+        hr[192] = 0x3f7f0000u; hr[193] = 0xbf7e8000u;
+        hipMemcpy(in, hr, sizeof hr, hipMemcpyHostToDevice);
+        static float o1[64], o3[64];
+        hipLaunchKernelGGL(chain<1>, dim3(1), dim3(64), 0, 0, out, in, 4096); hipMemcpy(o1, out, sizeof o1, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(chain<3>, dim3(1), dim3(64), 0, 0, out, in, 4096); hipMemcpy(o3, out, sizeof o3, hipMemcpyDeviceToHost);
+        int diff = 0; for (int i = 0; i < 64; ++i) diff += memcmp(&o1[i], &o3[i], 4) != 0;
+        printf("dependent v_fma_mix_f32 chains of 4096 steps, with vs without s_nop: %d of 64 lanes differ (lane 0: %g %g)\n", diff, o1[0], o3[0]);
+        hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
     }
     long long * cl; hipMalloc(&cl, 64); long long hc[3];
     for (int n : { 1 << 12, 1 << 16, 1 << 20 }) {
