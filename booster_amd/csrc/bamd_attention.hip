@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(512) attn_pv_kernel(bamd_attn_args a, int gq) 
 #define BAMD_PV_STEPS(V_, PA_, PB_, u_, n_) do { \
         const uint32_t w[4] = { V_[u_].x, V_[u_].y, V_[u_].z, V_[u_].w }; \
         const float pv[8] = { PA_[u_].x, PA_[u_].y, PA_[u_].z, PA_[u_].w, PB_[u_].x, PB_[u_].y, PB_[u_].z, PB_[u_].w }; \
-        _Pragma("unroll") for (int k = 0; k < (n_); ++k) acc = fmaf(h2f((w[k >> 1] >> (16 * (k & 1))) & 0xffffu), pv[k], acc); } while (0)
+        acc = fma_mix_chain<n_>(acc, w, pv); } while (0)
 #define BAMD_PV_CHAIN(V_, PA_, PB_) do { _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) BAMD_PV_STEPS(V_, PA_, PB_, u, 8); } while (0)
 #define BAMD_PV_TAIL(V_, PA_, PB_) do { \
         _Pragma("unroll") for (int u = 0; u < BAMD_PV_U; ++u) { \

@@ -159,9 +159,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
             const uint32_t keep = (pl & 1) ? 0x0000ffffu : 0xffff0000u, ins = (pl & 1) ? (uint32_t) vcur[dd_] << 16 : (uint32_t) vcur[dd_]; \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) if (j == (pl >> 1)) w[j] = (w[j] & keep) | ins; \
         } \
-        float acc = acc4[dd_]; \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), pv[u], acc); \
-        acc4[dd_] = acc; \
+        acc4[dd_] = fma_mix_chain<8>(acc4[dd_], w, pv); \
     } while (0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {                                  // blocks whose V chunks were requested at kernel entry

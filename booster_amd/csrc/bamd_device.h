@@ -782,8 +782,7 @@ __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const flo
                 const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
                 const float4 qa = *(const float4 *) (qf + g * 8), qb = *(const float4 *) (qf + g * 8 + 4);
                 const float qv[8] = { qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w };
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = fmaf(h2f((w[u >> 1] >> (16 * (u & 1))) & 0xffffu), qv[u], acc);
+                acc = fma_mix_chain<8>(acc, w, qv);              // acc = fmaf((float) k_u, q_u, acc), u = 0..7 (hipcc: a v_cvt_f32_f16 per step beside the fma)
             }
         }
         return acc;
