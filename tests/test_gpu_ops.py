@@ -207,6 +207,27 @@ def test_mul_mat_batch(bamd, po, t, K, rows, T, impl):
         assert_bits(got[i], want, "mul_mat_batch type %d K %d T %d impl %d token %d" % (t, K, T, impl, i))
 
 
+def test_attention_long_context_eight_heads_per_kv_head(bamd, po):
+    """the 70B head layout at a long context: gq = 8 -> four query heads per workgroup of the softmax + P.V launch (128 KB of probability rows in
+    LDS at n_ctx 8192), the V^T ring over 125 blocks, a half block at the end (n_kv % 64 == 32)"""
+    H, Hkv, hd, n_ctx = 8, 1, 128, 8192
+    rng = np.random.default_rng(808)
+    Ekv = Hkv * hd
+    kc = (rng.standard_normal(n_ctx * Ekv) * 0.7).astype(np.float16).view(np.uint16).copy()
+    vc = rng.standard_normal(Ekv * n_ctx).astype(np.float16).view(np.uint16).copy()
+    for pos in (7999, 8170):
+        q = (rng.standard_normal(H * hd) * 2).astype(np.float32)
+        k = rng.standard_normal(Ekv).astype(np.float32)
+        v = rng.standard_normal(Ekv).astype(np.float32)
+        rope = po.rope_cache(pos, hd, 500000.0)
+        kc2, vc2 = kc.copy(), vc.copy()
+        want, wprobs = oracle_attention(po, q, k, v, kc2, vc2, rope, H, Hkv, hd, n_ctx, pos, False)
+        got, gprobs = bamd.op_attention(q, k, v, kc, vc, rope, H, Hkv, hd, n_ctx, pos, prefill_mode=False, want_probs=True)
+        assert_bits(gprobs[:wprobs.size], wprobs, "softmax pos %d" % pos)
+        assert np.array_equal(kc, kc2) and np.array_equal(vc, vc2), "KV store differs at pos %d" % pos
+        assert_bits(got, want, "attention out pos %d" % pos)
+
+
 @pytest.mark.parametrize("prefill", [False, True])
 def test_attention_long_context(bamd, po, prefill):
     """the three-kernel path at real long-context sizes: many 64-position tiles per workgroup, the softmax kernel both with its
