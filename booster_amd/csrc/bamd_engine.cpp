@@ -134,6 +134,7 @@ struct bamd_context {
     hipGraphExec_t graph = nullptr; int graph_fused = -1;
     unsigned long long * co_gran = nullptr;   // co-launch granules [H * hd] {value, tag} + give-up counter behind them (bamd_colaunch.hip), zero-initialised
     uint32_t * co_err = nullptr;
+    int32_t * slots = nullptr; int slots_cap = 0;   // device-side greedy loop after a context shift: {cell, padded KV length} of every step (bamd_generate_greedy)
     int host_serial = 0;             // host calls that set the device state so far (bamd_step_state.serial)
     // KV cell metadata (llama_kv_cache cells: pos / delta / head / used, llama.cpp:2700-2760) — inactive (cell i holds position i, nothing to
     // track) until the first bamd_kv_seq_rm / bamd_kv_seq_add
@@ -508,9 +509,10 @@ static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
     bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_ARGMAX, m->n_cu, s);
     if (tm) tm->end(s);
 }
-static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStream_t s) {
+static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStream_t s, bool with_slots = false) {
     bamd_model * m = c->m;
-    bamd_launch_step_begin(c->st, c->forced, n_forced, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, do_embed, s);
+    bamd_launch_step_begin(c->st, c->forced, n_forced, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, do_embed, s,
+                           with_slots ? c->slots : nullptr, with_slots ? c->cellpos : nullptr);
 }
 
 static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_key) {
@@ -921,7 +923,7 @@ static int build_graph(bamd_context * c, int pos_hi) {
     hipStream_t s = c->stream;
     hipGraph_t g = nullptr;
     HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    enqueue_begin(c, 0, 1, s);
+    enqueue_begin(c, 0, 1, s, c->cells.active);
     int rc = enqueue_layers(c, 0, s, nullptr, pos_hi);
     enqueue_lm_head(c, s, nullptr);
     hipError_t e = hipStreamEndCapture(s, &g);
@@ -937,13 +939,31 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) return fail("bamd_generate_greedy needs a stage that owns embedding and output");
     if (n_steps < 1 || n_past < 1 || n_past + n_steps > c->n_ctx || n_steps + 1 > c->out_cap) return fail("bad n_past / n_steps");
-    if (c->cells.active) return fail("after a context shift (bamd_kv_seq_add) use bamd_decode per token: the device-side loop assumes cell = position");
-    c->n_cached = std::max(c->n_cached, n_past + n_steps);
     HIPC(hipSetDevice(m->device));
     hipStream_t s = c->stream;
-    const int fused = attn_fused_for(c, n_past + n_steps) ? 1 : 0;
+    int attn_hi = n_past + n_steps;
+    if (c->cells.active) {
+        // cells no longer follow positions (context shift / Self-Extend): the reference keeps generating at full speed (cpp/bridge.cpp:487-503).
+        // llama_kv_cache_find_slot depends on the cell metadata only, not on the tokens: run it for all n_steps here and hand the device loop
+        // the cell and the padded KV length of every step (step_begin_kernel); pending rotations first (llama_kv_cache_update)
+        if (kv_update(c, s)) return 1;
+        if (c->slots_cap < n_steps) {
+            if (dev_alloc(c->allocs, (void **) &c->slots, (size_t) c->out_cap * 8)) return 1;
+            c->slots_cap = c->out_cap;
+            if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }            // (captured with the old pointer)
+        }
+        std::vector<int32_t> hs((size_t) n_steps * 2);
+        for (int t = 0; t < n_steps; ++t) {
+            int cell = 0, n_kv = 0;
+            if (kv_find_slot(c, n_past + t, &cell, &n_kv)) return 1;
+            hs[(size_t) 2 * t] = cell; hs[(size_t) 2 * t + 1] = n_kv; attn_hi = std::max(attn_hi, n_kv - 1);
+        }
+        HIPC(hipMemcpyAsync(c->slots, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipStreamSynchronize(s));                                    // (hs is a host temporary)
+    } else c->n_cached = std::max(c->n_cached, n_past + n_steps);
+    const int fused = attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0);     // 2: the shifted-cell kernels and the slot table (other arguments: recapture)
     if (c->graph && c->graph_fused != fused) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-    if (!c->graph && build_graph(c, n_past + n_steps)) return 1;
+    if (!c->graph && build_graph(c, attn_hi)) return 1;
     c->graph_fused = fused;
     if (set_state(c, n_past, s, true)) return 1;
     EventPair ev; HIPC(ev.create());

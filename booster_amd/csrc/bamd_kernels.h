@@ -73,7 +73,7 @@ void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K
 void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s);
 void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipStream_t s);
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
-                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s);
+                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots = nullptr, int32_t * cellpos = nullptr);
 int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);
 // single-launch attention and the wo projection (+ residual) behind it in ONE launch (bamd_colaunch.hip); gran: [H * hd] zero-initialised 8-byte
 // granules of the context (the attention output travels through them), il: layer index (part of the tag), err: give-up counter.

@@ -195,9 +195,12 @@ __global__ void __launch_bounds__(512) matvec_split_kernel(bamd_mv_args a) {
 // Step begin: pick the token of this step (forced prompt token, or the arg-max of the previous step's logits),
 // advance the position, and dequantise its embedding row into the residual stream.
 // ===========================================================================================================
+// slots (null = cells follow positions, or ONE step whose cell / padded length the host put into the state): after a context shift the device-side
+// greedy loop takes the cell and the padded KV length of step k from slots[2 k], slots[2 k + 1] — llama_kv_cache_find_slot does not depend on
+// the tokens, so the host runs it for all steps ahead (bamd_generate_greedy) — and records the position in the cell's mask entry (cellpos)
 __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
                                                          int32_t * out_tokens, const uint8_t * embd, int embd_type, int E, int V,
-                                                         float * x, int do_embed) {
+                                                         float * x, int do_embed, const int32_t * slots, int32_t * cellpos) {
     __shared__ int tok_s;
     if (threadIdx.x == 0) {
         bamd_step_state h = *st;                              // ONE round trip for the whole state (field by field: a dependent load each)
@@ -218,6 +221,7 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
             int n_kv = (h.pos + 1 + 31) / 32 * 32;
             if (n_kv > h.n_ctx) n_kv = h.n_ctx;
             h.n_kv = h.n_kv_fixed ? h.n_kv_fixed : n_kv;
+            if (slots) { h.cell = slots[2 * step]; h.n_kv = slots[2 * step + 1]; cellpos[h.cell] = h.pos; }
             h.step = step + 1;
             h.best_key = 0ull;                                // a flush-only call leaves the key for the next generate call
         }
@@ -305,8 +309,8 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 }
 
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
-                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s) {
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed);
+                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots, int32_t * cellpos) {
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed, slots, cellpos);
 }
 
 

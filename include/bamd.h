@@ -61,8 +61,8 @@ const float * bamd_get_logits(bamd_context * c);                        /* llama
  * Cells whose position leaves the sequence are freed and refilled in cell order (llama_kv_cache_find_slot, :3028-3127); the K rows of
  * moved cells are re-rotated by their delta before the next evaluation (K-shift: build_k_shift :8482-8512, ggml.c:14169-14290); the
  * attention then runs over cells and masks by the position each holds — all as the reference does, bit for bit.  While cells and
- * positions differ, tokens are evaluated one per bamd_decode / bamd_stage_step call (bamd_generate_greedy and multi-token calls return an
- * error); an edit that leaves cell i holding position i again (a plain truncation, seq_rm(n, -1)) ends that mode at once.  The calls wait
+ * positions differ, tokens are evaluated one per bamd_decode / bamd_stage_step call (multi-token calls return an error) or by the device
+ * loop bamd_generate_greedy, which runs find_slot for all its steps ahead on the host (it does not depend on the tokens); an edit that leaves cell i holding position i again (a plain truncation, seq_rm(n, -1)) ends that mode at once.  The calls wait
  * for the device to go idle first (hipDeviceSynchronize): work of this context still in flight on any stream is finished before the cell
  * metadata changes.
  * Negative p0 / p1 mean 0 / infinity as in llama.h.  Layer-split: call on every stage's context.  Return 0 on success. */
