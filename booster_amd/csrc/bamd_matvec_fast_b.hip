@@ -2,8 +2,10 @@
 // rationale of the fast kernels.
 #include "bamd_matvec_core.h"
 
-template <int TYPE, int NBW, int M, int PRO, int EPI, bool ONEB>
-__global__ void __launch_bounds__(512) matvec_split_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+// NW: waves per workgroup (8; 14 for K = 14336 = 14 x 4 super-blocks: the ffn_down launch is not paced by its bytes but by what ONE wave walks
+// between entry and its last store — Q8_K of its blocks, the terms of its records, the chain — at one vector instruction per ~10 clocks)
+template <int TYPE, int NBW, int M, int PRO, int EPI, bool ONEB, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) matvec_split_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
     BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TL_STAMP(a.tl, 0);
@@ -153,17 +155,23 @@ bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, 
     return false;
 }
 
-template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false>
+template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false, int NW = 8>
 static void launch_fast_b_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (NBW * M > 8 ? 1 : 2) * M * nb * 256 * 4;
-    hipLaunchKernelGGL((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a);
+    hipLaunchKernelGGL((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
 }
+static const bool g_down14 = [] { const char * e = getenv("BAMD_DOWN14"); return !(e && e[0] == '0'); }();
 template <int PRO, int EPI>
 static bool launch_fast_b_types(const bamd_mv_args & a, int t, int nbw, int grid, hipStream_t s) {
     // row-groups per batch: the largest M of the kernel family that every workgroup can fill (cnt_q = the smallest count)
     // (K = 14336 with both row-groups of a workgroup in flight — M = 2, 14 records per wave — measured no faster, again: the wave that
     // issues 130 KB of requests up front sits in the issue stage until most of them have landed, and its prologue starts that much later)
+    if (g_down14 && PRO == BAMD_PRO_PLAIN && (a.K >> 8) == 56 && a.cnt_q >= 1) {                // K = 14336 on fourteen waves, four records each (one row-group per batch: 128 VGPRs)
+#define BAMD_B14(T_) if (t == T_) { launch_fast_b_inst<PRO, EPI, T_, 4, 1, false, 14>(a, grid, s); return true; }
+        BAMD_B14(BAMD_Q4_K) BAMD_B14(BAMD_Q5_K) BAMD_B14(BAMD_Q6_K)
+#undef BAMD_B14
+    }
     const int mmax = nbw == 1 ? 8 : nbw == 2 ? 4 : nbw == 4 ? 2 : 1;
     int m = 1; while (m * 2 <= mmax && m * 2 <= a.cnt_q) m *= 2;
     // exactly M row-groups in every workgroup: the single-batch instances (residual-add launches: wo, ffn_down)
