@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 static const bool g_colaunch = [] { const char * e = getenv("BAMD_COLAUNCH"); return !(e && e[0] == '0'); }();
-static const int g_ring_delay = [] { const char * e = getenv("BAMD_COLAUNCH_DELAY"); return e ? atoi(e) : 10 + 256; }();   // low byte: x ~0.2 us; + 256: s_sleep between polls (A/B on the MI355X: 698 / 703 / 704 tok/s at 8 / 8 + sleep / 12)      // x ~0.2 us before the wo role requests its weights
+static const int g_ring_delay = [] { const char * e = getenv("BAMD_COLAUNCH_DELAY"); return e ? atoi(e) : 12 + 256; }();   // low byte: x ~0.2 us; + 256: s_sleep between polls (A/B on the MI355X, round 3 end: 707 / 708 / 710 / 713-717 / 712 / 705 / 694 tok/s at 6 / 8 / 10 / 12 / 14 / 16 / 20, all + sleep)      // x ~0.2 us before the wo role requests its weights
 
 // 0 = launched; 1 = this shape has no co-launch kernel (the caller issues the two ordinary launches)
 int bamd_launch_attn_wo(const bamd_attn_args & t, int gq, const bamd_mv_args & wo, int n_cu, unsigned long long * gran, int il, uint32_t * err, hipStream_t s) {
