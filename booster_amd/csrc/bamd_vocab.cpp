@@ -41,6 +41,7 @@ static bool in_ranges(const uint32_t (*r)[2], int n, uint32_t cp) {
 static bool is_letter(uint32_t c) { return in_ranges(BAMD_UNI_LETTER, BAMD_UNI_LETTER_N, c); }
 static bool is_number(uint32_t c) { return in_ranges(BAMD_UNI_NUMBER, BAMD_UNI_NUMBER_N, c); }
 static bool is_space(uint32_t c)  { return in_ranges(BAMD_UNI_SPACE, BAMD_UNI_SPACE_N, c); }
+static bool is_punct(uint32_t c)  { return in_ranges(BAMD_UNI_PUNCT, BAMD_UNI_PUNCT_N, c); }
 
 // GPT-2 byte <-> unicode map (bytes_to_unicode): printable bytes map to themselves, the rest to 256+n
 static void byte_maps(uint32_t b2u[256], std::unordered_map<uint32_t, uint8_t> & u2b) {
@@ -86,16 +87,24 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
                 bpe_ranks[std::make_pair(w.substr(0, p), w.substr(p + 1))] = (int) i;
             }
         }
-        // pre-tokeniser (llm_load_vocab, llama.cpp:5375-5472): the llama-3 regex and the GPT-2 regex have hand-written splitters here;
-        // every other value — including a missing key or "default", whose four-regex chain is not implemented — FAILS the load
-        // instead of silently producing a different token stream
+        // pre-tokeniser (llm_load_vocab, llama.cpp:5375-5472; regex sets llama-vocab.cpp:340-443): hand-written splitters for the llama-3 regex
+        // (and its qwen2 form), the GPT-2 regex and the chains built around it (starcoder family, default, falcon), poro / viking and
+        // deepseek-coder; every other value (deepseek-llm: a 600-range letter class; tekken: look-aheads) FAILS the load instead of
+        // silently producing a different token stream
         std::string pre;
         g.get_str("tokenizer.ggml.pre", pre);
         if (pre == "llama3" || pre == "llama-v3" || pre == "llama-bpe") { pre_llama3 = true; ignore_merges = true; add_bos = true; }
         else if (pre == "dbrx" || pre == "smaug-bpe" || pre == "chatglm-bpe") pre_llama3 = true;              // same regex, no flags
         else if (pre == "gpt-2" || pre == "phi-2" || pre == "jina-es" || pre == "jina-de" || pre == "jina-v2-es" || pre == "jina-v2-de" ||
                  pre == "jina-v2-code" || pre == "mpt" || pre == "olmo" || pre == "jais") pre_llama3 = false;
-        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 and GPT-2 family pre-tokenisers only)"; return false; }
+        else if (pre == "qwen2" || pre == "stablelm2") { pre_llama3 = true; pre_maxdigits = 1; }
+        else if (pre == "starcoder" || pre == "refact" || pre == "command-r" || pre == "smollm" || pre == "codeshell") pre_chain = 1;
+        else if (pre.empty() || pre == "default") pre_chain = 2;                 // (a missing key: the reference warns and uses "default")
+        else if (pre == "falcon") pre_chain = 3;
+        else if (pre == "poro-chat") pre_chain = 4;
+        else if (pre == "viking") pre_chain = 5;
+        else if (pre == "deepseek-coder") pre_chain = 6;
+        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 / qwen2, GPT-2, starcoder, default, falcon, poro / viking and deepseek-coder pre-tokenisers only)"; return false; }
     }
     uint32_t u;
     if (g.get_u32("tokenizer.ggml.bos_token_id", u)) bos = (int) u;
@@ -244,7 +253,7 @@ static void spm_tokenize(const BamdVocab & v, const std::string & text, std::vec
 // ---- byte-level BPE (llama-vocab.cpp:488-590) ----------------------------------------------------------------------------------
 // split of the llama-3 pre-tokeniser regex (llama-vocab.cpp:345-349):
 // (?:'[sS]|'[tT]|'[rR][eE]|'[vV][eE]|'[mM]|'[lL][lL]|'[dD])|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
-static std::vector<std::pair<size_t, size_t>> split_llama3(const std::vector<uint32_t> & c) {
+static std::vector<std::pair<size_t, size_t>> split_llama3(const std::vector<uint32_t> & c, size_t maxdigits) {     // maxdigits 3: llama-3; 1: qwen2 (\\p{N})
     std::vector<std::pair<size_t, size_t>> out; const size_t n = c.size(); size_t i = 0;
     auto lower = [](uint32_t x) { return x >= 'A' && x <= 'Z' ? x + 32 : x; };
     while (i < n) {
@@ -260,7 +269,7 @@ static std::vector<std::pair<size_t, size_t>> split_llama3(const std::vector<uin
             if (!(x == '\r' || x == '\n' || is_letter(x) || is_number(x)) && i + 1 < n && is_letter(c[i + 1])) k = i + 1;
             if (k < n && is_letter(c[k])) { while (k < n && is_letter(c[k])) ++k; j = k; }
         }
-        if (j == i && is_number(x)) { size_t k = i; while (k < n && k < i + 3 && is_number(c[k])) ++k; j = k; }     // \p{N}{1,3}
+        if (j == i && is_number(x)) { size_t k = i; while (k < n && k < i + maxdigits && is_number(c[k])) ++k; j = k; }     // \p{N}{1,3} / \p{N}
         if (j == i) {                                                         //  ?[^\s\p{L}\p{N}]+[\r\n]*
             size_t k = i; if (x == ' ' && i + 1 < n) k = i + 1;
             if (k < n && !is_space(c[k]) && !is_letter(c[k]) && !is_number(c[k])) {
@@ -308,10 +317,69 @@ static std::vector<std::pair<size_t, size_t>> split_gpt2(const std::vector<uint3
     return out;
 }
 
+// ---- regex CHAINS (unicode_regex_split, unicode.cpp:645-800): every regex splits every piece the previous ones left — its matches become
+//      pieces and so do the gaps between them (unicode_regex_split_stl, :485-513) ----
+typedef std::vector<std::pair<size_t, size_t>> Spans;
+// one simple regex over [lo, hi): `len(i)` = length of the match that starts at i (0 = none)
+template <typename F> static void split_by(const std::vector<uint32_t> & c, const Spans & in, Spans & out, F len) {
+    out.clear();
+    for (const auto & sp : in) {
+        size_t start = sp.first, i = sp.first;
+        while (i < sp.second) {
+            const size_t m = len(i, sp.second);
+            if (m == 0) { ++i; continue; }
+            if (i > start) out.emplace_back(start, i);
+            out.emplace_back(i, i + m);
+            i += m; start = i;
+        }
+        if (start < sp.second) out.emplace_back(start, sp.second);
+    }
+}
+static Spans split_chain(const std::vector<uint32_t> & c, int chain) {
+    Spans a = { { 0, c.size() } }, b;
+    if (c.empty()) return Spans();
+    auto gpt2 = [&](const Spans & in, Spans & out) {           // the GPT-2 regex inside every piece (unicode_regex_split_custom_gpt2 works per piece)
+        out.clear();
+        for (const auto & sp : in) {
+            const std::vector<uint32_t> sub(c.begin() + (long) sp.first, c.begin() + (long) sp.second);
+            for (const auto & q : split_gpt2(sub)) out.emplace_back(sp.first + q.first, sp.first + q.second);
+        }
+    };
+    if (chain == 4 || chain == 5) {                            // poro / viking: " ?[^(\\s|.,!?…。，、।۔،)]+" (viking: then "\\p{N}")
+        auto ok = [&](uint32_t x) { return !(is_space(x) || x == '(' || x == '|' || x == '.' || x == ',' || x == '!' || x == '?' || x == ')' || x == 0x2026 || x == 0x3002 ||
+                                             x == 0xFF0C || x == 0x3001 || x == 0x0964 || x == 0x06D4 || x == 0x060C); };
+        split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; if (c[i] == ' ' && i + 1 < hi && ok(c[i + 1])) k = i + 1; size_t e = k; while (e < hi && ok(c[e])) ++e; return e > k ? e - i : (size_t) 0; });
+        if (chain == 4) return b;
+        split_by(c, b, a, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });
+        return a;
+    }
+    if (chain == 6) {                                          // deepseek-coder: "[\r\n]", "\\s?\\p{L}+", "\\s?\\p{P}+", "[一-龥ࠀ-一가-퟿]+", "\\p{N}"
+        split_by(c, a, b, [&](size_t i, size_t) { return c[i] == '\r' || c[i] == '\n' ? (size_t) 1 : (size_t) 0; });
+        split_by(c, b, a, [&](size_t i, size_t hi) { size_t k = i; if (is_space(c[i]) && i + 1 < hi && is_letter(c[i + 1])) k = i + 1; size_t e = k; while (e < hi && is_letter(c[e])) ++e; return e > k ? e - i : (size_t) 0; });
+        split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; if (is_space(c[i]) && i + 1 < hi && is_punct(c[i + 1])) k = i + 1; size_t e = k; while (e < hi && is_punct(c[e])) ++e; return e > k ? e - i : (size_t) 0; });
+        auto cjk = [](uint32_t x) { return (x >= 0x0800 && x <= 0x9FA5) || (x >= 0xAC00 && x <= 0xD7FF); };
+        split_by(c, b, a, [&](size_t i, size_t hi) { size_t e = i; while (e < hi && cjk(c[e])) ++e; return e - i; });
+        split_by(c, a, b, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });
+        return b;
+    }
+    if (chain == 1) {                                          // "\\p{N}" then GPT-2
+        split_by(c, a, b, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });
+        gpt2(b, a);
+        return a;
+    }
+    const bool falcon = chain == 3;
+    auto punct = [&](uint32_t x) { return is_punct(x) || x == '$' || x == '+' || x == '<' || x == '=' || x == '>' || x == '^' || x == '~' || x == '|' || (falcon && x == '`'); };
+    split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && punct(c[k])) ++k; return k - i; });       // "[\\p{P}\\$\\+<=>\\^~\\|]+" (falcon: + `)
+    gpt2(b, a);
+    if (falcon) split_by(c, a, b, [&](size_t i, size_t hi) { return i + 3 <= hi && c[i] >= '0' && c[i] <= '9' && c[i + 1] >= '0' && c[i + 1] <= '9' && c[i + 2] >= '0' && c[i + 2] <= '9' ? (size_t) 3 : (size_t) 0; });
+    else        split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && is_number(c[k])) ++k; return k - i; });                     // "\\p{N}+"
+    return b;
+}
+
 static void bpe_tokenize(const BamdVocab & v, const std::string & text, std::vector<int> & out) {
     uint32_t b2u[256]; std::unordered_map<uint32_t, uint8_t> u2b; byte_maps(b2u, u2b);
     const std::vector<uint32_t> cps = utf8_to_cpts(text);
-    const auto spans = v.pre_llama3 ? split_llama3(cps) : split_gpt2(cps);
+    const auto spans = v.pre_chain ? split_chain(cps, v.pre_chain) : v.pre_llama3 ? split_llama3(cps, (size_t) v.pre_maxdigits) : split_gpt2(cps);
     std::string raw, word, lt, rt;
     PieceTable pt;
     for (const auto & sp : spans) {

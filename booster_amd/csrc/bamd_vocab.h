@@ -19,7 +19,11 @@ enum {   // llama_token_attr (llama.h)
 
 struct BamdVocab {
     int type = BAMD_VOCAB_NONE;
-    bool pre_llama3 = false;                 // tokenizer.ggml.pre in {llama3, llama-v3, llama-bpe}
+    bool pre_llama3 = false;                 // tokenizer.ggml.pre in {llama3, llama-v3, llama-bpe} and the others with that regex
+    int pre_chain = 0;                       // 0: the single llama-3 / GPT-2 regex; else a regex chain around the GPT-2 regex (llama-vocab.cpp:379-443):
+                                             // 1 = {\p{N}} + GPT-2 (starcoder, refact, command-r, smollm, codeshell); 2 = default ({[\p{P}$+<=>^~|]+} + GPT-2 + {\p{N}+});
+                                             // 3 = falcon ({[\p{P}$+<=>^~|`]+} + GPT-2 + {[0-9][0-9][0-9]})
+    int pre_maxdigits = 3;                   // llama-3 regex: \p{N}{1,3}; qwen2 / stablelm2: \p{N}
     bool ignore_merges = false;
     bool add_space_prefix = true;
     bool add_bos = false, add_eos = false;

@@ -25,7 +25,12 @@ TOK_REF = os.path.join(ROOT, "oracle", "_ref", "tok_ref")
 
 def vocabs():
     return {"bpe32k": gguf.synthetic_bpe_vocab(n_merges=32768, seed=11), "gpt2": gguf.synthetic_bpe_vocab(n_merges=600, seed=12, pre="gpt-2"),
-            "spm": gguf.synthetic_spm_vocab()}
+            "spm": gguf.synthetic_spm_vocab(),
+            # the regex chains around the GPT-2 regex and the qwen2 form of the llama-3 regex (llama-vocab.cpp:379-443)
+            "qwen2": gguf.synthetic_bpe_vocab(n_merges=600, seed=13, pre="qwen2"), "starcoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=14, pre="starcoder"),
+            "default": gguf.synthetic_bpe_vocab(n_merges=600, seed=15, pre="default"), "falcon": gguf.synthetic_bpe_vocab(n_merges=600, seed=16, pre="falcon"),
+            "poro": gguf.synthetic_bpe_vocab(n_merges=600, seed=17, pre="poro-chat"), "viking": gguf.synthetic_bpe_vocab(n_merges=600, seed=18, pre="viking"),
+            "dscoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=19, pre="deepseek-coder")}
 
 
 def valid(cp):
@@ -36,13 +41,14 @@ def strings():
     rnd = random.Random(21)
     cls = json.load(open(os.path.join(HERE, "unicode_classes.json")))
     edge = []
-    for key in ("letter", "number", "whitespace"):
+    for key in ("letter", "number", "whitespace", "punctuation"):
         for lo, hi in cls[key]:
             for cp in (lo - 1, lo, hi, hi + 1):
                 if valid(cp):
                     edge.append(chr(cp))
     out = ["Hello world", " Hello  world!!", "it's he'll we'Re DON'T I'M you'D", "x = 12345 + 678;\n\n\ty++", "a\n\n b \r\n c   ", "   ", "\t\t\n", "1234567890",
-           "<|begin_of_text|>abc<|eot_id|>def <|start_header_id|>", "<s>hi</s> there<unk>", "ab<0x41>cd", "\x1c\x1d\x1e\x1f a\x1cb", "  x　y", "", " ", "\n"]
+           "<|begin_of_text|>abc<|eot_id|>def <|start_header_id|>", "<s>hi</s> there<unk>", "ab<0x41>cd", "\x1c\x1d\x1e\x1f a\x1cb", "  x　y", "", " ", "\n",
+           "a+=b<<2;c^=~d|e$f`g`", "1234567 12 123 1234 ٣٣٣٣ 12a345", "f(x)=[1,2]{3}...!?", "x$$+y==z>=w<=v^^u~~t||s", "  ...  !!\n\n??", "100%done#tag@me", "a。b，c…d«e»"]
     ctx = ["a%sb", " %s%s ", "1%s2", "%s\n%s", "x %s", "%s's", "'%s", "..%s!!", " %s1", "%s \r\n %s", "  %s", "%s\t"]
     rnd.shuffle(edge)
     for i in range(0, len(edge), 4):
@@ -52,7 +58,7 @@ def strings():
             c = ctx[rnd.randrange(len(ctx))]
             s += c % ((ch,) * c.count("%s"))
         out.append(s)
-    alphabet = "abcdehtAZ  \n\r\t'.,!?0189éжЖ中文ßıİǅ٣५๓½²ⅷ  ​\x1c_-+=#"
+    alphabet = "abcdehtAZ  \n\r\t'.,!?0189éжЖ中文ßıİǅ٣५๓½²ⅷ  ​\x1c_-+=#$<>^~|`«…。()，、।۔،가龥ࠀ"
     for _ in range(1200):
         n = rnd.randint(1, 48)
         out.append("".join(rnd.choice(alphabet) for _ in range(n)))
