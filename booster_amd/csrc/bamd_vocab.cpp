@@ -89,8 +89,8 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
         }
         // pre-tokeniser (llm_load_vocab, llama.cpp:5375-5472; regex sets llama-vocab.cpp:340-443): hand-written splitters for the llama-3 regex
         // (and its qwen2 form), the GPT-2 regex and the chains built around it (starcoder family, default, falcon), poro / viking and
-        // deepseek-coder; every other value (deepseek-llm: a 600-range letter class; tekken: look-aheads) FAILS the load instead of
-        // silently producing a different token stream
+        // deepseek-coder, tekken; every other value (deepseek-llm: a 600-range letter class) FAILS the load instead of silently producing
+        // a different token stream
         std::string pre;
         g.get_str("tokenizer.ggml.pre", pre);
         if (pre == "llama3" || pre == "llama-v3" || pre == "llama-bpe") { pre_llama3 = true; ignore_merges = true; add_bos = true; }
@@ -104,7 +104,8 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
         else if (pre == "poro-chat") pre_chain = 4;
         else if (pre == "viking") pre_chain = 5;
         else if (pre == "deepseek-coder") pre_chain = 6;
-        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 / qwen2, GPT-2, starcoder, default, falcon, poro / viking and deepseek-coder pre-tokenisers only)"; return false; }
+        else if (pre == "tekken") { pre_chain = 7; ignore_merges = true; add_bos = true; }
+        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 / qwen2, GPT-2, starcoder, default, falcon, poro / viking, deepseek-coder and tekken pre-tokenisers only)"; return false; }
     }
     uint32_t u;
     if (g.get_u32("tokenizer.ggml.bos_token_id", u)) bos = (int) u;
@@ -291,6 +292,54 @@ static std::vector<std::pair<size_t, size_t>> split_llama3(const std::vector<uin
     }
     return out;
 }
+// tekken (Mistral-Nemo; llama-vocab.cpp:428-434): the case classes of the original regex are approximated in the reference by look-aheads,
+//   U = (?=[\p{L}])([^a-z]) = a letter that is not ASCII lower case,  W = (?=[\p{L}])([^A-Z]) = a letter that is not ASCII upper case
+// (a non-ASCII letter is both), and the regex is  P?U*W+ | P?U+W* | \p{N} |  ?[^\s\p{L}\p{N}]+[\r\n/]* | \s*[\r\n]+ | \s+(?!\S) | \s+
+// with P = [^\r\n\p{L}\p{N}].  ECMAScript semantics: first alternative that matches, greedy quantifiers with backtracking — U* gives
+// characters back until a W can follow.
+static std::vector<std::pair<size_t, size_t>> split_tekken(const std::vector<uint32_t> & c) {
+    std::vector<std::pair<size_t, size_t>> out; const size_t n = c.size(); size_t i = 0;
+    auto isU = [](uint32_t x) { return is_letter(x) && !(x >= 'a' && x <= 'z'); };
+    auto isW = [](uint32_t x) { return is_letter(x) && !(x >= 'A' && x <= 'Z'); };
+    while (i < n) {
+        size_t j = i;
+        const uint32_t x = c[i];
+        const bool isP = !(x == '\r' || x == '\n' || is_letter(x) || is_number(x));
+        for (int p = isP ? 1 : 0; p >= 0 && j == i; --p) {                    // P?U*W+
+            const size_t k = i + (size_t) p;
+            size_t umax = 0; while (k + umax < n && isU(c[k + umax])) ++umax;
+            for (size_t u = umax + 1; u-- > 0 && j == i; ) {
+                size_t w = 0; while (k + u + w < n && isW(c[k + u + w])) ++w;
+                if (w >= 1) j = k + u + w;
+            }
+        }
+        for (int p = isP ? 1 : 0; p >= 0 && j == i; --p) {                    // P?U+W*
+            const size_t k = i + (size_t) p;
+            size_t u = 0; while (k + u < n && isU(c[k + u])) ++u;
+            if (u >= 1) { size_t w = 0; while (k + u + w < n && isW(c[k + u + w])) ++w; j = k + u + w; }
+        }
+        if (j == i && is_number(x)) j = i + 1;                                // \p{N}
+        if (j == i) {                                                         //  ?[^\s\p{L}\p{N}]+[\r\n/]*
+            size_t k = i; if (x == ' ' && i + 1 < n) k = i + 1;
+            if (k < n && !is_space(c[k]) && !is_letter(c[k]) && !is_number(c[k])) {
+                while (k < n && !is_space(c[k]) && !is_letter(c[k]) && !is_number(c[k])) ++k;
+                while (k < n && (c[k] == '\r' || c[k] == '\n' || c[k] == '/')) ++k;
+                j = k;
+            }
+        }
+        if (j == i && is_space(x)) {
+            size_t e = i; while (e < n && is_space(c[e])) ++e;                // whitespace run [i, e)
+            size_t last_nl = (size_t) -1; for (size_t k = i; k < e; ++k) if (c[k] == '\r' || c[k] == '\n') last_nl = k;
+            if (last_nl != (size_t) -1) j = last_nl + 1;                      // \s*[\r\n]+
+            else if (e == n) j = e;                                           // \s+(?!\S) at end of text
+            else if (e - i >= 2) j = e - 1;                                   // \s+(?!\S): leave one for the next word
+            else j = e;                                                       // \s+
+        }
+        if (j == i) j = i + 1;
+        out.emplace_back(i, j); i = j;
+    }
+    return out;
+}
 // default GPT-2 style: 's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+
 static std::vector<std::pair<size_t, size_t>> split_gpt2(const std::vector<uint32_t> & c) {
     std::vector<std::pair<size_t, size_t>> out; const size_t n = c.size(); size_t i = 0;
@@ -379,7 +428,7 @@ static Spans split_chain(const std::vector<uint32_t> & c, int chain) {
 static void bpe_tokenize(const BamdVocab & v, const std::string & text, std::vector<int> & out) {
     uint32_t b2u[256]; std::unordered_map<uint32_t, uint8_t> u2b; byte_maps(b2u, u2b);
     const std::vector<uint32_t> cps = utf8_to_cpts(text);
-    const auto spans = v.pre_chain ? split_chain(cps, v.pre_chain) : v.pre_llama3 ? split_llama3(cps, (size_t) v.pre_maxdigits) : split_gpt2(cps);
+    const auto spans = v.pre_chain == 7 ? split_tekken(cps) : v.pre_chain ? split_chain(cps, v.pre_chain) : v.pre_llama3 ? split_llama3(cps, (size_t) v.pre_maxdigits) : split_gpt2(cps);
     std::string raw, word, lt, rt;
     PieceTable pt;
     for (const auto & sp : spans) {
