@@ -89,8 +89,8 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
         }
         // pre-tokeniser (llm_load_vocab, llama.cpp:5375-5472; regex sets llama-vocab.cpp:340-443): hand-written splitters for the llama-3 regex
         // (and its qwen2 form), the GPT-2 regex and the chains built around it (starcoder family, default, falcon), poro / viking and
-        // deepseek-coder, tekken; every other value (deepseek-llm: a 600-range letter class) FAILS the load instead of silently producing
-        // a different token stream
+        // deepseek-coder / deepseek-llm, tekken — every name llm_load_vocab knows; any other value FAILS the load instead of silently
+        // producing a different token stream
         std::string pre;
         g.get_str("tokenizer.ggml.pre", pre);
         if (pre == "llama3" || pre == "llama-v3" || pre == "llama-bpe") { pre_llama3 = true; ignore_merges = true; add_bos = true; }
@@ -105,7 +105,8 @@ bool BamdVocab::load(const GgufFile & g, std::string & err) {
         else if (pre == "viking") pre_chain = 5;
         else if (pre == "deepseek-coder") pre_chain = 6;
         else if (pre == "tekken") { pre_chain = 7; ignore_merges = true; add_bos = true; }
-        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 / qwen2, GPT-2, starcoder, default, falcon, poro / viking, deepseek-coder and tekken pre-tokenisers only)"; return false; }
+        else if (pre == "deepseek-llm") pre_chain = 8;
+        else { err = "tokenizer.ggml.pre \"" + pre + "\" is not supported (llama-3 / qwen2, GPT-2, starcoder, default, falcon, poro / viking, deepseek and tekken pre-tokenisers only)"; return false; }
     }
     uint32_t u;
     if (g.get_u32("tokenizer.ggml.bos_token_id", u)) bos = (int) u;
@@ -410,6 +411,25 @@ static Spans split_chain(const std::vector<uint32_t> & c, int chain) {
         split_by(c, b, a, [&](size_t i, size_t hi) { size_t e = i; while (e < hi && cjk(c[e])) ++e; return e - i; });
         split_by(c, a, b, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });
         return b;
+    }
+    if (chain == 8) {                                          // deepseek-llm: "[\r\n]", "\\s?[W]+", "\\s?[P]+", "\\s+$", "[C]+", "\\p{N}+" — W, P, C: what std::wregex makes of
+        // the literal classes of the reference's regexes, recorded code point by code point through its own unicode_regex_split
+        // (tests/golden/gen_deepseek_class.py; P includes ':'..'~', so the ASCII letters: regex 3 re-splits the words of regex 2)
+        auto in = [](const uint32_t (*r)[2], int n, uint32_t x) { return in_ranges(r, n, x); };
+        auto cls_run = [&](const uint32_t (*r)[2], int nr, bool space_first) {
+            return [&, r, nr, space_first](size_t i, size_t hi) {
+                size_t k = i; if (space_first && is_space(c[i]) && i + 1 < hi && in(r, nr, c[i + 1])) k = i + 1;
+                size_t e = k; while (e < hi && in(r, nr, c[e])) ++e;
+                return e > k ? e - i : (size_t) 0;
+            };
+        };
+        split_by(c, a, b, [&](size_t i, size_t) { return c[i] == '\r' || c[i] == '\n' ? (size_t) 1 : (size_t) 0; });
+        split_by(c, b, a, cls_run(BAMD_UNI_DSWORD, BAMD_UNI_DSWORD_N, true));
+        split_by(c, a, b, cls_run(BAMD_UNI_DSPUNCT, BAMD_UNI_DSPUNCT_N, true));
+        split_by(c, b, a, [&](size_t i, size_t hi) { for (size_t k = i; k < hi; ++k) if (!is_space(c[k])) return (size_t) 0; return hi - i; });      // "\\s+$": to the end of the piece
+        split_by(c, a, b, cls_run(BAMD_UNI_DSCJK, BAMD_UNI_DSCJK_N, false));
+        split_by(c, b, a, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && is_number(c[k])) ++k; return k - i; });
+        return a;
     }
     if (chain == 1) {                                          // "\\p{N}" then GPT-2
         split_by(c, a, b, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });

@@ -30,7 +30,8 @@ def vocabs():
             "qwen2": gguf.synthetic_bpe_vocab(n_merges=600, seed=13, pre="qwen2"), "starcoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=14, pre="starcoder"),
             "default": gguf.synthetic_bpe_vocab(n_merges=600, seed=15, pre="default"), "falcon": gguf.synthetic_bpe_vocab(n_merges=600, seed=16, pre="falcon"),
             "poro": gguf.synthetic_bpe_vocab(n_merges=600, seed=17, pre="poro-chat"), "viking": gguf.synthetic_bpe_vocab(n_merges=600, seed=18, pre="viking"),
-            "dscoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=19, pre="deepseek-coder"), "tekken": gguf.synthetic_bpe_vocab(n_merges=600, seed=20, pre="tekken")}
+            "dscoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=19, pre="deepseek-coder"), "tekken": gguf.synthetic_bpe_vocab(n_merges=600, seed=20, pre="tekken"),
+            "dsllm": gguf.synthetic_bpe_vocab(n_merges=600, seed=21, pre="deepseek-llm")}
 
 
 def valid(cp):
@@ -48,7 +49,7 @@ def strings():
                     edge.append(chr(cp))
     out = ["Hello world", " Hello  world!!", "it's he'll we'Re DON'T I'M you'D", "x = 12345 + 678;\n\n\ty++", "a\n\n b \r\n c   ", "   ", "\t\t\n", "1234567890",
            "<|begin_of_text|>abc<|eot_id|>def <|start_header_id|>", "<s>hi</s> there<unk>", "ab<0x41>cd", "\x1c\x1d\x1e\x1f a\x1cb", "  x　y", "", " ", "\n",
-           "a+=b<<2;c^=~d|e$f`g`", "1234567 12 123 1234 ٣٣٣٣ 12a345", "f(x)=[1,2]{3}...!?", "x$$+y==z>=w<=v^^u~~t||s", "  ...  !!\n\n??", "100%done#tag@me", "a。b，c…d«e»", "HELLOworld helloWORLD HeLLo ÉCOLEécole ÀBc aÀB ABC abc ŻÓŁĆ żółć a/b//c\n/ x1Y2", "McDonald's iPhone XMLHttpRequest ΑΒΓαβγ"]
+           "a+=b<<2;c^=~d|e$f`g`", "1234567 12 123 1234 ٣٣٣٣ 12a345", "f(x)=[1,2]{3}...!?", "x$$+y==z>=w<=v^^u~~t||s", "  ...  !!\n\n??", "100%done#tag@me", "a。b，c…d«e»", "HELLOworld helloWORLD HeLLo ÉCOLEécole ÀBc aÀB ABC abc ŻÓŁĆ żółć a/b//c\n/ x1Y2", "McDonald's iPhone XMLHttpRequest ΑΒΓαβγ", "aÀa bÖc ＡＢＣabc！？ 中文字가나다 x  \n y   ", "tail   ", "‘quoted’ 。，、 １２３ 123abc"]
     ctx = ["a%sb", " %s%s ", "1%s2", "%s\n%s", "x %s", "%s's", "'%s", "..%s!!", " %s1", "%s \r\n %s", "  %s", "%s\t"]
     rnd.shuffle(edge)
     for i in range(0, len(edge), 4):
