@@ -14,8 +14,22 @@
 // COLAUNCH: the output is not stored as floats but as 8-byte GRANULES {value bits, tag} with one write-through (sc1) store each — the data is its own
 // flag (MI355X_MICROARCH.md, R2): the wo workgroups of the same launch re-read their granules until every tag is this launch's tag, with no drain,
 // barrier or flag hop on this side.  done_flags then points at the granule array [H * hd].
-template <int LG, bool COLAUNCH>
-__device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const int h, const int tokb_in, unsigned char * attn_dyn, uint32_t * done_flags, uint32_t tag) {
+// ENV: where the body runs.  AttnEnvWG = a whole 512-thread workgroup (attn_fused_kernel, attn_wo_kernel): thread / wave ids from the hardware,
+// __syncthreads, this token's q / k / v read from the f32 vectors of the argument block.  The weight-stream engine (bamd_wse.hip) runs the same body
+// on eight of its consumer waves: ids relative to the first of them, a counting barrier among those waves, q / k / v from an LDS stage it filled
+// from the validated granules of the QKV launch role.
+struct AttnEnvWG {
+    int tid, wave, nthr;
+    __device__ __forceinline__ AttnEnvWG() : tid((int) threadIdx.x), wave(wave_id()), nthr((int) blockDim.x) { }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ float2 qk2(const bamd_attn_args & a, int role, int h, int hk, int hd, int rp) const {
+        const float * rsrc = role == 1 ? a.k + (size_t) hk * hd : a.q + (size_t) h * hd;
+        return *(const float2 *) (rsrc + 2 * rp);
+    }
+    __device__ __forceinline__ float vel(const bamd_attn_args & a, int hk, int hd, int i) const { return a.v[hk * hd + i]; }
+};
+template <int LG, bool COLAUNCH, typename ENV = AttnEnvWG>
+__device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const int h, const int tokb_in, unsigned char * attn_dyn, uint32_t * done_flags, uint32_t tag, const ENV env = ENV()) {
     __shared__ __attribute__((aligned(16))) float qt[256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
@@ -34,21 +48,20 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     constexpr int hd = LG * 64, L = LG * 8, hp = hd / 2;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int hk = h / gq;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7;
+    const int tid = env.tid, lane = tid & 63, wave = env.wave, e = lane & 7;
     const float * rope = a.rope + (size_t) pos * hd;
     TL_STAMP(a.tl, 0);
     // 1. the small, latency-critical requests go out FIRST: this token's q / k pair and its cos / sin for the thread's RoPE role, and
     //    the v elements the KV store and the P.V splice need.  Loads return in order: they land ~1 us before the K / V^T chunks
     //    requested behind them, and RoPE runs while those stream in.
     const int role = tid / hp, rp = tid - role * hp;              // role 0: q pair rp, role 1: k pair rp, others: (a redundant copy of role 0)
-    const float * rsrc = role == 1 ? a.k + (size_t) hk * hd : a.q + (size_t) h * hd;
-    const float2 xin = *(const float2 *) (rsrc + 2 * rp);
+    const float2 xin = env.qk2(a, role, h, hk, hd, rp);
     const float2 cs = *(const float2 *) (rope + 2 * rp);
-    const float vst = a.v[hk * hd + (tid < hd ? tid : 0)];        // KV store: element tid of this token's v
+    const float vst = env.vel(a, hk, hd, tid < hd ? tid : 0);     // KV store: element tid of this token's v
     const int r_pos = wave * 8 + (lane >> 3);                     // position inside a 64-tile (scores) / d inside a 64-block (P.V)
     float vcf[LG];
 #pragma unroll
-    for (int dd = 0; dd < LG; ++dd) vcf[dd] = a.v[hk * hd + r_pos + 64 * dd];
+    for (int dd = 0; dd < LG; ++dd) vcf[dd] = env.vel(a, hk, hd, r_pos + 64 * dd);
     // 2. this lane's K chunks of the first 4 x 64 positions and its V^T chunks of the first 4 blocks (rows d = r_pos + 64 dd), all
     //    unconditional: a tile past the end of the cache is clamped to the last one, positions >= pos hold zeros or stale finite
     //    values whose scores are masked below and whose probabilities are exactly 0
@@ -73,7 +86,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
         if (role == 0) { qt[i0] = r0; qt[i1] = r1; q16t[i0] = f2h(r0); q16t[i1] = f2h(r1); }
         else if (role == 1) { k16t[i0] = f2h(r0); k16t[i1] = f2h(r1); }
     }
-    __syncthreads();
+    env.sync();
     // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
     if (h == hk * gq && !a.batch && tid < hd) {
         a.kc[(size_t) pos * Ekv + hk * hd + tid] = k16t[tid];
@@ -105,22 +118,22 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
         BAMD_SCORE_TILE(t0, kl);
     }
 #undef BAMD_SCORE_TILE
-    __syncthreads();
+    env.sync();
     TL_STAMP(a.tl, 2);
     // ---- softmax (ggml.c:13682-13778 + :2619-2671): wp = s*scale (+mask), max, exp, 8-chunk f32 sums, double total ----
     const float scale = a.kq_scale;
     float mx = -INFINITY;
-    for (int i = tid; i < n_kv; i += blockDim.x) { const float w = sc[i] * scale; mx = w > mx ? w : mx; }
+    for (int i = tid; i < n_kv; i += env.nthr) { const float w = sc[i] * scale; mx = w > mx ? w : mx; }
     {   // -inf..inf floats: order-preserving key for an unsigned max
         uint32_t u = __float_as_uint(mx); u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
         u = wave_max_u32(u);
         if (lane == 0) redf[wave] = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
     }
-    __syncthreads();
+    env.sync();
     mx = redf[0];
     for (int w = 1; w < 8; ++w) mx = redf[w] > mx ? redf[w] : mx;
     double sum = 0.0;
-    for (int i = tid; i < n_kv; i += blockDim.x) {                 // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
+    for (int i = tid; i < n_kv; i += env.nthr) {                 // n_kv % 32 == 0: 8-lane groups are all-active or all-idle
         const float w = sc[i] * scale;
         const float val = v_expf(w - mx);
         sc[i] = val;
@@ -129,21 +142,21 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     }
     sum = wave_sum_f64(sum);
     if (lane == 0) redd[wave] = sum;
-    __syncthreads();
+    env.sync();
     double tot = 0.0;
     for (int w = 0; w < 8; ++w) tot += redd[w];
     double rs = 1.0 / tot;
     float fs = (float) rs;
     if (!f32_rounding_safe(rs, BAMD_F64_GUARD_ULPS(n_kv / 8))) {          // workgroup-uniform, rare: the reference's sequential order (bamd_device.h)
-        __syncthreads();
+        env.sync();
         if (tid == 0) redd[0] = seq_expsum8(sc, n_kv);
-        __syncthreads();
+        env.sync();
         rs = 1.0 / redd[0]; fs = (float) rs;
     }
-    for (int i = tid; i < n_kv; i += blockDim.x) pt[vperm(i)] = sc[i] * fs;
+    for (int i = tid; i < n_kv; i += env.nthr) pt[vperm(i)] = sc[i] * fs;
     // half-filled last block (n_kv % 64 == 32): p = 0 for the missing positions, so the chain steps there are exact no-ops
-    for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += blockDim.x) pt[vperm(i)] = 0.f;
-    __syncthreads();
+    for (int i = n_kv + tid; i < ((n_kv + 63) & ~63); i += env.nthr) pt[vperm(i)] = 0.f;
+    env.sync();
     TL_STAMP(a.tl, 3);
     // ---- P.V: lane (d, e) carries the tinyBLAS chain Cv[e] of output d (A = V^T row, B = p), up to 4 rows d per lane ----
     unsigned short vcur[4] = { 0, 0, 0, 0 };

@@ -1,0 +1,488 @@
+// bamd_wse.hip — the weight-stream engine kernel: one persistent launch runs a whole decode step (or any sub-range of its ops).
+// Design, wave roles and the reference functions it replaces: bamd_wse.h.  Numerics: the per-record terms are block_terms() and the chains
+// chain_step() / finish_row() of bamd_device.h — the code the launch kernels run — so every output is the launch path's, bit for bit.
+//
+// Intra-CU hand-overs are LDS words (the LDS of a CU is one in-order unit: a wave's data writes are visible before its later flag write):
+//   fill[slot]   = global slot number + 1 once the slot's DMA has landed            (loader -> consumers)
+//   freec[slot] += 1 per record copied out of the slot into registers               (consumers -> loader; monotonic)
+//   chunk[c]    += 1 per record parked in term chunk c (8 records)                  (consumers -> chainer; the chainer resets it)
+//   chain_done   = records chained so far                                           (chainer -> consumers: term slots free below chain_done + tr)
+//   cbar / cbar8 = counting barriers among the consumer waves (all of them / the eight that run an attention head)
+// Inter-CU hand-overs are 8-byte {value, tag} granules, one sc1 store each, re-read with sc1 loads until every tag matches
+// (cdna_hip_programming.md, Guideline 16 R2); tag = (host serial, device step, consumer layer) is unique among consecutive uses of a word.
+#include "bamd_matvec_core.h"
+#include "bamd_attn_fused.h"
+#include "bamd_wse.h"
+
+#define WSE_SPINS_LDS (1u << 21)       /* bounded waits: ~0.2 s of LDS polling / ~1 s of granule polling, then give up (err) and run on */
+#define WSE_SPINS_GLB (1u << 20)
+
+enum { W_FILL = 0, W_FREE = 16, W_EXPECT = 32, W_CHAIN_DONE = 48, W_CBAR = 49, W_CBAR8 = 50, W_ABORT = 51, W_GATHERING = 52, W_CHUNK = 64,
+       W_RED_BYTES = 384, W_STASH_BYTES = 512 };       /* words of the control block; red: 16 doubles; stash: BAMD_WSE_STASH floats */
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t * w) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void lds_st(uint32_t * w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wse_fail(const bamd_wse_args & a, uint32_t * misc, uint32_t code) {
+    if ((threadIdx.x & 63) == 0) {
+        lds_st(misc + W_ABORT, 1u);
+        if (atomicAdd(a.err, 1u) == 0u) { a.err[1] = code; a.err[2] = blockIdx.x; a.err[3] = threadIdx.x >> 6; }
+    }
+}
+// wait until (int) (*w - want) >= 0 (monotonic counters) or, EQ, until *w == want
+template <bool EQ>
+__device__ __forceinline__ void lds_wait(const bamd_wse_args & a, uint32_t * misc, const uint32_t * w, uint32_t want, uint32_t code) {
+    for (unsigned spins = 0;; ++spins) {
+        const uint32_t v = lds_ld(w);
+        if (EQ ? v == want : (int) (v - want) >= 0) break;
+        if (spins > WSE_SPINS_LDS || lds_ld(misc + W_ABORT)) { if (spins > WSE_SPINS_LDS) wse_fail(a, misc, code); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");          // nothing that follows may be read ahead of the flag (the LDS itself serves a wave in order)
+}
+// a pointer that arrives through memory (a field of the argument block picked by a run-time index, an op's 64-bit address) is a GENERIC pointer to
+// hipcc: its loads become FLAT instructions, which count on both wait counters.  Everything here is global memory: say so.
+template <typename T> __device__ __forceinline__ T * as_global(const void * p) { return (T *) (__attribute__((address_space(1))) T *) (uintptr_t) p; }
+template <typename T> __device__ __forceinline__ T * as_global(uint64_t p) { return (T *) (__attribute__((address_space(1))) T *) (uintptr_t) p; }
+// The roles of a wave are inlined into ONE loop over its program; without this LLVM hoists every lane-dependent address expression of every role out
+// of that loop and keeps them all live through the attention body (204 VGPRs instead of ~110).  An opaque copy of the lane / thread id at the entry
+// of each role keeps its arithmetic inside the role.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+struct CBar { uint32_t target = 0; };
+__device__ __forceinline__ void cbar(const bamd_wse_args & a, uint32_t * misc, int word, CBar & b, int n, uint32_t code) {
+    lds_drain();
+    if ((threadIdx.x & 63) == 0) atomicAdd(misc + word, 1u);
+    b.target += (uint32_t) n;
+    lds_wait<false>(a, misc, misc + word, b.target, code);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void tl_stamp(const bamd_wse_args & a, const bamd_wse_op & op, int ev) {
+    if (a.tl && op.tlslot != 255 && (threadIdx.x & 63) == 0) a.tl[((size_t) blockIdx.x * a.tl_ops + op.tlslot) * 8 + ev] = wall_clock64();
+}
+__device__ __forceinline__ uint32_t wse_tagbase(const bamd_step_state * st) { return ((uint32_t) st->serial << 20) | (((uint32_t) st->step & 0xfffu) << 8); }
+
+// ---- LOADER ------------------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void * wse_lds_vp;
+// one 1 KiB piece of a fill: lane l moves the 16 bytes at gsrc (its own address) to LDS dst + 16 l.  Inline asm: invisible to hipcc's wait counting
+// (the loader counts vmcnt itself); M0 is written in the statement that reads it (cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void dma1k(const uint8_t * gsrc, uint32_t dst_) {
+    const uint32_t dst = (uint32_t) __builtin_amdgcn_readfirstlane((int) dst_);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void wse_loader(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t ring0 = (uint32_t) (size_t) (wse_lds_vp) smem;
+    const uint32_t ns = (uint32_t) a.ns;
+    uint32_t gs = 0, slot = 0;            // next slot to issue (global number, ring position)
+    uint32_t pub = 0, pslot = 0;          // next slot to publish
+    auto publish_to = [&](uint32_t upto) {        // everything below `upto` has landed
+        while (pub < upto) { lds_st(misc + W_FILL + pslot, pub + 1u); ++pub; pslot = pslot + 1u == ns ? 0u : pslot + 1u; }
+    };
+    for (int io = 0;; ++io) {
+        const bamd_wse_op op = ops[io];
+        if (op.kind == BAMD_WSE_END) break;
+        if (op.kind != BAMD_WSE_MATVEC) continue;
+        const uint32_t recb = (uint32_t) bamd_record_bytes((int) op.type), nrec = op.ntask * op.nb;
+        const uint8_t * src = as_global<const uint8_t>(op.src);
+        for (uint32_t done = 0; done < nrec; done += op.rps, ++gs) {
+            const uint32_t nr = nrec - done < op.rps ? nrec - done : op.rps;
+            const uint32_t want = lds_ld(misc + W_EXPECT + slot);
+            if (gs >= ns && lds_ld(misc + W_FREE + slot) != want) {          // ring full: nothing to issue, so let everything land and publish it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publish_to(gs);
+                lds_wait<true>(a, misc, misc + W_FREE + slot, want, 0x100u);
+            }
+            lds_st(misc + W_EXPECT + slot, want + nr);
+            const uint32_t nld = (nr * recb + 1023u) >> 10, dst = ring0 + slot * BAMD_WSE_SLOT;
+            const uint8_t * p = src + (size_t) done * recb + lane * 16;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i) {       // always 16 requests (vmcnt arithmetic stays constant); past the data: the last KiB again (a cache hit)
+                const uint32_t k = i < nld ? i : nld - 1u;
+                dma1k(p + (size_t) k * 1024u, dst + k * 1024u);
+            }
+            if (a.thin && lds_ld(misc + W_GATHERING)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish_to(gs + 1u); }
+            else { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (gs >= 2u) publish_to(gs - 1u); }       // two fills may be in flight
+            slot = slot + 1u == ns ? 0u : slot + 1u;
+        }
+        tl_stamp(a, op, BAMD_WSE_TL_LOADED);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish_to(gs);
+}
+
+// ---- CONSUMERS ---------------------------------------------------------------------------------------------------------------------------------
+// records out of an LDS slot: the record layout of bamd_formats.h, addressed as load_rec() does in global memory
+__device__ __forceinline__ void lds_rec(RecQ4K & R, const unsigned char * p, int lane) {
+    R.qs = *(const uint4 *) (p + lane * 16); R.hd = *(const uint4 *) (p + 1024 + (lane >> 3) * 16); R.mn47 = 0u;
+}
+__device__ __forceinline__ void lds_rec(RecQ5K & R, const unsigned char * p, int lane) {
+    R.qs = *(const uint4 *) (p + lane * 16); R.qh = *(const uint32_t *) (p + 1024 + lane * 4); R.hd = *(const uint4 *) (p + 1280 + (lane >> 3) * 16); R.mn47 = 0u;
+}
+__device__ __forceinline__ void lds_rec(RecQ6K & R, const unsigned char * p, int lane) {
+    R.ql = *(const uint4 *) (p + lane * 16); R.qh = *(const uint2 *) (p + 1024 + lane * 8);
+    R.sc = *(const uint2 *) (p + 1536 + (lane >> 3) * 16 + ((lane >> 2) & 1) * 8); R.d = (uint32_t) *(const unsigned short *) (p + 1664 + (lane >> 3) * 2);
+}
+
+struct ActPtrs { uint32_t * q8; int * S; float * yd; };
+__device__ __forceinline__ ActPtrs act_ptrs(unsigned char * smem, const bamd_wse_args & a, int buf, int nb) {
+    ActPtrs p; p.q8 = (uint32_t *) (smem + a.off_act[buf]); p.S = (int *) (p.q8 + nb * 64); p.yd = (float *) (p.S + nb * 8); return p;
+}
+
+// two granules (16 bytes) of a vector another CU publishes: sc1, past this CU's L1
+__device__ __forceinline__ uint4 gran2(bamd_rsrc r, uint32_t byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, 16);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ bamd_rsrc vec_rsrc(const void * base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) base), 0, (int) bytes, 0x00020000);
+}
+
+// the activation vector of an op -> Q8_K (optionally RMSNorm * weight first) in LDS buffer op.actbuf, by all NC consumer waves:
+// consumer cw takes the blocks cw, cw + NC, ... in batches of BAMD_ACT_BATCH.  Arithmetic: ActPro::quantize_batch and the sum of ActPro::finish.
+template <bool NORM>
+__device__ __forceinline__ void wse_gather(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, CBar & cb, uint32_t tagbase) {
+    const int lane = opaque((int) threadIdx.x & 63), nc = a.nc, nb = (int) op.nb, K = nb * 256;
+    const bamd_wse_vec vin = a.vec[op.in_vec];
+    const ActPtrs ap_ = act_ptrs(smem, a, op.actbuf, nb);
+    double * red = (double *) ((unsigned char *) misc + W_RED_BYTES);
+    const uint32_t tag = tagbase | op.in_tag;
+    const bamd_rsrc gr = vec_rsrc(vin.p, vin.n * (vin.gran ? 8u : 4u));
+    const float * nw = as_global<const float>(op.normw);
+    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_GATHER0); if (a.thin && lane == 0) lds_st(misc + W_GATHERING, 1u); }
+    float scale = 1.0f;
+    for (int base = cw; base < nb || (NORM && base == cw); base += BAMD_ACT_BATCH * nc) {
+        ActPro<NORM> ap; ap.okmask = 0;
+        int blk[BAMD_ACT_BATCH];
+#pragma unroll
+        for (int b = 0; b < BAMD_ACT_BATCH; ++b) { const int i = base + b * nc; const bool ok = i < nb; ap.okmask |= ok ? 1 << b : 0; blk[b] = ok ? i : nb - 1; }
+        if (NORM) {
+#pragma unroll
+            for (int b = 0; b < BAMD_ACT_BATCH; ++b) ap.w[b] = *(const float4 *) (nw + blk[b] * 256 + lane * 4);
+        }
+        if (vin.gran) {
+            for (unsigned spins = 0;; ++spins) {
+                asm volatile("" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                    const uint32_t off = (uint32_t) (blk[b] * 256 + lane * 4) * 8u;
+                    const uint4 g0 = gran2(gr, off), g1 = gran2(gr, off + 16u);
+                    ap.v[b] = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.z), __uint_as_float(g1.x), __uint_as_float(g1.z));
+                    ok = ok && g0.y == tag && g0.w == tag && g1.y == tag && g1.w == tag;
+                }
+                if (__all(ok)) break;
+                if (spins > WSE_SPINS_GLB || lds_ld(misc + W_ABORT) || (spins & 255u) == 255u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (spins > WSE_SPINS_GLB) wse_fail(a, misc, 0x200u | op.in_vec);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < BAMD_ACT_BATCH; ++b) ap.v[b] = *(const float4 *) (as_global<const float>(vin.p) + blk[b] * 256 + lane * 4);
+        }
+        if (cw == 0 && base == cw) tl_stamp(a, op, BAMD_WSE_TL_VALID);
+        if (NORM) {      // one batch holds the wave's whole share (planner: <= 4 blocks per wave): sum of squares in double, ggml.c:11874-11877
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
+                if (ap.okmask >> b & 1) { s += (double) (ap.v[b].x * ap.v[b].x); s += (double) (ap.v[b].y * ap.v[b].y); s += (double) (ap.v[b].z * ap.v[b].z); s += (double) (ap.v[b].w * ap.v[b].w); }
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) red[cw] = s;
+            cbar(a, misc, W_CBAR, cb, nc, 0x300u);
+            double tot = 0.0;
+            for (int w2 = 0; w2 < nc; ++w2) tot += red[w2];
+            double md = (K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K;
+            float mean = (float) md;
+            if (!f32_rounding_safe(md, BAMD_F64_GUARD_ULPS(K))) {            // uniform over the consumers (same tot); rare: the reference's order, one lane
+                cbar(a, misc, W_CBAR, cb, nc, 0x301u);                       // everybody has read red[]
+                if (cw == 0 && lane == 0) {
+                    double sq = 0.0;
+                    for (int i = 0; i < K; ++i) {
+                        float xv;
+                        if (vin.gran) xv = __uint_as_float((uint32_t) __hip_atomic_load(as_global<const unsigned long long>(vin.p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        else xv = as_global<const float>(vin.p)[i];
+                        sq += (double) (xv * xv);
+                    }
+                    red[15] = sq;
+                }
+                cbar(a, misc, W_CBAR, cb, nc, 0x302u);
+                md = red[15] / (double) K; mean = (float) md;
+            }
+            scale = 1.0f / sqrtf(mean + a.eps);
+        }
+        ap.template quantize_batch<BAMD_ACT_BATCH>(scale, K, base, ap_.q8, ap_.S, ap_.yd, nc, nb);
+        if (NORM) break;
+    }
+    cbar(a, misc, W_CBAR, cb, nc, 0x303u);
+    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_ACTREADY); if (a.thin && lane == 0) lds_st(misc + W_GATHERING, 0u); }
+}
+
+// the records j = cw, cw + NC, ... of a piece: slot -> registers -> terms -> term ring
+template <int TYPE>
+__device__ __forceinline__ void wse_records(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw) {
+    typedef typename RecOf<TYPE>::type REC;
+    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
+    const int lane = opaque((int) threadIdx.x & 63), nc = a.nc;
+    const uint32_t nb = op.nb, nrec = op.ntask * nb, ns = (uint32_t) a.ns, tr = (uint32_t) a.tr, nchunk = tr >> 3;
+    const ActPtrs ap = act_ptrs(smem, a, op.actbuf, (int) nb);
+    unsigned char * terms = smem + a.off_terms;
+    // incremental (slot, index in slot, super-block) of record j: no divisions in the loop
+    uint32_t s = (uint32_t) cw / op.rps, r = (uint32_t) cw - s * op.rps, sb = (uint32_t) cw % nb;
+    for (uint32_t j = (uint32_t) cw; j < nrec; j += (uint32_t) nc) {
+        const uint32_t gs = op.gs0 + s, slot = gs % ns;
+        lds_wait<true>(a, misc, misc + W_FILL + slot, gs + 1u, 0x400u);
+        REC R;
+        lds_rec(R, smem + slot * BAMD_WSE_SLOT + r * RECB, lane);
+        pin_rec(R);                                                    // the record is in registers: hand the slot space back (after a slot's last record the loader refills it)
+        if (lane == 0) atomicAdd(misc + W_FREE + slot, 1u);
+        const Terms T = block_terms(R, (int) sb, lane, ap.q8, ap.S, ap.yd);
+        const uint32_t grec = op.grec0 + j, ts = grec % tr;
+        lds_wait<false>(a, misc, misc + W_CHAIN_DONE, grec + 1u - tr, 0x401u);           // term slot ts is free once the chainer has passed record grec - tr
+        unsigned char * t = terms + ts * BAMD_WSE_TERM_BYTES;
+        *(float2 *) (t + lane * 8) = make_float2(T.fs, T.pm);
+        if ((lane & 7) == 0) *(float2 *) (t + 512 + (lane >> 3) * 8) = make_float2(T.d, T.dmin);
+        lds_drain();
+        if (lane == 0) atomicAdd(misc + W_CHUNK + ((grec >> 3) % nchunk), 1u);
+        if (j == (uint32_t) cw && cw == 0) tl_stamp(a, op, BAMD_WSE_TL_FIRSTREC);
+        r += (uint32_t) nc; while (r >= op.rps) { r -= op.rps; ++s; }
+        sb += (uint32_t) nc; while (sb >= nb) sb -= nb;
+    }
+    if (cw == 0) tl_stamp(a, op, BAMD_WSE_TL_LASTREC);
+}
+
+// attention of query head h on consumer waves 0..7 (attn_fused_body): q / k / v of this token come from the QKV granules through an LDS stage
+struct AttnEnvWSE {
+    int tid, wave, nthr;
+    const bamd_wse_args * a; uint32_t * misc; CBar * cb; const float * stage;      // stage: [q hd | k hd | v hd] f32 in LDS
+    __device__ __forceinline__ void sync() const { cbar(*a, misc, W_CBAR8, *cb, 8, 0x500u); }
+    __device__ __forceinline__ float2 qk2(const bamd_attn_args &, int role, int, int, int hd, int rp) const { return *(const float2 *) (stage + (role == 1 ? hd : 0) + 2 * rp); }
+    __device__ __forceinline__ float vel(const bamd_attn_args &, int, int hd, int i) const { return stage[2 * hd + i]; }
+};
+template <int LG>
+__device__ __forceinline__ void wse_attention(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, CBar & cb8, uint32_t tagbase) {
+    constexpr int hd = LG * 64;
+    const int tid = opaque((int) threadIdx.x - 128), lane = tid & 63, h = (int) blockIdx.x, hk = h / a.gq, Hq = a.H, Ekv = (Hq / a.gq) * hd;
+    unsigned char * scratch = smem + a.off_attn;
+    const int ld = a.at.lds_ld;
+    float * stage = (float *) (scratch + (size_t) ld * 8);
+    if (cw == 0) tl_stamp(a, op, BAMD_WSE_TL_GATHER0);
+    {   // q head h | k head hk | v head hk of the QKV vector: 3 hd granules, thread t takes t and t + 512
+        const bamd_wse_vec vin = a.vec[op.in_vec];
+        const uint32_t tag = tagbase | op.in_tag;
+        const unsigned long long * g = as_global<const unsigned long long>(vin.p);
+        int idx[2]; bool use[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + u * 512; use[u] = t < 3 * hd;
+            const int tt = use[u] ? t : 0, part = tt / hd, d = tt - part * hd;
+            idx[u] = part == 0 ? h * hd + d : part == 1 ? Hq * hd + hk * hd + d : Hq * hd + Ekv + hk * hd + d;
+        }
+        uint32_t val[2] = { 0u, 0u };
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned long long x = __hip_atomic_load(g + idx[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                val[u] = (uint32_t) x; ok = ok && (!use[u] || (uint32_t) (x >> 32) == tag);
+            }
+            if (__all(ok)) break;
+            if (spins > WSE_SPINS_GLB || lds_ld(misc + W_ABORT) || (spins & 255u) == 255u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (spins > WSE_SPINS_GLB) wse_fail(a, misc, 0x210u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (use[u]) stage[tid + u * 512] = __uint_as_float(val[u]);
+    }
+    cbar(a, misc, W_CBAR8, cb8, 8, 0x501u);
+    if (cw == 0) tl_stamp(a, op, BAMD_WSE_TL_ACTREADY);
+    bamd_attn_args at = a.at;
+    at.kc = as_global<unsigned short>(a.kc[op.layer]); at.vc = as_global<unsigned short>(a.vc[op.layer]);
+    AttnEnvWSE env; env.tid = tid; env.wave = cw; env.nthr = 512; env.a = &a; env.misc = misc; env.cb = &cb8; env.stage = stage;
+    attn_fused_body<LG, true, AttnEnvWSE>(at, a.gq, h, 0, scratch, as_global<uint32_t>(a.vec[op.out_vec].p), tagbase | op.out_tag, env);
+    if (cw == 0) tl_stamp(a, op, BAMD_WSE_TL_PUBLISHED);
+}
+
+template <int LG>
+__device__ __forceinline__ void wse_consumer(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc, int cw) {
+    CBar cb, cb8;
+    const uint32_t tagbase = wse_tagbase(a.st);
+    for (int io = 0;; ++io) {
+        const bamd_wse_op op = ops[io];
+        if (op.kind == BAMD_WSE_END) break;
+        if (op.kind == BAMD_WSE_ATTN) {
+            if ((int) blockIdx.x < a.H && cw < 8) {
+                lds_wait<false>(a, misc, misc + W_CHAIN_DONE, op.grec0, 0x402u);        // the attention scratch aliases the term ring: the chainer must be through
+                if (LG > 0) wse_attention<(LG > 0 ? LG : 1)>(a, op, smem, misc, cw, cb8, tagbase);
+            }
+            continue;
+        }
+        if (op.act & BAMD_WSE_ACT_GATHER) {
+            if (op.act & BAMD_WSE_ACT_NORM) wse_gather<true>(a, op, smem, misc, cw, cb, tagbase);
+            else wse_gather<false>(a, op, smem, misc, cw, cb, tagbase);
+        }
+        if (op.type == BAMD_Q4_K) wse_records<BAMD_Q4_K>(a, op, smem, misc, cw);
+        else if (op.type == BAMD_Q5_K) wse_records<BAMD_Q5_K>(a, op, smem, misc, cw);
+        else wse_records<BAMD_Q6_K>(a, op, smem, misc, cw);
+    }
+}
+
+// ---- CHAINER -----------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float vec_value(const bamd_wse_args & a, const bamd_wse_vec & v, uint32_t row, uint32_t tag, uint32_t * misc, uint32_t code) {
+    if (!v.gran) return as_global<const float>(v.p)[row];
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long x = __hip_atomic_load(as_global<const unsigned long long>(v.p) + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t) (x >> 32) == tag) return __uint_as_float((uint32_t) x);
+        if (spins > WSE_SPINS_GLB || lds_ld(misc + W_ABORT)) { if (spins > WSE_SPINS_GLB) wse_fail(a, misc, code); return 0.f; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ void vec_store(const bamd_wse_vec & v, uint32_t row, float val, uint32_t tag) {
+    if (v.gran) __hip_atomic_store(as_global<unsigned long long>(v.p) + row, ((unsigned long long) tag << 32) | __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else as_global<float>(v.p)[row] = val;
+}
+template <int TYPE>
+__device__ __forceinline__ void wse_chain_piece(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, uint32_t tagbase, unsigned long long & best) {
+    const int lane = opaque((int) threadIdx.x & 63), r8 = lane >> 3;
+    const uint32_t nb = op.nb, tr = (uint32_t) a.tr, nchunk = tr >> 3;
+    unsigned char * terms = smem + a.off_terms;
+    float * stash = (float *) ((unsigned char *) misc + W_STASH_BYTES);
+    const bamd_wse_vec vout = a.vec[op.out_vec];
+    // residual rows of all tasks, fetched now: old by the time the first chain ends
+    float resv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (op.epi == BAMD_WSE_EPI_ADD) {
+        const bamd_wse_vec vr = a.vec[op.res_vec];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t row = op.row0 + (uint32_t) t * 8u + (uint32_t) r8;
+            if ((uint32_t) t < op.ntask && row < op.nvalid && (lane & 7) == 0) resv[t] = vec_value(a, vr, row, tagbase | op.res_tag, misc, 0x600u);
+        }
+    }
+    uint32_t grec = op.grec0;
+    for (uint32_t t = 0; t < op.ntask; ++t) {
+        RowAcc A = { 0.f, 0.f };
+        for (uint32_t c = 0; c < nb; c += 8, grec += 8) {
+            const uint32_t ck = (grec >> 3) % nchunk, ts0 = grec % tr;
+            lds_wait<true>(a, misc, misc + W_CHUNK + ck, 8u, 0x601u);
+            float2 fp[8], dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned char * p = terms + (ts0 + u) * BAMD_WSE_TERM_BYTES;
+                fp[u] = *(const float2 *) (p + lane * 8); dd[u] = *(const float2 *) (p + 512 + r8 * 8);
+            }
+            lds_drain();
+            lds_st(misc + W_CHUNK + ck, 0u);
+            asm volatile("" ::: "memory");
+            lds_st(misc + W_CHAIN_DONE, grec + 8u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dd[u].x, fp[u].x, dd[u].y, fp[u].y);
+            if (t == 0 && c == 0) tl_stamp(a, op, BAMD_WSE_TL_CHAIN0);
+        }
+        const float val = finish_row<TYPE>(A);
+        const uint32_t row = op.row0 + t * 8u + (uint32_t) r8;
+        if ((lane & 7) == 0 && row < op.nvalid) {
+            if (op.epi == BAMD_WSE_EPI_GATE) stash[t * 8u + (uint32_t) r8] = val;
+            else {
+                float o = val;
+                if (op.epi == BAMD_WSE_EPI_ADD) { float rv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) rv = (uint32_t) k == t ? resv[k] : rv;
+                    o = val + rv; }
+                else if (op.epi == BAMD_WSE_EPI_UP) o = v_silu(stash[t * 8u + (uint32_t) r8]) * val;
+                vec_store(vout, row, o, tagbase | op.out_tag);
+                if (op.epi == BAMD_WSE_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, (int) row); best = k > best ? k : best; }
+            }
+        }
+    }
+    tl_stamp(a, op, BAMD_WSE_TL_PUBLISHED);
+}
+__device__ __forceinline__ void wse_chainer(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc) {
+    const uint32_t tagbase = wse_tagbase(a.st);
+    unsigned long long best = 0ull; bool any_best = false;
+    for (int io = 0;; ++io) {
+        const bamd_wse_op op = ops[io];
+        if (op.kind == BAMD_WSE_END) break;
+        if (op.kind != BAMD_WSE_MATVEC) continue;
+        if (op.type == BAMD_Q4_K) wse_chain_piece<BAMD_Q4_K>(a, op, smem, misc, tagbase, best);
+        else if (op.type == BAMD_Q5_K) wse_chain_piece<BAMD_Q5_K>(a, op, smem, misc, tagbase, best);
+        else wse_chain_piece<BAMD_Q6_K>(a, op, smem, misc, tagbase, best);
+        any_best = any_best || op.epi == BAMD_WSE_EPI_ARGMAX;
+    }
+    if (any_best && a.best_key) {
+        // wave maximum of the keys (64-bit), then one atomic per CU
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = ((unsigned long long) (uint32_t) __shfl_xor((int) (uint32_t) (best >> 32), off) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) best, off);
+            best = o > best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0 && best) atomicMax(a.best_key, best);
+    }
+}
+
+// LG = head_dim / 64 of the attention role (0: a program without attention ops): one instance per head size, so that the register budget of a
+// launch (16 waves per CU: 128 VGPRs) is that of ITS attention body, not of the largest
+// MAXT = threads per workgroup the instance is compiled for: 768 (loader + chainer + up to 10 consumers: 3 waves per SIMD, 168 VGPRs — what the
+// attention body of head_dim 128 needs without spilling) or 1024 (up to 14 consumers, 128 VGPRs)
+template <int LG, int MAXT>
+__global__ void __launch_bounds__(MAXT) wse_kernel(const bamd_wse_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t * misc = (uint32_t *) (smem + a.off_misc);
+    for (int i = (int) threadIdx.x; i < BAMD_WSE_MISC_BYTES / 4; i += (int) blockDim.x) misc[i] = 0u;
+    __syncthreads();
+    const bamd_wse_op * ops = a.ops + (size_t) blockIdx.x * a.ops_per_cu;
+    const int wave = wave_id();
+    if (wave == 0) wse_loader(a, ops, smem, misc);
+    else if (wave == 1) wse_chainer(a, ops, smem, misc);
+    else if (wave - 2 < a.nc) wse_consumer<LG>(a, ops, smem, misc, wave - 2);
+}
+
+// hardware facts the loader relies on, probed once on the device (bamd_wse_selftest): an LDS-DMA destination above 64 KiB (M0 carries the full
+// LDS byte address), and what the instruction's offset field moves (global address only, or the LDS address as well).
+// src: u32 word i holds i.  out[0]: words correct of 256 at LDS 100 KiB; out[1..4]: for offset:1024 with M0 = 8 KiB and source byte 4096: the first
+// word found at LDS 8 KiB, at 9 KiB (0xffffffff = untouched) — word 1280 there means the offset moved both addresses.
+__global__ void wse_selftest_kernel(const uint8_t * src, uint32_t * out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    uint32_t * w = (uint32_t *) smem;
+    for (int i = lane; i < 160 * 256; i += 64) w[i] = 0xffffffffu;
+    __syncthreads();
+    const uint32_t base = (uint32_t) (size_t) (wse_lds_vp) smem;
+    dma1k(src + lane * 16, base + 100u * 1024u);
+    {
+        const uint8_t * p = src + 4096 + lane * 16; const uint32_t dst = (uint32_t) __builtin_amdgcn_readfirstlane((int) (base + 8192u));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:1024 nt" :: "v"(p), "s"(dst) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int ok = 0;
+    for (int i = lane; i < 256; i += 64) ok += w[100 * 256 + i] == (uint32_t) i ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) ok += __shfl_xor(ok, off);
+    if (lane == 0) { out[0] = (uint32_t) ok; out[1] = w[8192 / 4]; out[2] = w[9216 / 4]; out[3] = w[8192 / 4 + 255]; out[4] = w[9216 / 4 + 255]; out[5] = base; }
+}
+int bamd_wse_selftest_launch(const uint8_t * src, uint32_t * out, hipStream_t s) {
+    if (hipFuncSetAttribute((const void *) wse_selftest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void) hipGetLastError(); return 1; }
+    hipLaunchKernelGGL(wse_selftest_kernel, dim3(1), dim3(64), 160 * 1024, s, src, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int bamd_launch_wse(const bamd_wse_args & a, int n_cu, size_t lds_bytes, hipStream_t s) {
+    if (a.ns < 3 || a.ns > BAMD_WSE_MAX_SLOTS || a.tr < 8 || a.tr > BAMD_WSE_MAX_TERMS || (a.tr & 7) || a.nc < 8 || a.nc > 14) return 1;
+    const int lg = a.H > 0 ? a.at.hd >> 6 : 0;
+    if (lg < 0 || lg > 4 || (a.H > 0 && (a.at.hd & 63))) return 1;
+    const int big = a.nc > 10 ? 1 : 0;
+    static bool attr_set[2][5] = { { false, false, false, false, false }, { false, false, false, false, false } };
+    const dim3 grid(n_cu), block(64 * (2 + a.nc));
+#define WSE_GO(LG_, MT_) do { \
+        if (!attr_set[big][lg]) { \
+            if (hipFuncSetAttribute((const void *) wse_kernel<LG_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void) hipGetLastError(); return 1; } \
+            attr_set[big][lg] = true; \
+        } \
+        hipLaunchKernelGGL((wse_kernel<LG_, MT_>), grid, block, lds_bytes, s, a); } while (0)
+#define WSE_GO_LG(MT_) do { switch (lg) { case 0: WSE_GO(0, MT_); break; case 1: WSE_GO(1, MT_); break; case 2: WSE_GO(2, MT_); break; case 3: WSE_GO(3, MT_); break; default: WSE_GO(4, MT_); break; } } while (0)
+    if (big) WSE_GO_LG(1024); else WSE_GO_LG(768);
+#undef WSE_GO_LG
+#undef WSE_GO
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
