@@ -551,6 +551,7 @@ static int wse_init(bamd_context * c) {
     if (m->hd % 64 || m->hd > 256) { w.why = "head_dim not 64 / 128 / 192 / 256"; return 1; }
     const size_t attn_lds = (size_t) ld * 8 + (size_t) 3 * m->hd * 4;
     if (bamd_wse_plan_build(&w.plan, L.data(), 0, nl, m->n_cu, m->E, m->H, m->Hkv, m->hd, m->F, nullptr, 0, m->V, attn_lds, g_wse_nc, BAMD_WSE_LDS_LIMIT)) { w.why = w.plan.why; return 1; }
+    if (bamd_wse_setup(m->hd)) { w.why = "the device refused the engine kernel's LDS size"; return 1; }
     const size_t ob = (size_t) w.plan.n_cu * w.plan.ops_per_cu * sizeof(bamd_wse_op);
     if (dev_alloc(c->allocs, (void **) &w.d_ops, ob)) return 1;
     HIPC(hipMemcpy(w.d_ops, w.plan.ops, ob, hipMemcpyHostToDevice));
@@ -1382,6 +1383,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_wse_matvec(int typ
     a.vec[BAMD_WSE_V_XIN] = { dx, (uint32_t) k, 0 }; a.vec[BAMD_WSE_V_X2] = { dres, (uint32_t) nrows, 0 };
     a.vec[BAMD_WSE_V_XOUT] = { dy, (uint32_t) nrows, 0 }; a.vec[BAMD_WSE_V_LOGITS] = { dy, (uint32_t) nrows, 0 };
     a.st = st; a.err = err; a.tl = dtl; a.tl_ops = plan.tl_ops; a.best_key = &st->best_key; a.eps = eps; a.thin = thin;
+    if (bamd_wse_setup(0)) return fail("weight-stream engine: the device refused the kernel's LDS size");
     if (bamd_launch_wse(a, n_cu, plan.lds_bytes, nullptr)) return fail("weight-stream engine: launch refused");
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());

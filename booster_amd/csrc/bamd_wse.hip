@@ -467,19 +467,29 @@ int bamd_wse_selftest_launch(const uint8_t * src, uint32_t * out, hipStream_t s)
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// the engine kernels use more dynamic LDS than the default limit: raise it once per instance (160 KiB less the static arrays of attn_fused_body:
+// BAMD_WSE_LDS_LIMIT of the planner).  Not allowed while a stream is being captured, so the
+// host calls this when it plans (head_dim = 0: programs without attention ops)
+static bool g_wse_attr[2][5] = { { false, false, false, false, false }, { false, false, false, false, false } };
+int bamd_wse_setup(int head_dim) {
+    const int lg = head_dim >> 6;
+    if (lg < 0 || lg > 4 || (head_dim & 63)) return 1;
+#define WSE_ATTR(LG_) do { \
+        if (!g_wse_attr[0][LG_] && hipFuncSetAttribute((const void *) wse_kernel<LG_, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2560) != hipSuccess) { (void) hipGetLastError(); return 1; } \
+        if (!g_wse_attr[1][LG_] && hipFuncSetAttribute((const void *) wse_kernel<LG_, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2560) != hipSuccess) { (void) hipGetLastError(); return 1; } \
+        g_wse_attr[0][LG_] = g_wse_attr[1][LG_] = true; } while (0)
+    switch (lg) { case 0: WSE_ATTR(0); break; case 1: WSE_ATTR(1); break; case 2: WSE_ATTR(2); break; case 3: WSE_ATTR(3); break; default: WSE_ATTR(4); break; }
+#undef WSE_ATTR
+    return 0;
+}
 int bamd_launch_wse(const bamd_wse_args & a, int n_cu, size_t lds_bytes, hipStream_t s) {
     if (a.ns < 3 || a.ns > BAMD_WSE_MAX_SLOTS || a.tr < 8 || a.tr > BAMD_WSE_MAX_TERMS || (a.tr & 7) || a.nc < 8 || a.nc > 14) return 1;
     const int lg = a.H > 0 ? a.at.hd >> 6 : 0;
     if (lg < 0 || lg > 4 || (a.H > 0 && (a.at.hd & 63))) return 1;
     const int big = a.nc > 10 ? 1 : 0;
-    static bool attr_set[2][5] = { { false, false, false, false, false }, { false, false, false, false, false } };
+    if (!g_wse_attr[big][lg]) return 1;                 // bamd_wse_setup(head_dim) must have run (outside any stream capture)
     const dim3 grid(n_cu), block(64 * (2 + a.nc));
-#define WSE_GO(LG_, MT_) do { \
-        if (!attr_set[big][lg]) { \
-            if (hipFuncSetAttribute((const void *) wse_kernel<LG_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void) hipGetLastError(); return 1; } \
-            attr_set[big][lg] = true; \
-        } \
-        hipLaunchKernelGGL((wse_kernel<LG_, MT_>), grid, block, lds_bytes, s, a); } while (0)
+#define WSE_GO(LG_, MT_) hipLaunchKernelGGL((wse_kernel<LG_, MT_>), grid, block, lds_bytes, s, a)
 #define WSE_GO_LG(MT_) do { switch (lg) { case 0: WSE_GO(0, MT_); break; case 1: WSE_GO(1, MT_); break; case 2: WSE_GO(2, MT_); break; case 3: WSE_GO(3, MT_); break; default: WSE_GO(4, MT_); break; } } while (0)
     if (big) WSE_GO_LG(1024); else WSE_GO_LG(768);
 #undef WSE_GO_LG
