@@ -277,7 +277,7 @@ def op_ffn_gate_up(ttype, wg_raw, wu_raw, nrows, k, x, norm_w=None, eps=0.0):
 WSE_EPI_STORE, WSE_EPI_ADD, WSE_EPI_GATE, WSE_EPI_UP, WSE_EPI_ARGMAX = 0, 1, 2, 3, 4
 
 
-def op_wse_matvec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, w_up_raw=None, nc=10, thin=0, n_cu=0, timeline=False):
+def op_wse_matvec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, w_up_raw=None, nc=10, thin=0, n_cu=0, timeline=False, nch=1):
     """y = W . Q8_K(x) through the weight-stream engine kernel (csrc/bamd_wse.hip) as a one-piece program; with w_up_raw: silu(Wg a) * (Wu a).
     Returns (y, info) or (y, info, stamps); info = [n_cu, ring slots, term records, ops per CU, LDS bytes, err0..3]"""
     w_raw = np.ascontiguousarray(w_raw, np.uint8); x = np.ascontiguousarray(x, np.float32)
@@ -287,7 +287,7 @@ def op_wse_matvec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None
     y = np.zeros(nrows, np.float32); info = np.zeros(16, np.int32)
     tl = np.zeros((512, 2, 8), np.uint64) if timeline else None
     epi = WSE_EPI_ADD if residual is not None else WSE_EPI_STORE
-    _chk(lib().bamd_op_wse_matvec(ttype, _p(w_raw), _p(wu), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y), epi, nc, thin, n_cu, _p(tl), _p(info)))
+    _chk(lib().bamd_op_wse_matvec(ttype, _p(w_raw), _p(wu), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y), epi, nc, int(thin) | (256 if nch == 2 else 0), n_cu, _p(tl), _p(info)))
     if timeline:
         n = int(info[0]); pieces = 2 if wu is not None else 1
         return y, info, tl.reshape(-1)[:n * pieces * 8].reshape(n, pieces, 8)

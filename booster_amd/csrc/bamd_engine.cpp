@@ -35,8 +35,9 @@ static int fail(const std::string & m) { g_err = m; return 1; }
 // the weight-stream engine (bamd_wse.h): the layers of a decode step as ONE persistent launch.  BAMD_WSE=0 / 1 overrides the default;
 // BAMD_WSE_NC = consumer waves per CU (8..14), BAMD_WSE_THIN=1 keeps one fill outstanding while a CU gathers
 static int g_wse = [] { const char * e = getenv("BAMD_WSE"); return e ? atoi(e) : 0; }();
-static int g_wse_nc = [] { const char * e = getenv("BAMD_WSE_NC"); const int v = e ? atoi(e) : 12; return v < 8 ? 8 : v > 14 ? 14 : v; }();
+static int g_wse_nc = [] { const char * e = getenv("BAMD_WSE_NC"); const int v = e ? atoi(e) : 10; return v < 8 ? 8 : v > 14 ? 14 : v; }();
 static int g_wse_thin = [] { const char * e = getenv("BAMD_WSE_THIN"); return e ? atoi(e) : 0; }();
+static int g_wse_nch = [] { const char * e = getenv("BAMD_WSE_NCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 2 ? 2 : v; }();
 #define BAMD_WSE_LDS_LIMIT (160 * 1024 - 2560)      /* dynamic LDS the engine may plan with: 160 KiB less the static arrays of attn_fused_body (2144 B) */
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
@@ -566,7 +567,7 @@ static int wse_init(bamd_context * c) {
 static void wse_fill_args(bamd_context * c, bamd_wse_args & a) {
     bamd_model * m = c->m; bamd_context::Wse & w = c->wse;
     memset(&a, 0, sizeof a);
-    a.ops = w.d_ops; a.ops_per_cu = w.plan.ops_per_cu; a.ns = w.plan.ns; a.tr = w.plan.tr; a.nc = w.plan.nc;
+    a.ops = w.d_ops; a.ops_per_cu = w.plan.ops_per_cu; a.ns = w.plan.ns; a.tr = w.plan.tr; a.nc = w.plan.nc; a.nch = g_wse_nch;
     a.off_act[0] = w.plan.off_act[0]; a.off_act[1] = w.plan.off_act[1]; a.off_terms = w.plan.off_terms; a.off_misc = w.plan.off_misc; a.off_attn = w.plan.off_attn;
     const uint32_t Ekv = (uint32_t) (m->Hkv * m->hd);
     a.vec[BAMD_WSE_V_XIN] = { c->x, (uint32_t) m->E, 0 };
@@ -1378,7 +1379,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_wse_matvec(int typ
     if (!dops || (tl && !dtl)) return fail("device alloc/copy failed");
     if (dtl) HIPC(hipMemset(dtl, 0, (size_t) n_cu * plan.tl_ops * 64));
     bamd_wse_args a; memset(&a, 0, sizeof a);
-    a.ops = dops; a.ops_per_cu = plan.ops_per_cu; a.ns = plan.ns; a.tr = plan.tr; a.nc = plan.nc;
+    a.ops = dops; a.ops_per_cu = plan.ops_per_cu; a.ns = plan.ns; a.tr = plan.tr; a.nc = plan.nc; a.nch = thin >> 8 ? 2 : 1; thin &= 255;
     a.off_act[0] = plan.off_act[0]; a.off_act[1] = plan.off_act[1]; a.off_terms = plan.off_terms; a.off_misc = plan.off_misc; a.off_attn = plan.off_attn;
     a.vec[BAMD_WSE_V_XIN] = { dx, (uint32_t) k, 0 }; a.vec[BAMD_WSE_V_X2] = { dres, (uint32_t) nrows, 0 };
     a.vec[BAMD_WSE_V_XOUT] = { dy, (uint32_t) nrows, 0 }; a.vec[BAMD_WSE_V_LOGITS] = { dy, (uint32_t) nrows, 0 };

@@ -48,7 +48,7 @@ struct bamd_wse_op {
     uint32_t row0;         // output row of task 0, lane row 0 (index into the out / residual vectors)
     uint32_t nvalid;       // rows >= nvalid are padding of the stream: never stored
     uint32_t gs0;          // global slot number of the piece's first slot (slots count over the CU's whole program)
-    uint32_t rps;          // records per slot (the last slot of the piece may hold fewer)
+    uint32_t rps;          // records per slot (the last slot of the piece may hold fewer); ATTN: the MATVEC pieces before this op in the CU's program
     uint32_t grec0;        // global record number of the piece's first record (a multiple of 8)
     uint8_t act;           // BAMD_WSE_ACT_* bits
     uint8_t actbuf;        // which of the two LDS activation buffers
@@ -66,7 +66,7 @@ struct bamd_wse_vec { void * p; uint32_t n; uint32_t gran; };     // gran: 1 = 8
 struct bamd_wse_args {
     const bamd_wse_op * ops;           // [n_cu][ops_per_cu]
     int ops_per_cu;
-    int ns, tr, nc;                    // ring slots, term-ring records (multiple of 8), consumer waves
+    int ns, tr, nc, nch;               // ring slots, term-ring records (a power of two), consumer waves, chainer waves (1 or 2)
     uint32_t off_act[2], off_terms, off_misc, off_attn;   // LDS byte offsets (16-byte multiples): activation buffers, term ring, control words, attention scratch
     bamd_wse_vec vec[BAMD_WSE_NVEC];
     const bamd_step_state * st;

@@ -3,10 +3,11 @@
 // chain_step() / finish_row() of bamd_device.h — the code the launch kernels run — so every output is the launch path's, bit for bit.
 //
 // Intra-CU hand-overs are LDS words (the LDS of a CU is one in-order unit: a wave's data writes are visible before its later flag write):
-//   fill[slot]   = global slot number + 1 once the slot's DMA has landed            (loader -> consumers)
+//   filled       = number of slots whose DMA has landed, in program order             (loader -> consumers; slot g lives at ring position g % ns)
 //   freec[slot] += 1 per record copied out of the slot into registers               (consumers -> loader; monotonic)
-//   chunk[c]    += 1 per record parked in term chunk c (8 records)                  (consumers -> chainer; the chainer resets it)
-//   chain_done   = records chained so far                                           (chainer -> consumers: term slots free below chain_done + tr)
+//   chunk[c]    += 1 per record parked in term chunk c (8 records)                  (consumers -> chainers; the chainer that owns the chunk resets it)
+//   rel[c]       = how many times term chunk c has been read and handed back        (chainers -> consumers: record g may be parked when rel >= g / tr)
+//   pieces[k]    = pieces chainer k has finished                                    (chainers -> consumers: the attention scratch aliases the term ring)
 //   cbar / cbar8 = counting barriers among the consumer waves (all of them / the eight that run an attention head)
 // Inter-CU hand-overs are 8-byte {value, tag} granules, one sc1 store each, re-read with sc1 loads until every tag matches
 // (cdna_hip_programming.md, Guideline 16 R2); tag = (host serial, device step, consumer layer) is unique among consecutive uses of a word.
@@ -17,7 +18,7 @@
 #define WSE_SPINS_LDS (1u << 21)       /* bounded waits: ~0.2 s of LDS polling / ~1 s of granule polling, then give up (err) and run on */
 #define WSE_SPINS_GLB (1u << 20)
 
-enum { W_FILL = 0, W_FREE = 16, W_EXPECT = 32, W_CHAIN_DONE = 48, W_CBAR = 49, W_CBAR8 = 50, W_ABORT = 51, W_GATHERING = 52, W_CHUNK = 64,
+enum { W_FILL = 0, W_FREE = 16, W_EXPECT = 32, W_CHAIN_DONE = 48, W_CBAR = 49, W_CBAR8 = 50, W_ABORT = 51, W_GATHERING = 52, W_FILLED = 53, W_PIECES = 56, W_CHUNK = 64, W_REL = 80,
        W_RED_BYTES = 384, W_STASH_BYTES = 512 };       /* words of the control block; red: 16 doubles; stash: BAMD_WSE_STASH floats */
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t * w) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
@@ -48,9 +49,21 @@ template <typename T> __device__ __forceinline__ T * as_global(uint64_t p) { ret
 // of that loop and keeps them all live through the attention body (204 VGPRs instead of ~110).  An opaque copy of the lane / thread id at the entry
 // of each role keeps its arithmetic inside the role.
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// monotonic counter: wait until (int) (*w - want) >= 0; returns the value seen (callers cache it: the next few waits need no LDS round trip)
+__device__ __forceinline__ uint32_t lds_wait_ge(const bamd_wse_args & a, uint32_t * misc, const uint32_t * w, uint32_t want, uint32_t code) {
+    uint32_t v;
+    for (unsigned spins = 0;; ++spins) {
+        v = lds_ld(w);
+        if ((int) (v - want) >= 0) break;
+        if (spins > WSE_SPINS_LDS || lds_ld(misc + W_ABORT)) { if (spins > WSE_SPINS_LDS) wse_fail(a, misc, code); v = want; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return v;
+}
 struct CBar { uint32_t target = 0; };
 __device__ __forceinline__ void cbar(const bamd_wse_args & a, uint32_t * misc, int word, CBar & b, int n, uint32_t code) {
-    lds_drain();
+    asm volatile("" ::: "memory");           // the wave's earlier LDS writes reach the LDS before its arrival (in-order unit): no hardware wait needed
     if ((threadIdx.x & 63) == 0) atomicAdd(misc + word, 1u);
     b.target += (uint32_t) n;
     lds_wait<false>(a, misc, misc + word, b.target, code);
@@ -74,9 +87,9 @@ __device__ __forceinline__ void wse_loader(const bamd_wse_args & a, const bamd_w
     const uint32_t ring0 = (uint32_t) (size_t) (wse_lds_vp) smem;
     const uint32_t ns = (uint32_t) a.ns;
     uint32_t gs = 0, slot = 0;            // next slot to issue (global number, ring position)
-    uint32_t pub = 0, pslot = 0;          // next slot to publish
+    uint32_t pub = 0;                     // slots published so far
     auto publish_to = [&](uint32_t upto) {        // everything below `upto` has landed
-        while (pub < upto) { lds_st(misc + W_FILL + pslot, pub + 1u); ++pub; pslot = pslot + 1u == ns ? 0u : pslot + 1u; }
+        if (pub < upto) { pub = upto; lds_st(misc + W_FILLED, pub); }
     };
     for (int io = 0;; ++io) {
         const bamd_wse_op op = ops[io];
@@ -100,11 +113,11 @@ __device__ __forceinline__ void wse_loader(const bamd_wse_args & a, const bamd_w
                 const uint32_t k = i < nld ? i : nld - 1u;
                 dma1k(p + (size_t) k * 1024u, dst + k * 1024u);
             }
-            if (a.thin && lds_ld(misc + W_GATHERING)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish_to(gs + 1u); }
-            else { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (gs >= 2u) publish_to(gs - 1u); }       // two fills may be in flight
+            if ((a.thin & 1) && lds_ld(misc + W_GATHERING)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish_to(gs + 1u); }
+            else { asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); if (gs >= 3u) publish_to(gs - 2u); }       // three fills (48 KiB per CU, 12 MiB on the chip) may be in flight
             slot = slot + 1u == ns ? 0u : slot + 1u;
         }
-        tl_stamp(a, op, BAMD_WSE_TL_LOADED);
+        if (!(a.thin & 2)) tl_stamp(a, op, BAMD_WSE_TL_LOADED);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     publish_to(gs);
@@ -139,8 +152,9 @@ __device__ __forceinline__ bamd_rsrc vec_rsrc(const void * base, uint32_t bytes)
 
 // the activation vector of an op -> Q8_K (optionally RMSNorm * weight first) in LDS buffer op.actbuf, by all NC consumer waves:
 // consumer cw takes the blocks cw, cw + NC, ... in batches of BAMD_ACT_BATCH.  Arithmetic: ActPro::quantize_batch and the sum of ActPro::finish.
-template <bool NORM>
+template <bool NORM, int NB, int NBAT>
 __device__ __forceinline__ void wse_gather(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, CBar & cb, uint32_t tagbase) {
+    static_assert(!NORM || NBAT == 1, "the RMSNorm prologue keeps a wave's whole share in one batch");
     const int lane = opaque((int) threadIdx.x & 63), nc = a.nc, nb = (int) op.nb, K = nb * 256;
     const bamd_wse_vec vin = a.vec[op.in_vec];
     const ActPtrs ap_ = act_ptrs(smem, a, op.actbuf, nb);
@@ -148,108 +162,175 @@ __device__ __forceinline__ void wse_gather(const bamd_wse_args & a, const bamd_w
     const uint32_t tag = tagbase | op.in_tag;
     const bamd_rsrc gr = vec_rsrc(vin.p, vin.n * (vin.gran ? 8u : 4u));
     const float * nw = as_global<const float>(op.normw);
-    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_GATHER0); if (a.thin && lane == 0) lds_st(misc + W_GATHERING, 1u); }
+    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_GATHER0); if ((a.thin & 1) && lane == 0) lds_st(misc + W_GATHERING, 1u); }
     float scale = 1.0f;
-    for (int base = cw; base < nb || (NORM && base == cw); base += BAMD_ACT_BATCH * nc) {
-        ActPro<NORM> ap; ap.okmask = 0;
-        int blk[BAMD_ACT_BATCH];
+    // this wave's blocks: cw + (bt * NB + b) * nc — ALL of them requested in one sweep (a second batch behind the first quantisation would cost a
+    // second memory round trip), quantised batch by batch
+  for (int first = cw; first < nb || first == cw; first += NB * NBAT * nc) {        // (one sweep unless a wave's share exceeds NB * NBAT blocks: 70B ffn_down)
+    ActPro<NORM> ap[NBAT];
+    int blk[NBAT][NB];
 #pragma unroll
-        for (int b = 0; b < BAMD_ACT_BATCH; ++b) { const int i = base + b * nc; const bool ok = i < nb; ap.okmask |= ok ? 1 << b : 0; blk[b] = ok ? i : nb - 1; }
-        if (NORM) {
+    for (int bt = 0; bt < NBAT; ++bt) {
+        ap[bt].okmask = 0;
 #pragma unroll
-            for (int b = 0; b < BAMD_ACT_BATCH; ++b) ap.w[b] = *(const float4 *) (nw + blk[b] * 256 + lane * 4);
-        }
-        if (vin.gran) {
-            for (unsigned spins = 0;; ++spins) {
-                asm volatile("" ::: "memory");
-                bool ok = true;
+        for (int b = 0; b < NB; ++b) { const int i = first + (bt * NB + b) * nc; const bool ok = i < nb; ap[bt].okmask |= ok ? 1 << b : 0; blk[bt][b] = ok ? i : nb - 1; }
+    }
+    if (NORM) {
 #pragma unroll
-                for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
-                    const uint32_t off = (uint32_t) (blk[b] * 256 + lane * 4) * 8u;
+        for (int b = 0; b < NB; ++b) ap[0].w[b] = *(const float4 *) (nw + blk[0][b] * 256 + lane * 4);
+    }
+    if (vin.gran) {
+        for (unsigned spins = 0;; ++spins) {
+            asm volatile("" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int bt = 0; bt < NBAT; ++bt)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const uint32_t off = (uint32_t) (blk[bt][b] * 256 + lane * 4) * 8u;
                     const uint4 g0 = gran2(gr, off), g1 = gran2(gr, off + 16u);
-                    ap.v[b] = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.z), __uint_as_float(g1.x), __uint_as_float(g1.z));
+                    ap[bt].v[b] = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.z), __uint_as_float(g1.x), __uint_as_float(g1.z));
                     ok = ok && g0.y == tag && g0.w == tag && g1.y == tag && g1.w == tag;
                 }
-                if (__all(ok)) break;
-                if (spins > WSE_SPINS_GLB || lds_ld(misc + W_ABORT) || (spins & 255u) == 255u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    if (spins > WSE_SPINS_GLB) wse_fail(a, misc, 0x200u | op.in_vec);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
+            if (__all(ok)) break;
+            if (spins > WSE_SPINS_GLB || lds_ld(misc + W_ABORT) || ((spins & 255u) == 255u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (spins > WSE_SPINS_GLB) wse_fail(a, misc, 0x200u | op.in_vec);
+                break;
             }
-        } else {
-#pragma unroll
-            for (int b = 0; b < BAMD_ACT_BATCH; ++b) ap.v[b] = *(const float4 *) (as_global<const float>(vin.p) + blk[b] * 256 + lane * 4);
+            // not there yet: do not sweep the whole share again and again (polling-cost: 2560 waves re-reading 2 - 8 KB each slow every producer down);
+            // watch ONE granule per lane — the last one of each lane's quarter of the first block — and sweep again when those carry the tag
+            for (unsigned sp2 = 0;; ++sp2) {
+                const unsigned long long x = __hip_atomic_load(as_global<const unsigned long long>(vin.p) + blk[0][0] * 256 + lane * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((uint32_t) (x >> 32) == tag) || sp2 > WSE_SPINS_GLB || lds_ld(misc + W_ABORT)) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
-        if (cw == 0 && base == cw) tl_stamp(a, op, BAMD_WSE_TL_VALID);
-        if (NORM) {      // one batch holds the wave's whole share (planner: <= 4 blocks per wave): sum of squares in double, ggml.c:11874-11877
-            double s = 0.0;
+    } else {
 #pragma unroll
-            for (int b = 0; b < BAMD_ACT_BATCH; ++b) {
-                if (ap.okmask >> b & 1) { s += (double) (ap.v[b].x * ap.v[b].x); s += (double) (ap.v[b].y * ap.v[b].y); s += (double) (ap.v[b].z * ap.v[b].z); s += (double) (ap.v[b].w * ap.v[b].w); }
-            }
-            s = wave_sum_f64(s);
-            if (lane == 0) red[cw] = s;
-            cbar(a, misc, W_CBAR, cb, nc, 0x300u);
-            double tot = 0.0;
-            for (int w2 = 0; w2 < nc; ++w2) tot += red[w2];
-            double md = (K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K;
-            float mean = (float) md;
-            if (!f32_rounding_safe(md, BAMD_F64_GUARD_ULPS(K))) {            // uniform over the consumers (same tot); rare: the reference's order, one lane
-                cbar(a, misc, W_CBAR, cb, nc, 0x301u);                       // everybody has read red[]
-                if (cw == 0 && lane == 0) {
-                    double sq = 0.0;
-                    for (int i = 0; i < K; ++i) {
-                        float xv;
-                        if (vin.gran) xv = __uint_as_float((uint32_t) __hip_atomic_load(as_global<const unsigned long long>(vin.p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        else xv = as_global<const float>(vin.p)[i];
-                        sq += (double) (xv * xv);
-                    }
-                    red[15] = sq;
-                }
-                cbar(a, misc, W_CBAR, cb, nc, 0x302u);
-                md = red[15] / (double) K; mean = (float) md;
-            }
-            scale = 1.0f / sqrtf(mean + a.eps);
-        }
-        ap.template quantize_batch<BAMD_ACT_BATCH>(scale, K, base, ap_.q8, ap_.S, ap_.yd, nc, nb);
-        if (NORM) break;
+        for (int bt = 0; bt < NBAT; ++bt)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) ap[bt].v[b] = *(const float4 *) (as_global<const float>(vin.p) + blk[bt][b] * 256 + lane * 4);
     }
+    if (cw == 0 && first == cw) tl_stamp(a, op, BAMD_WSE_TL_VALID);
+    if (NORM) {      // sum of squares in double, ggml.c:11874-11877 (tree here; f32_rounding_safe decides whether the order can matter)
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4 v = ap[0].v[b];
+            if (ap[0].okmask >> b & 1) { s += (double) (v.x * v.x); s += (double) (v.y * v.y); s += (double) (v.z * v.z); s += (double) (v.w * v.w); }
+        }
+        s = wave_sum_f64(s);
+        if (lane == 0) red[cw] = s;
+        cbar(a, misc, W_CBAR, cb, nc, 0x300u);
+        double tot = 0.0;
+        for (int w2 = 0; w2 < nc; ++w2) tot += red[w2];
+        double md = (K & (K - 1)) == 0 ? tot * (1.0 / (double) K) : tot / (double) K;
+        float mean = (float) md;
+        if (!f32_rounding_safe(md, BAMD_F64_GUARD_ULPS(K))) {            // uniform over the consumers (same tot); rare: the reference's order, one lane
+            cbar(a, misc, W_CBAR, cb, nc, 0x301u);                       // everybody has read red[]
+            if (cw == 0 && lane == 0) {
+                double sq = 0.0;
+                for (int i = 0; i < K; ++i) {
+                    float xv;
+                    if (vin.gran) xv = __uint_as_float((uint32_t) __hip_atomic_load(as_global<const unsigned long long>(vin.p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    else xv = as_global<const float>(vin.p)[i];
+                    sq += (double) (xv * xv);
+                }
+                red[15] = sq;
+            }
+            cbar(a, misc, W_CBAR, cb, nc, 0x302u);
+            md = red[15] / (double) K; mean = (float) md;
+        }
+        scale = 1.0f / sqrtf(mean + a.eps);
+    }
+#pragma unroll
+    for (int bt = 0; bt < NBAT; ++bt) ap[bt].template quantize_batch<NB>(scale, K, first + bt * NB * nc, ap_.q8, ap_.S, ap_.yd, nc, nb);
+    if (NORM) break;
+  }
     cbar(a, misc, W_CBAR, cb, nc, 0x303u);
-    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_ACTREADY); if (a.thin && lane == 0) lds_st(misc + W_GATHERING, 0u); }
+    if (cw == 0) { tl_stamp(a, op, BAMD_WSE_TL_ACTREADY); if ((a.thin & 1) && lane == 0) lds_st(misc + W_GATHERING, 0u); }
+}
+// blocks per wave and batch: the share of a wave (ceil(nb / nc)) in as few equal batches of <= 4 as possible
+__device__ __forceinline__ void wse_gather_any(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, CBar & cb, uint32_t tagbase) {
+    const int share = ((int) op.nb + a.nc - 1) / a.nc, nbat = (share + 3) / 4, per = (share + nbat - 1) / nbat;
+#define WSE_G(N_, NB_, NBAT_) wse_gather<N_, NB_, NBAT_>(a, op, smem, misc, cw, cb, tagbase)
+    if (op.act & BAMD_WSE_ACT_NORM) {
+        switch (per) { case 1: WSE_G(true, 1, 1); break; case 2: WSE_G(true, 2, 1); break; case 3: WSE_G(true, 3, 1); break; default: WSE_G(true, 4, 1); break; }
+    } else if (nbat <= 1) {
+        switch (per) { case 1: WSE_G(false, 1, 1); break; case 2: WSE_G(false, 2, 1); break; case 3: WSE_G(false, 3, 1); break; default: WSE_G(false, 4, 1); break; }
+    } else {
+        switch (per) { case 3: WSE_G(false, 3, 2); break; default: WSE_G(false, 4, 2); break; }       // shares beyond 8 blocks: a second sweep
+    }
+#undef WSE_G
 }
 
-// the records j = cw, cw + NC, ... of a piece: slot -> registers -> terms -> term ring
+// One piece on one consumer wave: the records j = cw, cw + NC, ... : slot -> registers -> terms -> term ring.
+//  * the wave's FIRST record is read out of the ring BEFORE the activations are gathered (the weights are there long before: that is the point of the
+//    engine), and inside the loop the NEXT record's LDS reads are issued before the terms of the current one are computed;
+//  * the loader's progress counter is cached, so that in the steady state a record costs no flag round trip; the release counter of the term chunk is
+//    requested ahead of the terms and looked at behind them;
+//  * hand-backs need no hardware wait (the LDS serves a wave's instructions in order: a ds_add behind the reads of a record executes after them).
+// Term chunk layout (8 records, 4608 B): [pair p][lane] float4 {fs, pm of record 2p | fs, pm of record 2p + 1}, then [pair p][row] float4 {d, dmin | d, dmin}:
+// the chainer reads a chunk with 8 conflict-free 16-byte reads per lane.
 template <int TYPE>
-__device__ __forceinline__ void wse_records(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw) {
+__device__ __forceinline__ void wse_piece(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, uint32_t & filled, CBar & cb, uint32_t tagbase) {
     typedef typename RecOf<TYPE>::type REC;
     constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
-    const int lane = opaque((int) threadIdx.x & 63), nc = a.nc;
-    const uint32_t nb = op.nb, nrec = op.ntask * nb, ns = (uint32_t) a.ns, tr = (uint32_t) a.tr, nchunk = tr >> 3;
+    const int lane = opaque((int) threadIdx.x & 63);
+    const uint32_t nc = (uint32_t) a.nc, nb = op.nb, nrec = op.ntask * nb, ns = (uint32_t) a.ns, tr = (uint32_t) a.tr, ckm = (tr >> 3) - 1u, rps = op.rps;
+    const uint32_t trs = (uint32_t) (31 - __builtin_clz(tr));
     const ActPtrs ap = act_ptrs(smem, a, op.actbuf, (int) nb);
     unsigned char * terms = smem + a.off_terms;
-    // incremental (slot, index in slot, super-block) of record j: no divisions in the loop
-    uint32_t s = (uint32_t) cw / op.rps, r = (uint32_t) cw - s * op.rps, sb = (uint32_t) cw % nb;
-    for (uint32_t j = (uint32_t) cw; j < nrec; j += (uint32_t) nc) {
-        const uint32_t gs = op.gs0 + s, slot = gs % ns;
-        lds_wait<true>(a, misc, misc + W_FILL + slot, gs + 1u, 0x400u);
-        REC R;
-        lds_rec(R, smem + slot * BAMD_WSE_SLOT + r * RECB, lane);
-        pin_rec(R);                                                    // the record is in registers: hand the slot space back (after a slot's last record the loader refills it)
+    uint32_t j = (uint32_t) cw;
+    const bool any = j < nrec;
+    const bool dbg = (a.thin & 2) && cw == 0 && a.tl;      // experiment builds of the timeline: ticks consumer 0 spends waiting for the loader / the chainer
+    unsigned long long w_fill = 0, w_rel = 0;
+    // (slot of the piece, index in the slot, super-block, ring position) of record j, advanced incrementally: no divisions in the loop
+    uint32_t s = 0, r = 0, sb = 0, slot = 0;
+    REC Rn;
+    if (any) {
+        s = j / rps; r = j - s * rps; sb = j % nb; slot = (op.gs0 + s) % ns;
+        if ((int) (filled - (op.gs0 + s + 1u)) < 0) filled = lds_wait_ge(a, misc, misc + W_FILLED, op.gs0 + s + 1u, 0x400u);
+        lds_rec(Rn, smem + slot * BAMD_WSE_SLOT + r * RECB, lane);
         if (lane == 0) atomicAdd(misc + W_FREE + slot, 1u);
-        const Terms T = block_terms(R, (int) sb, lane, ap.q8, ap.S, ap.yd);
-        const uint32_t grec = op.grec0 + j, ts = grec % tr;
-        lds_wait<false>(a, misc, misc + W_CHAIN_DONE, grec + 1u - tr, 0x401u);           // term slot ts is free once the chainer has passed record grec - tr
-        unsigned char * t = terms + ts * BAMD_WSE_TERM_BYTES;
-        *(float2 *) (t + lane * 8) = make_float2(T.fs, T.pm);
-        if ((lane & 7) == 0) *(float2 *) (t + 512 + (lane >> 3) * 8) = make_float2(T.d, T.dmin);
-        lds_drain();
-        if (lane == 0) atomicAdd(misc + W_CHUNK + ((grec >> 3) % nchunk), 1u);
-        if (j == (uint32_t) cw && cw == 0) tl_stamp(a, op, BAMD_WSE_TL_FIRSTREC);
-        r += (uint32_t) nc; while (r >= op.rps) { r -= op.rps; ++s; }
-        sb += (uint32_t) nc; while (sb >= nb) sb -= nb;
+    }
+    if (op.act & BAMD_WSE_ACT_GATHER) wse_gather_any(a, op, smem, misc, cw, cb, tagbase);
+    if (any) {
+        for (;;) {
+            REC R = Rn;
+            const uint32_t sb_cur = sb, grec = op.grec0 + j, ck = (grec >> 3) & ckm, gen = grec >> trs;
+            const uint32_t relv = __hip_atomic_load(misc + W_REL + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // looked at behind the terms
+            j += nc;
+            const bool more = j < nrec;
+            if (more) {
+                r += nc; while (r >= rps) { r -= rps; ++s; slot = slot + 1u == ns ? 0u : slot + 1u; }
+                sb += nc; while (sb >= nb) sb -= nb;
+                if ((int) (filled - (op.gs0 + s + 1u)) < 0) {
+                    const unsigned long long t0 = dbg ? wall_clock64() : 0ull;
+                    filled = lds_wait_ge(a, misc, misc + W_FILLED, op.gs0 + s + 1u, 0x400u);
+                    if (dbg) w_fill += wall_clock64() - t0;
+                }
+                lds_rec(Rn, smem + slot * BAMD_WSE_SLOT + r * RECB, lane);
+                if (lane == 0) atomicAdd(misc + W_FREE + slot, 1u);
+            }
+            const Terms T = block_terms(R, (int) sb_cur, lane, ap.q8, ap.S, ap.yd);
+            if ((int) ((uint32_t) __builtin_amdgcn_readfirstlane((int) relv) - gen) < 0) {       // the chunk's previous tenants have not been chained yet
+                const unsigned long long t0 = dbg ? wall_clock64() : 0ull;
+                lds_wait_ge(a, misc, misc + W_REL + ck, gen, 0x401u);
+                if (dbg) w_rel += wall_clock64() - t0;
+            }
+            const uint32_t u = grec & 7u;
+            unsigned char * t = terms + ck * (8 * BAMD_WSE_TERM_BYTES) + (u >> 1) * 1024u + (u & 1u) * 8u;
+            *(float2 *) (t + lane * 16) = make_float2(T.fs, T.pm);
+            if ((lane & 7) == 0) *(float2 *) (terms + ck * (8 * BAMD_WSE_TERM_BYTES) + 4096u + (u >> 1) * 128u + (u & 1u) * 8u + (lane >> 3) * 16) = make_float2(T.d, T.dmin);
+            asm volatile("" ::: "memory");
+            if (lane == 0) atomicAdd(misc + W_CHUNK + ck, 1u);
+            if (grec == op.grec0 && cw == 0) tl_stamp(a, op, BAMD_WSE_TL_FIRSTREC);
+            if (!more) break;
+        }
     }
     if (cw == 0) tl_stamp(a, op, BAMD_WSE_TL_LASTREC);
+    if (dbg && op.tlslot != 255 && lane == 0) { unsigned long long * row = a.tl + ((size_t) blockIdx.x * a.tl_ops + op.tlslot) * 8; row[BAMD_WSE_TL_VALID] = w_fill; row[BAMD_WSE_TL_LOADED] = w_rel; }
 }
 
 // attention of query head h on consumer waves 0..7 (attn_fused_body): q / k / v of this token come from the QKV granules through an LDS stage
@@ -263,7 +344,7 @@ struct AttnEnvWSE {
 template <int LG>
 __device__ __forceinline__ void wse_attention(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, int cw, CBar & cb8, uint32_t tagbase) {
     constexpr int hd = LG * 64;
-    const int tid = opaque((int) threadIdx.x - 128), lane = tid & 63, h = (int) blockIdx.x, hk = h / a.gq, Hq = a.H, Ekv = (Hq / a.gq) * hd;
+    const int tid = opaque((int) threadIdx.x - 64 * (1 + a.nch)), lane = tid & 63, h = (int) blockIdx.x, hk = h / a.gq, Hq = a.H, Ekv = (Hq / a.gq) * hd;
     unsigned char * scratch = smem + a.off_attn;
     const int ld = a.at.lds_ld;
     float * stage = (float *) (scratch + (size_t) ld * 8);
@@ -309,24 +390,21 @@ __device__ __forceinline__ void wse_attention(const bamd_wse_args & a, const bam
 template <int LG>
 __device__ __forceinline__ void wse_consumer(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc, int cw) {
     CBar cb, cb8;
+    uint32_t filled = 0;                   // cached copy of the loader's progress counter
     const uint32_t tagbase = wse_tagbase(a.st);
     for (int io = 0;; ++io) {
         const bamd_wse_op op = ops[io];
         if (op.kind == BAMD_WSE_END) break;
         if (op.kind == BAMD_WSE_ATTN) {
             if ((int) blockIdx.x < a.H && cw < 8) {
-                lds_wait<false>(a, misc, misc + W_CHAIN_DONE, op.grec0, 0x402u);        // the attention scratch aliases the term ring: the chainer must be through
+                for (int k = 0; k < a.nch; ++k) lds_wait_ge(a, misc, misc + W_PIECES + k, op.rps, 0x402u);   // the attention scratch aliases the term ring: every chainer must be through the pieces before this op (planner: rps = their number)
                 if (LG > 0) wse_attention<(LG > 0 ? LG : 1)>(a, op, smem, misc, cw, cb8, tagbase);
             }
             continue;
         }
-        if (op.act & BAMD_WSE_ACT_GATHER) {
-            if (op.act & BAMD_WSE_ACT_NORM) wse_gather<true>(a, op, smem, misc, cw, cb, tagbase);
-            else wse_gather<false>(a, op, smem, misc, cw, cb, tagbase);
-        }
-        if (op.type == BAMD_Q4_K) wse_records<BAMD_Q4_K>(a, op, smem, misc, cw);
-        else if (op.type == BAMD_Q5_K) wse_records<BAMD_Q5_K>(a, op, smem, misc, cw);
-        else wse_records<BAMD_Q6_K>(a, op, smem, misc, cw);
+        if (op.type == BAMD_Q4_K) wse_piece<BAMD_Q4_K>(a, op, smem, misc, cw, filled, cb, tagbase);
+        else if (op.type == BAMD_Q5_K) wse_piece<BAMD_Q5_K>(a, op, smem, misc, cw, filled, cb, tagbase);
+        else wse_piece<BAMD_Q6_K>(a, op, smem, misc, cw, filled, cb, tagbase);
     }
 }
 
@@ -344,75 +422,114 @@ __device__ __forceinline__ void vec_store(const bamd_wse_vec & v, uint32_t row, 
     if (v.gran) __hip_atomic_store(as_global<unsigned long long>(v.p) + row, ((unsigned long long) tag << 32) | __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else as_global<float>(v.p)[row] = val;
 }
+// chainer k of NCH takes the row-groups t = k, k + NCH, ... of every piece (the chains of different row-groups are independent; a chunk of 8 records
+// belongs to one row-group, so exactly one chainer reads and releases it)
 template <int TYPE>
-__device__ __forceinline__ void wse_chain_piece(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, uint32_t tagbase, unsigned long long & best) {
+__device__ __forceinline__ void wse_chain_piece(const bamd_wse_args & a, const bamd_wse_op & op, unsigned char * smem, uint32_t * misc, uint32_t tagbase, unsigned long long & best, int k) {
     const int lane = opaque((int) threadIdx.x & 63), r8 = lane >> 3;
-    const uint32_t nb = op.nb, tr = (uint32_t) a.tr, nchunk = tr >> 3;
+    const uint32_t nb = op.nb, tr = (uint32_t) a.tr, ckm = (tr >> 3) - 1u, nch = (uint32_t) a.nch;            // tr: a power of two (planner)
+    const uint32_t trs = (uint32_t) (31 - __builtin_clz(tr));
     unsigned char * terms = smem + a.off_terms;
     float * stash = (float *) ((unsigned char *) misc + W_STASH_BYTES);
     const bamd_wse_vec vout = a.vec[op.out_vec];
-    // residual rows of all tasks, fetched now: old by the time the first chain ends
-    float resv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    if (op.epi == BAMD_WSE_EPI_ADD) {
-        const bamd_wse_vec vr = a.vec[op.res_vec];
+    if ((uint32_t) k < op.ntask) {
+        // residual rows of this chainer's tasks, fetched now: old by the time the first chain ends
+        float resv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (op.epi == BAMD_WSE_EPI_ADD) {
+            const bamd_wse_vec vr = a.vec[op.res_vec];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const uint32_t row = op.row0 + (uint32_t) t * 8u + (uint32_t) r8;
-            if ((uint32_t) t < op.ntask && row < op.nvalid && (lane & 7) == 0) resv[t] = vec_value(a, vr, row, tagbase | op.res_tag, misc, 0x600u);
-        }
-    }
-    uint32_t grec = op.grec0;
-    for (uint32_t t = 0; t < op.ntask; ++t) {
-        RowAcc A = { 0.f, 0.f };
-        for (uint32_t c = 0; c < nb; c += 8, grec += 8) {
-            const uint32_t ck = (grec >> 3) % nchunk, ts0 = grec % tr;
-            lds_wait<true>(a, misc, misc + W_CHUNK + ck, 8u, 0x601u);
-            float2 fp[8], dd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned char * p = terms + (ts0 + u) * BAMD_WSE_TERM_BYTES;
-                fp[u] = *(const float2 *) (p + lane * 8); dd[u] = *(const float2 *) (p + 512 + r8 * 8);
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t row = op.row0 + (uint32_t) t * 8u + (uint32_t) r8;
+                if ((uint32_t) t < op.ntask && (uint32_t) t % nch == (uint32_t) k && row < op.nvalid && (lane & 7) == 0) resv[t] = vec_value(a, vr, row, tagbase | op.res_tag, misc, 0x600u);
             }
-            lds_drain();
+        }
+        // the terms of the next chunk are requested before the chain of the current one runs (a chunk = 8 records = 8 16-byte LDS reads per lane);
+        // a chunk is handed back to the consumers right behind its reads (in-order LDS: the two stores execute after them)
+        float4 fpn[4], ddn[4];
+        uint32_t pk_cnt = 0, pk_rel = 0;                      // the flags of the chunk after next, requested one chain early: no flag round trip per chunk in the steady state
+        auto peek = [&](uint32_t g) {
+            const uint32_t ck = (g >> 3) & ckm;
+            pk_cnt = __hip_atomic_load(misc + W_CHUNK + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pk_rel = __hip_atomic_load(misc + W_REL + ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto fetch = [&](uint32_t g, bool peeked) {
+            const uint32_t ck = (g >> 3) & ckm;
+            const bool ready = peeked && (uint32_t) __builtin_amdgcn_readfirstlane((int) pk_cnt) == 8u && (uint32_t) __builtin_amdgcn_readfirstlane((int) pk_rel) == g >> trs;
+            if (!ready) {
+                lds_wait<true>(a, misc, misc + W_REL + ck, g >> trs, 0x602u);     // (two chainers: the other one may still own the slot's previous tenant — a full count must be THIS chunk's)
+                lds_wait<true>(a, misc, misc + W_CHUNK + ck, 8u, 0x601u);
+            }
+            asm volatile("" ::: "memory");
+            const unsigned char * p = terms + ck * (8 * BAMD_WSE_TERM_BYTES);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fpn[q] = *(const float4 *) (p + q * 1024 + lane * 16); ddn[q] = *(const float4 *) (p + 4096 + q * 128 + r8 * 16); }
+            asm volatile("" ::: "memory");
             lds_st(misc + W_CHUNK + ck, 0u);
             asm volatile("" ::: "memory");
-            lds_st(misc + W_CHAIN_DONE, grec + 8u);
+            lds_st(misc + W_REL + ck, (g >> trs) + 1u);
+        };
+        // this chainer's chunks in order: (t, c) -> next chunk, or none
+        auto next_of = [&](uint32_t t, uint32_t c, uint32_t & g) -> bool {
+            if (c + 8u < nb) { g = op.grec0 + t * nb + c + 8u; return true; }
+            if (t + nch < op.ntask) { g = op.grec0 + (t + nch) * nb; return true; }
+            return false;
+        };
+        fetch(op.grec0 + (uint32_t) k * nb, false);
+        bool peeked = false;
+        for (uint32_t t = (uint32_t) k; t < op.ntask; t += nch) {
+            RowAcc A = { 0.f, 0.f };
+            for (uint32_t c = 0; c < nb; c += 8) {
+                float4 fp[4], dd[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dd[u].x, fp[u].x, dd[u].y, fp[u].y);
-            if (t == 0 && c == 0) tl_stamp(a, op, BAMD_WSE_TL_CHAIN0);
-        }
-        const float val = finish_row<TYPE>(A);
-        const uint32_t row = op.row0 + t * 8u + (uint32_t) r8;
-        if ((lane & 7) == 0 && row < op.nvalid) {
-            if (op.epi == BAMD_WSE_EPI_GATE) stash[t * 8u + (uint32_t) r8] = val;
-            else {
-                float o = val;
-                if (op.epi == BAMD_WSE_EPI_ADD) { float rv = 0.f;
+                for (int q = 0; q < 4; ++q) { fp[q] = fpn[q]; dd[q] = ddn[q]; }
+                uint32_t g1 = 0, g2 = 0;
+                const bool has1 = next_of(t, c, g1);
+                if (has1) {
+                    fetch(g1, peeked);
+                    const uint32_t t1 = c + 8u < nb ? t : t + nch, c1 = c + 8u < nb ? c + 8u : 0u;
+                    peeked = next_of(t1, c1, g2);
+                    if (peeked) peek(g2);
+                }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) rv = (uint32_t) k == t ? resv[k] : rv;
-                    o = val + rv; }
-                else if (op.epi == BAMD_WSE_EPI_UP) o = v_silu(stash[t * 8u + (uint32_t) r8]) * val;
-                vec_store(vout, row, o, tagbase | op.out_tag);
-                if (op.epi == BAMD_WSE_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, (int) row); best = k > best ? k : best; }
+                for (int q = 0; q < 4; ++q) { chain_step<TYPE>(A, dd[q].x, fp[q].x, dd[q].y, fp[q].y); chain_step<TYPE>(A, dd[q].z, fp[q].z, dd[q].w, fp[q].w); }
+                if (t == 0 && c == 0) tl_stamp(a, op, BAMD_WSE_TL_CHAIN0);
+            }
+            const float val = finish_row<TYPE>(A);
+            const uint32_t row = op.row0 + t * 8u + (uint32_t) r8;
+            if ((lane & 7) == 0 && row < op.nvalid) {
+                if (op.epi == BAMD_WSE_EPI_GATE) stash[t * 8u + (uint32_t) r8] = val;
+                else {
+                    float o = val;
+                    if (op.epi == BAMD_WSE_EPI_ADD) { float rv = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) rv = (uint32_t) q == t ? resv[q] : rv;
+                        o = val + rv; }
+                    else if (op.epi == BAMD_WSE_EPI_UP) o = v_silu(stash[t * 8u + (uint32_t) r8]) * val;
+                    vec_store(vout, row, o, tagbase | op.out_tag);
+                    if (op.epi == BAMD_WSE_EPI_ARGMAX) { const unsigned long long key = argmax_key(o, (int) row); best = key > best ? key : best; }
+                }
             }
         }
     }
     tl_stamp(a, op, BAMD_WSE_TL_PUBLISHED);
 }
-__device__ __forceinline__ void wse_chainer(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc) {
+__device__ __forceinline__ void wse_chainer(const bamd_wse_args & a, const bamd_wse_op * ops, unsigned char * smem, uint32_t * misc, int k) {
     const uint32_t tagbase = wse_tagbase(a.st);
     unsigned long long best = 0ull; bool any_best = false;
+    uint32_t pieces = 0;
     for (int io = 0;; ++io) {
         const bamd_wse_op op = ops[io];
         if (op.kind == BAMD_WSE_END) break;
         if (op.kind != BAMD_WSE_MATVEC) continue;
-        if (op.type == BAMD_Q4_K) wse_chain_piece<BAMD_Q4_K>(a, op, smem, misc, tagbase, best);
-        else if (op.type == BAMD_Q5_K) wse_chain_piece<BAMD_Q5_K>(a, op, smem, misc, tagbase, best);
-        else wse_chain_piece<BAMD_Q6_K>(a, op, smem, misc, tagbase, best);
+        if (op.type == BAMD_Q4_K) wse_chain_piece<BAMD_Q4_K>(a, op, smem, misc, tagbase, best, k);
+        else if (op.type == BAMD_Q5_K) wse_chain_piece<BAMD_Q5_K>(a, op, smem, misc, tagbase, best, k);
+        else wse_chain_piece<BAMD_Q6_K>(a, op, smem, misc, tagbase, best, k);
         any_best = any_best || op.epi == BAMD_WSE_EPI_ARGMAX;
+        asm volatile("" ::: "memory");
+        lds_st(misc + W_PIECES + k, ++pieces);
     }
     if (any_best && a.best_key) {
-        // wave maximum of the keys (64-bit), then one atomic per CU
+        // wave maximum of the keys (64-bit), then one atomic per chainer
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = ((unsigned long long) (uint32_t) __shfl_xor((int) (uint32_t) (best >> 32), off) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) best, off);
             best = o > best ? o : best;
@@ -423,8 +540,8 @@ __device__ __forceinline__ void wse_chainer(const bamd_wse_args & a, const bamd_
 
 // LG = head_dim / 64 of the attention role (0: a program without attention ops): one instance per head size, so that the register budget of a
 // launch (16 waves per CU: 128 VGPRs) is that of ITS attention body, not of the largest
-// MAXT = threads per workgroup the instance is compiled for: 768 (loader + chainer + up to 10 consumers: 3 waves per SIMD, 168 VGPRs — what the
-// attention body of head_dim 128 needs without spilling) or 1024 (up to 14 consumers, 128 VGPRs)
+// MAXT = threads per workgroup the instance is compiled for: 768 (loader + chainers + consumers = 12 waves: 3 per SIMD, 168 VGPRs — what the
+// attention body of head_dim 128 needs without spilling) or 1024 (16 waves, 128 VGPRs)
 template <int LG, int MAXT>
 __global__ void __launch_bounds__(MAXT) wse_kernel(const bamd_wse_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -433,9 +550,10 @@ __global__ void __launch_bounds__(MAXT) wse_kernel(const bamd_wse_args a) {
     __syncthreads();
     const bamd_wse_op * ops = a.ops + (size_t) blockIdx.x * a.ops_per_cu;
     const int wave = wave_id();
-    if (wave == 0) wse_loader(a, ops, smem, misc);
-    else if (wave == 1) wse_chainer(a, ops, smem, misc);
-    else if (wave - 2 < a.nc) wse_consumer<LG>(a, ops, smem, misc, wave - 2);
+    // the loader and the chainers issue few instructions, every one of them on the critical path of ten consumer waves: they go first on their SIMDs
+    if (wave == 0) { __builtin_amdgcn_s_setprio(3); wse_loader(a, ops, smem, misc); }
+    else if (wave <= a.nch) { __builtin_amdgcn_s_setprio(2); wse_chainer(a, ops, smem, misc, wave - 1); }
+    else if (wave - 1 - a.nch < a.nc) wse_consumer<LG>(a, ops, smem, misc, wave - 1 - a.nch);
 }
 
 // hardware facts the loader relies on, probed once on the device (bamd_wse_selftest): an LDS-DMA destination above 64 KiB (M0 carries the full
@@ -483,12 +601,12 @@ int bamd_wse_setup(int head_dim) {
     return 0;
 }
 int bamd_launch_wse(const bamd_wse_args & a, int n_cu, size_t lds_bytes, hipStream_t s) {
-    if (a.ns < 3 || a.ns > BAMD_WSE_MAX_SLOTS || a.tr < 8 || a.tr > BAMD_WSE_MAX_TERMS || (a.tr & 7) || a.nc < 8 || a.nc > 14) return 1;
+    if (a.ns < 3 || a.ns > BAMD_WSE_MAX_SLOTS || a.tr < 8 || a.tr > BAMD_WSE_MAX_TERMS || (a.tr & (a.tr - 1)) || a.nc < 8 || a.nch < 1 || a.nch > 2 || 1 + a.nch + a.nc > 16) return 1;
     const int lg = a.H > 0 ? a.at.hd >> 6 : 0;
     if (lg < 0 || lg > 4 || (a.H > 0 && (a.at.hd & 63))) return 1;
-    const int big = a.nc > 10 ? 1 : 0;
+    const int big = 1 + a.nch + a.nc > 12 ? 1 : 0;
     if (!g_wse_attr[big][lg]) return 1;                 // bamd_wse_setup(head_dim) must have run (outside any stream capture)
-    const dim3 grid(n_cu), block(64 * (2 + a.nc));
+    const dim3 grid(n_cu), block(64 * (1 + a.nch + a.nc));
 #define WSE_GO(LG_, MT_) hipLaunchKernelGGL((wse_kernel<LG_, MT_>), grid, block, lds_bytes, s, a)
 #define WSE_GO_LG(MT_) do { switch (lg) { case 0: WSE_GO(0, MT_); break; case 1: WSE_GO(1, MT_); break; case 2: WSE_GO(2, MT_); break; case 3: WSE_GO(3, MT_); break; default: WSE_GO(4, MT_); break; } } while (0)
     if (big) WSE_GO_LG(1024); else WSE_GO_LG(768);

@@ -84,6 +84,8 @@ struct Planner {
             bamd_wse_op op; memset(&op, 0, sizeof op);
             op.kind = BAMD_WSE_ATTN; op.layer = (uint8_t) layer; op.in_vec = BAMD_WSE_V_QKV; op.in_tag = (uint8_t) layer; op.out_vec = BAMD_WSE_V_ATT; op.out_tag = (uint8_t) layer;
             op.grec0 = cu[c].grec; op.gs0 = cu[c].gs; op.tlslot = (uint8_t) tlslot;
+            uint32_t pieces = 0; for (const bamd_wse_op & o : cu[c].ops) pieces += o.kind == BAMD_WSE_MATVEC ? 1u : 0u;
+            op.rps = pieces;                                          // the chainers must be through these before the attention scratch (aliasing the term ring) is written
             cu[c].ops.push_back(op);
         }
     }
@@ -97,8 +99,12 @@ struct Planner {
         size_t terms = std::max((size_t) tr * BAMD_WSE_TERM_BYTES, (attn_lds + 15) & ~(size_t) 15);
         long ring = (long) lds_limit - (long) fixed - (long) terms;
         int ns = (int) (ring / BAMD_WSE_SLOT);
-        if (ns > 8) { ns = 8; tr = (int) std::min<size_t>(BAMD_WSE_MAX_TERMS, ((size_t) lds_limit - fixed - (size_t) ns * BAMD_WSE_SLOT) / BAMD_WSE_TERM_BYTES / 8 * 8);
-                      terms = std::max((size_t) tr * BAMD_WSE_TERM_BYTES, (attn_lds + 15) & ~(size_t) 15); }
+        if (ns > 8) {                         // room to spare: a deeper term ring (a power of two: the kernel masks record numbers)
+            ns = 8;
+            const size_t room = ((size_t) lds_limit - fixed - (size_t) ns * BAMD_WSE_SLOT) / BAMD_WSE_TERM_BYTES;
+            tr = room >= 128 ? 128 : room >= 64 ? 64 : 32;
+            terms = std::max((size_t) tr * BAMD_WSE_TERM_BYTES, (attn_lds + 15) & ~(size_t) 15);
+        }
         if (ns < 3) { snprintf(plan->why, sizeof plan->why, "LDS: %zu B of activations + %zu B of terms leave %d ring slots", fixed, terms, ns); return 1; }
         plan->ns = ns; plan->tr = tr;
         plan->off_act[0] = (uint32_t) ((size_t) ns * BAMD_WSE_SLOT); plan->off_act[1] = plan->off_act[0] + (uint32_t) act_need[0];

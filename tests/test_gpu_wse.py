@@ -23,15 +23,15 @@ CASES = [(12, 14336, 4096, True, False), (12, 6144, 4096, True, False), (12, 409
 
 
 @pytest.mark.parametrize("t,rows,K,norm,res", CASES)
-@pytest.mark.parametrize("nc", [10, 12])
-def test_engine_piece_equals_launch_kernel(bamd, po, t, rows, K, norm, res, nc):
+@pytest.mark.parametrize("nc,nch", [(10, 1), (9, 2), (13, 2)])
+def test_engine_piece_equals_launch_kernel(bamd, po, t, rows, K, norm, res, nc, nch):
     rng = np.random.default_rng(31 * t + rows + K)
     W = random_kquant_tensor(t, K, rows, rng, amp=4.0)
     x = (rng.standard_normal(K) * 2).astype(np.float32)
     nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32) if norm else None
     r = rng.standard_normal(rows).astype(np.float32) if res else None
     want = bamd.op_mul_mat_vec(t, W, rows, K, x, norm_w=nw, eps=1e-5, residual=r)
-    got, info = bamd.op_wse_matvec(t, W, rows, K, x, norm_w=nw, eps=1e-5, residual=r, nc=nc)
+    got, info = bamd.op_wse_matvec(t, W, rows, K, x, norm_w=nw, eps=1e-5, residual=r, nc=nc, nch=nch)
     assert np.array_equal(bits(got), bits(want)), "engine piece differs from the launch kernel (type %d, %d x %d)" % (t, rows, K)
     if rows * (K // 256) <= 64 * 1024:                        # and from the oracle directly where that takes seconds
         a = (po.rms_norm(x, 1e-5) * nw).astype(np.float32) if norm else x
