@@ -569,7 +569,7 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     if (a.hd > 256 || (a.hd & 63) || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || !a.batch) return 1;
     if (gq < 1 || gq > 8) return 1;
     hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
-    if (bamd_launch_attention_batch_mfma(a, gq, T, s) == 0) return 0;        // head_dim 128, <= 2176 positions: the matrix-core kernel (bamd_attention_mfma.hip)
+    if (bamd_launch_attention_batch_mfma(a, gq, T, s) == 0) return 0;        // head_dim 128 (beyond 512 positions with a.batch_scratch): the matrix-core kernel (bamd_attention_mfma.hip)
     // as many query heads of a KV head per workgroup as have their score rows fit the LDS (ld floats each: the probabilities replace
     // the scores in place); a single head per workgroup runs on attn_fused_kernel (separate rows: 2 x ld floats)
     int gqh = (gq == 2 || gq == 4 || gq == 8) ? gq : 1;          // other ratios (3: Llama-3.2-3B): one query head per workgroup

@@ -634,11 +634,15 @@ BAMD_API void stopInference(int idx) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (idx >= 0 && idx < 8 && g_pods[idx]) g_pods[idx]->stop.store(true);
 }
-BAMD_API const char * status(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].c_str(); }
-BAMD_API int64_t promptEval(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_eval; }
-BAMD_API int64_t getPromptTokenCount(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].prompt_tokens; }
-BAMD_API int64_t timing(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].timing; }
-BAMD_API uint32_t getSeed(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); return g_jobs[jobID ? jobID : ""].seed; }
+// Read-only accessors: an unknown (never started, or retired) job id answers "" / 0 as the reference's map default does (cpp/bridge.cpp:662-695), but
+// WITHOUT inserting an entry: an inserted entry would never be "finished", so it could never be retired and a client polling stale ids would
+// grow the table past BAMD_MAX_JOBS.  Only doInference inserts.
+static Job * find_job(const char * jobID) { auto it = g_jobs.find(jobID ? jobID : ""); return it == g_jobs.end() ? nullptr : &it->second; }
+BAMD_API const char * status(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); Job * j = find_job(jobID); return j ? j->c_str() : ""; }
+BAMD_API int64_t promptEval(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); Job * j = find_job(jobID); return j ? j->prompt_eval : 0; }
+BAMD_API int64_t getPromptTokenCount(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); Job * j = find_job(jobID); return j ? j->prompt_tokens : 0; }
+BAMD_API int64_t timing(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); Job * j = find_job(jobID); return j ? j->timing : 0; }
+BAMD_API uint32_t getSeed(char * jobID) { std::lock_guard<std::mutex> lk(g_mu); Job * j = find_job(jobID); return j ? j->seed : 0; }
 
 // ---- test hooks (not part of the cgo surface): tokenizer and Janus as pure functions -------------------------------------------
 // test hook: the Janus shortlist of `logits` with a fixed cut-off, through the fast (1) or the full-sort (0) path -> ids, count

@@ -168,7 +168,7 @@ struct bamd_context {
         std::string why;
     } wse;
     int bcap = 0;
-    float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0;   // score rows of the matrix-core prefill attention beyond 2176 positions (grow-only)
+    float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0;   // score rows of the matrix-core prefill attention beyond BAMD_AM_MAXPOS = 512 positions (grow-only; absent = the VALU kernel runs)
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
@@ -860,10 +860,12 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
                 HIPC(hipStreamSynchronize(s));
                 if (c->attn_bscr) hipFree(c->attn_bscr);
                 c->attn_bscr = nullptr; c->attn_bscr_bytes = 0;
-                HIPC(hipMalloc((void **) &c->attn_bscr, need));
-                c->attn_bscr_bytes = need;
+                // ~ H * T * ld * 4 bytes (0.5 GB at 8 K positions on the 8B shape, 2.4 GB at 18 K on a 70B stage).  If the device cannot spare it the
+                // prompt is not lost: without a scratch block the matrix-core launcher declines and attn_batch_kernel (VALU, no scratch) runs
+                if (hipMalloc((void **) &c->attn_bscr, need) == hipSuccess) c->attn_bscr_bytes = need;
+                else { (void) hipGetLastError(); c->attn_bscr = nullptr; }
             }
-            t.batch_scratch = need ? c->attn_bscr : nullptr;
+            t.batch_scratch = need && c->attn_bscr_bytes >= need ? c->attn_bscr : nullptr;
         }
         if (bamd_launch_attention_batch(t, gq, T, s)) return fail("batched attention: unsupported head configuration");
         // x2 = x + Wo . att

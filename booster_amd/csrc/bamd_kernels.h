@@ -47,7 +47,7 @@ struct bamd_attn_args {
     float kq_scale;
     int prefill_mode;              // 1: KQ with the T>1 semantics of the reference (q -> f16, ggml_vec_dot_f16)
     int batch, ld_qkv, ld_out;     // batched prefill: q/k/v and out are [T][ld_*] f32, token = blockIdx.y, position st->pos + token
-    float * batch_scratch;         // batched prefill, more than 2176 positions: score rows of the matrix-core kernel (bamd_attention_batch_mfma_scratch bytes)
+    float * batch_scratch;         // batched prefill, more than 512 positions (BAMD_AM_MAXPOS): score rows of the matrix-core kernel (bamd_attention_batch_mfma_scratch bytes); null: the VALU kernel
     int batch_pos0p1;              // batched prefill: the position of token 0, plus one (= st->pos + 1, known to the host: the matrix-core kernel takes it from here
                                    // and starts its requests without a dependent load of the device state); 0 = read st->pos
     int lds_ld;                    // single-launch / batched kernels: floats per score / probability row in LDS — a multiple of 64 that bounds the padded

@@ -55,6 +55,10 @@ static void byte_maps(uint32_t b2u[256], std::unordered_map<uint32_t, uint8_t> &
 
 // ---- loading --------------------------------------------------------------------------------------------------------
 bool BamdVocab::load(const GgufFile & g, std::string & err) {
+    // the tokenizer serves the files the engine loads (bamd_engine.cpp: general.architecture "llama" — Llama-2/3, Mistral, deepseek-llm / -coder, SmolLM,
+    // Mistral-Nemo (tekken), Viking / Poro ... as GGUF names them); the pre-tokenisers of other architectures' families (qwen2, falcon, starcoder ...) are
+    // restated and pinned as well — llm_load_vocab keys on tokenizer.ggml.pre alone — but a file of another architecture is refused here as it is there
+    { std::string arch; if (g.get_str("general.architecture", arch) && arch != "llama") { err = "general.architecture must be \"llama\" (got \"" + arch + "\")"; return false; } }
     std::string model;
     if (!g.get_str("tokenizer.ggml.model", model)) { err = "missing tokenizer.ggml.model"; return false; }
     if (model == "no_vocab") { type = BAMD_VOCAB_NONE; return true; }
@@ -407,8 +411,9 @@ static Spans split_chain(const std::vector<uint32_t> & c, int chain) {
         split_by(c, a, b, [&](size_t i, size_t) { return c[i] == '\r' || c[i] == '\n' ? (size_t) 1 : (size_t) 0; });
         split_by(c, b, a, [&](size_t i, size_t hi) { size_t k = i; if (is_space(c[i]) && i + 1 < hi && is_letter(c[i + 1])) k = i + 1; size_t e = k; while (e < hi && is_letter(c[e])) ++e; return e > k ? e - i : (size_t) 0; });
         split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; if (is_space(c[i]) && i + 1 < hi && is_punct(c[i + 1])) k = i + 1; size_t e = k; while (e < hi && is_punct(c[e])) ++e; return e > k ? e - i : (size_t) 0; });
-        auto cjk = [](uint32_t x) { return (x >= 0x0800 && x <= 0x9FA5) || (x >= 0xAC00 && x <= 0xD7FF); };
-        split_by(c, b, a, [&](size_t i, size_t hi) { size_t e = i; while (e < hi && cjk(c[e])) ++e; return e - i; });
+        // "[一-龥ࠀ-一가-퟿]+" as std::wregex sees it on the reference's wtext, where non-ASCII white space has become 0x0B (unicode.cpp:786-792): the class
+        // recorded code point by code point for deepseek-llm's identical regex (U+1680, U+2000-200A, U+2028/9, U+202F, U+205F, U+3000 are holes)
+        split_by(c, b, a, [&](size_t i, size_t hi) { size_t e = i; while (e < hi && in_ranges(BAMD_UNI_DSCJK, BAMD_UNI_DSCJK_N, c[e])) ++e; return e - i; });
         split_by(c, a, b, [&](size_t i, size_t) { return is_number(c[i]) ? (size_t) 1 : (size_t) 0; });
         return b;
     }
@@ -440,9 +445,12 @@ static Spans split_chain(const std::vector<uint32_t> & c, int chain) {
     auto punct = [&](uint32_t x) { return is_punct(x) || x == '$' || x == '+' || x == '<' || x == '=' || x == '>' || x == '^' || x == '~' || x == '|' || (falcon && x == '`'); };
     split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && punct(c[k])) ++k; return k - i; });       // "[\\p{P}\\$\\+<=>\\^~\\|]+" (falcon: + `)
     gpt2(b, a);
-    if (falcon) split_by(c, a, b, [&](size_t i, size_t hi) { return i + 3 <= hi && c[i] >= '0' && c[i] <= '9' && c[i + 1] >= '0' && c[i + 1] <= '9' && c[i + 2] >= '0' && c[i + 2] <= '9' ? (size_t) 3 : (size_t) 0; });
-    else        split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && is_number(c[k])) ++k; return k - i; });                     // "\\p{N}+"
-    return b;
+    auto three_digits = [&](size_t i, size_t hi) { return i + 3 <= hi && c[i] >= '0' && c[i] <= '9' && c[i + 1] >= '0' && c[i + 1] <= '9' && c[i + 2] >= '0' && c[i + 2] <= '9' ? (size_t) 3 : (size_t) 0; };
+    if (falcon) { split_by(c, a, b, three_digits); return b; }                                                                                          // "[0-9][0-9][0-9]"
+    // default (also: no tokenizer.ggml.pre): FOUR regexes, llama-vocab.cpp:437-442 — "\\p{N}+" and then "[0-9][0-9][0-9]": 1234567 -> 123 | 456 | 7
+    split_by(c, a, b, [&](size_t i, size_t hi) { size_t k = i; while (k < hi && is_number(c[k])) ++k; return k - i; });
+    split_by(c, b, a, three_digits);
+    return a;
 }
 
 static void bpe_tokenize(const BamdVocab & v, const std::string & text, std::vector<int> & out) {

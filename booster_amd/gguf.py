@@ -382,8 +382,10 @@ def _bytes_to_unicode():
     return dict(zip(bs, [chr(c) for c in cs]))
 
 
-def synthetic_bpe_vocab(n_merges=300, seed=2, pre="llama-bpe"):
-    """Byte-level BPE vocab (GPT-2 / Llama-3 style): 256 byte symbols, random merges, a few control tokens."""
+def synthetic_bpe_vocab(n_merges=300, seed=2, pre="llama-bpe", extra_merges=None):
+    """Byte-level BPE vocab (GPT-2 / Llama-3 style): 256 byte symbols, random merges, a few control tokens.
+    extra_merges: [(left bytes, right bytes), ...] appended behind the random merges (digit-digit / cross-character merges, so that a different
+    pre-tokeniser split changes the token stream)."""
     import random
     rnd = random.Random(seed)
     b2u = _bytes_to_unicode()
@@ -395,6 +397,11 @@ def synthetic_bpe_vocab(n_merges=300, seed=2, pre="llama-bpe"):
         a = rnd.choice(toks if rnd.random() < 0.5 else common)
         b = rnd.choice(toks if rnd.random() < 0.3 else common)
         if a + b in seen or " " in a or " " in b:
+            continue
+        seen.add(a + b); toks.append(a + b); merges.append(a + " " + b)
+    for la, rb in (extra_merges or []):
+        a = "".join(b2u[x] for x in la); b = "".join(b2u[x] for x in rb)
+        if a + b in seen:
             continue
         seen.add(a + b); toks.append(a + b); merges.append(a + " " + b)
     types = [1] * len(toks)

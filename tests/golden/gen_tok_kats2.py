@@ -31,7 +31,21 @@ def vocabs():
             "default": gguf.synthetic_bpe_vocab(n_merges=600, seed=15, pre="default"), "falcon": gguf.synthetic_bpe_vocab(n_merges=600, seed=16, pre="falcon"),
             "poro": gguf.synthetic_bpe_vocab(n_merges=600, seed=17, pre="poro-chat"), "viking": gguf.synthetic_bpe_vocab(n_merges=600, seed=18, pre="viking"),
             "dscoder": gguf.synthetic_bpe_vocab(n_merges=600, seed=19, pre="deepseek-coder"), "tekken": gguf.synthetic_bpe_vocab(n_merges=600, seed=20, pre="tekken"),
-            "dsllm": gguf.synthetic_bpe_vocab(n_merges=600, seed=21, pre="deepseek-llm")}
+            "dsllm": gguf.synthetic_bpe_vocab(n_merges=600, seed=21, pre="deepseek-llm"),
+            # merges ACROSS the places where the chains split (the random merges above almost never join two digits or two characters): the default chain's
+            # fourth regex "[0-9][0-9][0-9]" (1234567 -> 123 | 456 | 7) and deepseek-coder's CJK class, whose std::wregex form has holes at the
+            # non-ASCII white space (U+3000 between two ideographs ends the run)
+            "default_digits": gguf.synthetic_bpe_vocab(n_merges=600, seed=15, pre="default", extra_merges=DIGIT_MERGES),
+            "falcon_digits": gguf.synthetic_bpe_vocab(n_merges=600, seed=16, pre="falcon", extra_merges=DIGIT_MERGES),
+            "dscoder_cjk": gguf.synthetic_bpe_vocab(n_merges=600, seed=19, pre="deepseek-coder", extra_merges=DIGIT_MERGES + CJK_MERGES),
+            "dsllm_cjk": gguf.synthetic_bpe_vocab(n_merges=600, seed=21, pre="deepseek-llm", extra_merges=DIGIT_MERGES + CJK_MERGES)}
+
+
+DIGIT_MERGES = [(b"1", b"2"), (b"12", b"3"), (b"3", b"4"), (b"123", b"4"), (b"4", b"5"), (b"5", b"6"), (b"45", b"6"), (b"6", b"7"), (b"7", b"8"), (b"8", b"9"), (b"0", b"0"),
+                (b"00", b"0"), (b"9", b"0"), (b"1", b"0"), (b"7", b"1"), (b"56", b"7"), (b"34", b"56"), (b".", b"."), (b"..", b"."), (b"!", b"!"), (b"?", b"!")]
+# last byte of an ideograph + first byte of U+3000 / U+2003 / U+1680 / U+2028, and their last byte + the first byte of an ideograph or a Hangul syllable
+CJK_MERGES = [(b"\xad", b"\xe3"), (b"\x87", b"\xe3"), (b"\x80", b"\xe4"), (b"\x80", b"\xe6"), (b"\xad", b"\xe2"), (b"\x83", b"\xe6"), (b"\xa8", b"\xe4"),
+              (b"\xad", b"\xe1"), (b"\x80", b"\xea"), (b"\xe4\xb8", b"\xad"), (b"\xe3\x80", b"\x80")]
 
 
 def valid(cp):
@@ -63,6 +77,12 @@ def strings():
     for _ in range(1200):
         n = rnd.randint(1, 48)
         out.append("".join(rnd.choice(alphabet) for _ in range(n)))
+    # (appended behind the random strings, so that everything above keeps its index) long digit runs and ideographs around the non-ASCII white space
+    out += ["1234567", "12345678901234567890", " 1234 5678 9", "a1234567b", "12 345 6789 0", "007 1000000 3.14159", "x=1234567890;y=100000", "٣٣٣٣1234", "123", "1234", "12345", "123456",
+            "中\u3000文", "\u2192\u3000\u2192", "中\u2003文\u2028中", "가\u1680龥", "中文\u3000\u3000中文123456", "中\u202f文\u205f中", "a中\u3000文b 12345", "中 文", "中\t文", "...!!?!..", "1234567...!!"]
+    for _ in range(200):
+        n = rnd.randint(1, 24)
+        out.append("".join(rnd.choice("0123456789012345 .中文\u3000가\u2003a") for _ in range(n)))
     return out
 
 
