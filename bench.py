@@ -151,18 +151,36 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="8b", choices=sorted(MODELS), help="8b = the BASELINE metric (default); 70b = BASELINE config 4 shapes; m7q6k = config 5 shapes")
     ap.add_argument("--pipeline-smoke", action="store_true", help="run the N > 1 code path (layer-split pipeline, RCCL group) with a single rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU plumbing check of the N > 1 leg (launch, rendezvous, schedule, JSON) "
+                                                                               "with a stand-in stage — tests/test_bench_selflaunch.py; never a measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (BASELINE configs 3, 5 and 4 at N = 1) of the N = 1 line")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     N = args.gpus
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the N = 1 line is started: no launcher given, so be the launcher — one rank per GPU under
+        # torch.distributed.run on this node (the reference's split needs none either: one process, cpp/bridge.cpp:745-750)
+        sys.exit(self_launch(N, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    dist = None
+    if args.backend == "gloo":
+        import torch.distributed as dist
+        assert world == N, "WORLD_SIZE %d but --gpus %d" % (world, N)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_pipeline_gloo import FakeStage, V as FAKE_V
+        from booster_amd import pipeline
+        result = pipeline.run_plumbing_check(N, rank, [3, 1, 4, 1, 5], args.warmup, args.steps, dist, FakeStage)
+        emit(rank, dist, result, "plumbing check (stand-in stage, vocabulary %d)" % FAKE_V, N, args.steps, args.warmup)
+        return
     import booster_amd
     from booster_amd import build as bbuild
     if rank == 0:
         bbuild.build()
-    dist = None
     if N > 1 or args.pipeline_smoke:
         import torch.distributed as dist
-        assert world == N, "launch with torch.distributed.run --nproc-per-node %d" % N
+        assert world == N, "WORLD_SIZE %d but --gpus %d (bench.py launches its own ranks when WORLD_SIZE is absent)" % (world, N)
         torch.cuda.set_device(local)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29517")
@@ -272,13 +290,18 @@ def main():
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
                         prompt_eval_tokens_per_s=round(prefill_tok_s, 1), launches_per_token=int((L_[0] + L_[1] + L_[2]) / reps), event_pair_overhead_us=round(ev_overhead_ms * 1e3, 3), empty_event_pair_us=round(ev_empty_ms * 1e3, 3)),
             roofline=dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                          traffic=traffic, traffic_source=traffic_source,
+                          # the WHOLE step against the roofline (every byte a token needs / the step time), beside the dominant kernel's own fraction
+                          step_frac=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4), step_achieved=round(tok_s * bytes_per_token / 1e9, 1),
+                          # HBM bytes are NOT counted in this run (PMC counters need their own rocprofv3 pass): null here; the committed pass is quoted beside it
+                          traffic=None, traffic_committed_pmc=traffic, traffic_source=traffic_source,
                           kernel="%s: %s — the launch kind with the largest share of the step (%.1f %%)" % (dom, KERNEL_OF.get(dom, dom), 100.0 * per_kind[dom]["share_of_step"]),
                           bytes_per_launch=per_kind[dom]["bytes_per_launch"], us_per_launch=per_kind[dom]["us_per_launch"],
                           per_kind=per_kind,
                           all_matvec_launches=dict(GBps=round(family_achieved, 1), frac=round(family_achieved / HBM_PEAK_GBS, 4), bytes_per_launch=int(mv_bytes_per_launch),
                                                    us_per_launch=round(mv_ms_per_launch * 1e3, 3))),
         )
+        if not args.no_secondary and args.model == "8b":
+            result["config"]["secondary"] = secondary_configs(booster_amd, m, torch)
         if not args.no_cpu_baseline:
             try:
                 try:
@@ -299,6 +322,132 @@ def main():
         from booster_amd import pipeline
         result = pipeline.run_layer_split_bench(path, CFG, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch, model_name)
 
+    emit(rank, dist, result, model_name, N, steps, warmup)
+
+
+def secondary_configs(booster_amd, m8b, torch):
+    """BASELINE.json's other single-GPU configurations, measured in the same run and reported under config.secondary (bounded: ~1 min in all; each
+    leg is skipped with its reason rather than taking the line down):
+      config3     Llama-3-8B Q4_K_M, 2048-token prompt in micro-batches of 512 at n_ctx 4096: tokens/s, TFLOP/s of mat-mul work, fraction of the dense f16 MFMA peak
+      config5     Mistral-7B shape, every matrix Q6_K, n_ctx 8192: decode at ~8000 cached positions THROUGH THE BRIDGE (the nine cgo symbols, Janus sampling
+                  with the device prefilter): tokens/s and the fraction of that shape's token roofline
+      config4_n1  the whole Llama-3-70B Q4_K_M on ONE GPU (the N = 1 point of the layer split), when /dev/shm has room for its 42 GB file"""
+    sec = {}
+    t_all = time.time()
+    try:                                                                   # ---- config 3
+        V = CFG_8B["V"]; n = 2048
+        toks = [(7919 * i + 13) % V for i in range(n)]
+        ctx = booster_amd.Context(m8b, 4096)
+        ctx.decode(toks[:16], 0)                                           # buffers
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(0, n, 512):
+                ctx.decode(toks[i:i + 512], i)
+            best = min(best, time.perf_counter() - t0)
+        ctx.close()
+        E, F, L, Ekv = CFG_8B["E"], CFG_8B["F"], CFG_8B["L"], CFG_8B["Hkv"] * (CFG_8B["E"] // CFG_8B["H"])
+        flop_tok = 2.0 * L * (E * (E + 2 * Ekv) + E * E + 3 * E * F)       # the layers' mat-muls (lm_head runs for the last token only)
+        tfl = flop_tok * n / best / 1e12
+        sec["config3"] = dict(workload="Llama-3-8B Q4_K_M shapes, 2048-token prompt, micro-batches of 512, n_ctx 4096 (exact-integer MFMA prefill)", value=round(n / best, 1), unit="tokens/s",
+                              tflops=round(tfl, 1), mfma_peak_tflops=2500.0, mfma_peak_frac=round(tfl / 2500.0, 4), ms=round(best * 1e3, 2))
+    except Exception as e:
+        sec["config3"] = dict(skipped="failed: %r" % (e,))
+    try:                                                                   # ---- config 5
+        sec["config5"] = bridge_longctx_rate()
+    except Exception as e:
+        sec["config5"] = dict(skipped="failed: %r" % (e,))
+    try:                                                                   # ---- config 4, N = 1
+        import shutil
+        p70 = model_path("70b")
+        free = shutil.disk_usage(os.path.dirname(p70)).free
+        if not os.path.exists(p70 + ".done") and free < (48 << 30):
+            sec["config4_n1"] = dict(skipped="no room for the 42 GB synthetic GGUF (%s has %.0f GB free)" % (os.path.dirname(p70), free / 2 ** 30))
+        elif time.time() - t_all > 120:
+            sec["config4_n1"] = dict(skipped="time budget of the secondary legs used up")
+        else:
+            ensure_model(p70, 0, "70b")
+            m = booster_amd.Model(p70, device=0); ctx = booster_amd.Context(m, 512)
+            prompt = [(7919 * i + 13) % CFG_70B["V"] for i in range(N_PROMPT)]
+            ctx.decode(prompt[:8], 0); ctx.decode(prompt, 0)
+            ctx.generate_greedy(N_PROMPT, 4)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ctx.generate_greedy(N_PROMPT + 4, 32)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            l, _, _ = ctx.profile_step_kinds(N_PROMPT + 36)
+            kvb = 2 * CFG_70B["L"] * CFG_70B["Hkv"] * 128 * 2
+            bpt = m.weight_bytes + kvb * (N_PROMPT + 20)
+            sec["config4_n1"] = dict(workload="the whole Llama-3-70B Q4_K_M (80 layers, %.1f GB of weights) on one MI355X, greedy decode, 128-token prompt" % (m.weight_bytes / 1e9),
+                                     value=round(32 / dt, 2), unit="tokens/s", ms_per_token=round(dt / 32 * 1e3, 3), bytes_per_token=int(bpt),
+                                     frac_of_hbm_roofline_tokens=round(32 / dt * bpt / (HBM_PEAK_GBS * 1e9), 4), launches_per_token=int(sum(l[:7])))
+            ctx.close(); m.close()
+            try:
+                os.remove(p70); os.remove(p70 + ".done")                  # 42 GB of tmpfs: do not leave it behind for whatever runs next on the box
+            except OSError:
+                pass
+    except Exception as e:
+        sec["config4_n1"] = dict(skipped="failed: %r" % (e,))
+    sec["seconds"] = round(time.time() - t_all, 1)
+    return sec
+
+
+def bridge_longctx_rate(n_pos=7900):
+    """BASELINE config 5 as specified: Mistral-7B shape, all Q6_K, 8 K context, Janus sampling — through include/booster_bridge.h's nine symbols (ctypes
+    stands where cgo would).  The decode rate at ~n_pos cached positions is the difference of two requests on the same prompt (n_predict 24 and 88): the
+    prompt evaluation, tokenisation and sampler set-up cancel."""
+    import ctypes as C
+    from booster_amd import gguf, build
+    path = os.path.join(os.path.dirname(model_path("m7q6k")), "bamd_bench_m7q6k_vocab.gguf")
+    if not os.path.exists(path + ".done"):
+        v = gguf.synthetic_bpe_vocab(n_merges=2000)
+        ctrl = v["tokens"][-4:]; toks = v["tokens"][:-4]; types = v["types"][:-4]
+        while len(toks) < 32000 - 4:
+            toks.append("\u0120fill%d" % len(toks)); types.append(1)
+        v["tokens"] = toks + ctrl; v["types"] = types + [3] * 4
+        n = len(v["tokens"]); v["bos_token_id"] = n - 4; v["eos_token_id"] = n - 3
+        gguf.write_synthetic_llama(path, E=4096, H=32, Hkv=8, L=32, F=14336, V=n, theta=10000.0, seed=7, reuse_layers=True, vocab=v,
+                                   type_fn=lambda name, il: gguf.Q6_K, embd_type=gguf.Q6_K)
+        open(path + ".done", "w").write("ok")
+    L = C.CDLL(build.build())
+    i, f, u = C.c_int, C.c_float, C.c_uint32
+    L.initContext.restype = C.c_void_p
+    L.initContext.argtypes = [i, C.c_char_p, i, i, i, i, i, i, i, i, C.c_int32, f, f, f, i, f, f, f, i, C.c_int32, C.c_int32, f, f, f, u, C.c_char_p]
+    L.doInference.restype = C.c_int64; L.doInference.argtypes = [i, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.getPromptTokenCount.restype = C.c_int64; L.getPromptTokenCount.argtypes = [C.c_char_p]
+    L.init(b"", b"")
+    unit = "the quick brown fox jumps over the lazy dog and then "
+    res = {}
+    n_prompt = 0
+    for idx, n_predict in ((1, 24), (2, 88)):
+        ctx = L.initContext(idx, path.encode(), 4, 512, 100, 0, 0, 0, 8192, n_predict, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64, 1, 200, 0.97, 0.99, 0.96, 42, b"")
+        if not ctx:
+            raise RuntimeError("initContext failed")
+        if n_prompt == 0:                                                  # size the prompt: tokens per repetition of the unit, from a short request's count
+            L.doInference(idx, ctx, b"probe", b"s", (unit * 8).encode())
+            per = max(L.getPromptTokenCount(b"probe") / 8.0, 1.0)
+            reps = int(n_pos / per)
+        prompt = (unit * reps).encode()
+        job = b"cfg5_%d" % n_predict
+        t0 = time.perf_counter()
+        n = L.doInference(idx, ctx, job, b"s", prompt)
+        res[n_predict] = (time.perf_counter() - t0, int(n), int(L.getPromptTokenCount(job)))
+        n_prompt = res[n_predict][2]
+    (ta, na, pa), (tb, nb, pb) = res[24], res[88]
+    gen = (nb - pb) - (na - pa)
+    if gen <= 0:
+        raise RuntimeError("the two requests generated %d and %d tokens (an end-of-generation token cut one short)" % (na - pa, nb - pb))
+    ms = (tb - ta) / gen * 1e3
+    E, F, Lr, V = 4096, 14336, 32, 32000
+    W = (Lr * (E * (E + 2 * 1024) + E * E + 3 * E * F) + V * E) // 256 * 210
+    bpt = W + 2 * Lr * 1024 * 2 * (pb + (nb - pb) // 2)
+    return dict(workload="Mistral-7B shape, every matrix Q6_K, n_ctx 8192, through the nine bridge symbols with Janus sampling (device prefilter): decode at %d cached positions" % pb,
+                value=round(1e3 / ms, 2), unit="tokens/s", ms_per_token=round(ms, 3), prompt_tokens=pb, generated=[na - pa, nb - pb], bytes_per_token=int(bpt),
+                frac_of_hbm_roofline_tokens=round(1e3 / ms * bpt / (HBM_PEAK_GBS * 1e9), 4), request_seconds=[round(ta, 3), round(tb, 3)])
+
+
+def emit(rank, dist, result, model_name, N, steps, warmup):
+    """rank 0 prints the ONE JSON line, after every rank has left the process group"""
+    out = None
     if rank == 0:
         out = dict(metric="decode tokens/sec " + model_name, value=result.pop("value"), unit="tokens/s", n_gpus=N, steps=steps,
                    warmup=warmup, ms_per_step=result.pop("ms_per_step"), higher_is_better=True, scaling=result.pop("scaling"),
@@ -319,6 +468,18 @@ def main():
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
+
+
+def self_launch(N, argv):
+    """re-exec this script under torch.distributed.run with N ranks on 127.0.0.1 (a free port); the ranks' stdout is ours: rank 0's JSON line"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(N), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd)
 
 
 if __name__ == "__main__":

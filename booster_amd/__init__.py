@@ -110,6 +110,16 @@ class Model:
         self.n_layer = lib().bamd_model_n_layer(self.h)
         self.weight_bytes = lib().bamd_model_weight_bytes(self.h)
 
+    def tensor_raw(self, name):
+        """the GGUF bytes of a tensor as the loader sees them (bamd_model_tensor_raw): uint8 array"""
+        n = lib().bamd_model_tensor_raw(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise BamdError(lib().bamd_last_error().decode())
+        out = np.zeros(n, np.uint8)
+        if lib().bamd_model_tensor_raw(self.h, name.encode(), _p(out), n) != n:
+            raise BamdError("bamd_model_tensor_raw: size changed")
+        return out
+
     def close(self):
         if self.h:
             lib().bamd_model_free(self.h)

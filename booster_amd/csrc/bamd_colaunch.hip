@@ -107,6 +107,45 @@ __device__ __forceinline__ void wo_role(const bamd_mv_args & a, const ProArgs & 
     }
 }
 
+// wo role at the Llama-3-70B width (K = 8192: four records per wave and row-group, five or six row-groups per workgroup): too many records to hold them
+// all in registers as wo_role does, so this role is the batched split-K loop of the stand-alone launch (split_stream, two row-groups per batch,
+// double-buffered terms) with the granule wait in the place of its activation requests: the records of the FIRST batch are requested at entry and
+// land while the attention role runs, the later batches stream behind the hand-over.
+template <int TYPE>
+__device__ __forceinline__ void wo_role_batched(const bamd_mv_args & a, const ProArgs & pa, const int j, const int G, const int count, float * part0, const unsigned long long * gran,
+                                                const bamd_step_state * st, const int il, const int ring_delay_in, uint32_t * err) {
+    typedef typename RecOf<TYPE>::type REC;
+    constexpr int NBW = 4;
+    const int ring_delay = ring_delay_in & 0xff; const bool poll_sleep = (ring_delay_in >> 8) & 1;
+    const int nb = pa.K >> 8, lane = threadIdx.x & 63, i0 = wave_id() * NBW;
+    for (int d = 0; d < ring_delay; ++d) __builtin_amdgcn_s_sleep(8);
+    ActPro<false> ap, ap2; ap.tl = pa.tl; ap.okmask = (1 << NBW) - 1;
+    auto wait_for_attention = [&]() {
+        const uint32_t tag = ((uint32_t) st->serial << 20) | (((uint32_t) st->step & 0xfffu) << 8) | (uint32_t) il;
+        const bamd_rsrc gr = weight_rsrc(gran);
+        unsigned spins = 0;
+        for (;;) {
+            asm volatile("" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const uint32_t off = (uint32_t) ((i0 + b) * 256 + lane * 4) * 8u;
+                const uint4 g0 = ld_coh128(gr, off), g1 = ld_coh128(gr, off + 16u);
+                ap.v[b] = make_float4(__uint_as_float(g0.x), __uint_as_float(g0.z), __uint_as_float(g1.x), __uint_as_float(g1.z));
+                ok = ok && g0.y == tag && g0.w == tag && g1.y == tag && g1.w == tag;
+            }
+            if (__all(ok)) break;
+            if (poll_sleep) __builtin_amdgcn_s_sleep(1);
+            if (++spins > BAMD_COLAUNCH_SPINS) { if (lane == 0) atomicAdd(err, 1u); break; }
+        }
+        TL_STAMP(pa.tl, 2);
+    };
+    int batchctr = 0;
+    const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
+    split_stream<TYPE, REC, NBW, 2, 2, BAMD_EPI_ADD, BAMD_PRO_PLAIN, true, false, false>((const uint8_t *) a.seg[0].w, nb, j, count, G, a.seg[0].out, a.res, pa, ap, ap2, false, true,
+                                                                                         part0, batchctr, nv, wait_for_attention);
+}
+
 template <int LG, int TYPE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_wo_kernel(bamd_attn_args at, int gq, bamd_mv_args wo, unsigned long long * gran, int il, int extra,
                                                                                                     int ring_delay, uint32_t * err) {
@@ -122,8 +161,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int j = (int) blockIdx.x - H, G = (int) gridDim.x - H;
     const ProArgs pa = carve_lds(wo, smem);
     float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(wo.K >> 8) + 16 * sizeof(double));
-    if (j < extra) wo_role<TYPE, 2, 3>(wo, pa, j, G, part0, gran, at.st, il, ring_delay, err);       // the first `extra` workgroups take a third row-group
-    else           wo_role<TYPE, 2, 2>(wo, pa, j, G, part0, gran, at.st, il, ring_delay, err);
+    if ((wo.K >> 8) == 32) {                                                                          // 70B width: batched (count = 5 or 6 row-groups)
+        const int nrg = wo.seg[0].nrows >> 3;
+        wo_role_batched<TYPE>(wo, pa, j, G, nrg / G + (j < nrg % G ? 1 : 0), part0, gran, at.st, il, ring_delay, err);
+    }
+    else if (j < extra) wo_role<TYPE, 2, 3>(wo, pa, j, G, part0, gran, at.st, il, ring_delay, err);  // the first `extra` workgroups take a third row-group
+    else                wo_role<TYPE, 2, 2>(wo, pa, j, G, part0, gran, at.st, il, ring_delay, err);
     TL_STAMP(wo.tl, 7);
 }
 
@@ -136,11 +179,19 @@ int bamd_launch_attn_wo(const bamd_attn_args & t, int gq, const bamd_mv_args & w
     const int H = t.Hkv * gq, ld = t.lds_ld ? t.lds_ld : t.n_ctx;
     if (t.batch || t.cellpos || t.hd > 256 || (t.hd & 63) || gq < 1 || gq > 8 || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || il < 0 || il > 255) return 1;
     const int nb = wo.K >> 8, type = wo.seg[0].type;
-    if (wo.nseg != 1 || nb != 16 || (wo.mode & 31) != 0 || !wo.res) return 1;                // K = 4096: two records per wave and row-group
+    if (wo.nseg != 1 || (nb != 16 && nb != 32) || (wo.mode & 31) != 0 || !wo.res) return 1;  // K = 4096: two records per wave and row-group; K = 8192: four, in batches
     const int G = n_cu - H, nrg = wo.seg[0].nrows >> 3;
-    if (G < 8 || nrg / G != 2) return 1;                                                      // two or three row-groups per wo workgroup
+    if (G < 8) return 1;
+    if (nb == 16 && nrg / G != 2) return 1;                                                   // two or three row-groups per wo workgroup
+    if (nb == 32) {
+        // the 70B width: MEASURED NEUTRAL (round 4: a 10-layer stage 1.267 ms per token co-launched against 1.260 with the two launches; the whole model 110.9
+        // against 115.2 tok/s in one bench.py pairing) — the wo role's 5 - 6 row-groups x 32 records are 190 KB per workgroup, of which only the first
+        // batch can be in flight while the attention role works, and the hand-over costs what the boundary did.  BAMD_COLAUNCH70=1 selects it.
+        static const bool on70 = [] { const char * e = getenv("BAMD_COLAUNCH70"); return e && e[0] == '1'; }();
+        if (!on70 || nrg / G < 2) return 1;
+    }
     const int extra = nrg - 2 * G;
-    const size_t lds_wo = act_lds_bytes(wo.K) + 16 + (size_t) 3 * nb * 256 * 4, lds_at = (size_t) ld * 8;
+    const size_t lds_wo = act_lds_bytes(wo.K) + 16 + (nb == 32 ? (size_t) 2 * 2 * nb * 256 * 4 : (size_t) 3 * nb * 256 * 4), lds_at = (size_t) ld * 8;
     const size_t lds = lds_wo > lds_at ? lds_wo : lds_at;
     const dim3 grid(n_cu), block(512);
 #define BAMD_CL(LG_, T_) hipLaunchKernelGGL((attn_wo_kernel<LG_, T_>), grid, block, lds, s, t, gq, wo, gran, il, extra, g_ring_delay, err)

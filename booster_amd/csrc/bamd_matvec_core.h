@@ -220,11 +220,15 @@ __device__ __forceinline__ void stream_pair_short(const uint8_t * __restrict__ w
 // (record by record) instead of one full wait at the loop head
 // UNEVEN: K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks): the first nb % 8 waves take NBW records of
 // a row-group, the others NBW - 1; a wave's ring slot past its share re-requests its last record and its term is not parked (wave-uniform).
-template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false, bool UNEVEN = false>
+// PRE: called once between the first ring requests and the activation prologue (default: nothing).  The co-launched attention || wo kernel waits
+// there for its activations (granules of the attention role, bamd_colaunch.hip) and fills ap.v itself: the weights of the first batch are in
+// flight while it waits.
+struct SplitNoPre { __device__ __forceinline__ void operator()() const { } };
+template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false, bool UNEVEN = false, typename PRE = SplitNoPre>
 __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
                                              ActPro<PRO == BAMD_PRO_NORM> & ap, ActPro<PRO == BAMD_PRO_NORM> & ap2, bool issue_here, bool do_pro,
-                                             float * part0, int & batchctr, int nvalid) {
+                                             float * part0, int & batchctr, int nvalid, PRE pre = PRE()) {
     constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;     // bamd_record_bytes
     constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -272,6 +276,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     };
     ring_fill(0, DH);
     TL_STAMP(pa.tl, 1);
+    pre();
     if (do_pro) {
         if (OWN) {
             static_assert(NBW <= 2 * BAMD_ACT_BATCH, "own-slice prologue handles two batches");

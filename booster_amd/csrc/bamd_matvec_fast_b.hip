@@ -35,7 +35,10 @@ __global__ void __launch_bounds__(64 * NW) matvec_split_fast_kernel(BAMD_LEAD_PA
 // 0..MA replay one chain each.  The type of the last row-group is a template parameter and the kernel branches on it ONCE, right
 // after the activation requests, so that each side is straight-line code with counted waits.  (Through mode A this launch ran on 3
 // of 8 waves per CU, 16 records each: 10 us against 6.4 us for the all-Q4_K layers.)
-template <int TA, int TB, int NBW, int MA>
+// COMPACT (the 70B widths: five row-groups of 32 super-blocks per workgroup): a parked record takes 576 bytes — {fs, pm} per lane, {d, dmin} per row —
+// instead of a float4 per lane, so that the five term buffers fit the LDS (92 KB); the first MA - 2 rings go out at entry, the others behind the
+// prologue's first barrier
+template <int TA, int TB, int NBW, int MA, bool COMPACT = false>
 __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const ProArgs & pa, ActPro<true> & ap, float * part0, int g_last) {
     typedef typename RecOf<TA>::type RECA;
     typedef typename RecOf<TB>::type RECB_T;
@@ -49,8 +52,9 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
     const bamd_rsrc rs0 = weight_rsrc(a.seg[0].w), rs1 = weight_rsrc(SAME ? a.seg[0].w : a.seg[1].w);
     const int rgbA = nb * RA, rgbB = nb * RB;
     RECA ring[MA * NBW]; RECB_T ringL[NBW];
+    constexpr int MEARLY = COMPACT ? (MA > 2 ? MA - 2 : MA) : MA;      // rings requested at entry
 #pragma unroll
-    for (int m = 0; m < MA; ++m)
+    for (int m = 0; m < MEARLY; ++m)
 #pragma unroll
         for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs0, (b + m * grid) * rgbA + (i0 + j) * RA, lane);
     const int lastoff = SAME ? g_last * rgbA : (g_last - nrg0) * rgbB;
@@ -59,44 +63,63 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
     // accepting the first rings for ~1 us, and the barrier would wait for the slowest wave's issue stage)
     auto last_ring = [&]() {
 #pragma unroll
+        for (int m = MEARLY; m < MA; ++m)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) load_rec(ring[m * NBW + j], rs0, (b + m * grid) * rgbA + (i0 + j) * RA, lane);
+#pragma unroll
         for (int j = 0; j < NBW; ++j) load_rec(ringL[j], rs1, lastoff + (i0 + j) * RB, lane);
     };
     BAMD_PRO_FINISH_NB_MID(ap, pa, last_ring, BAMD_NB1(NBW));
     TL_STAMP(pa.tl, 2);
     const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
-    const size_t rg_floats = BAMD_TERM_FLOATS(nb);
+    const size_t rg_floats = COMPACT ? (size_t) nb * 144 : BAMD_TERM_FLOATS(nb);         // floats per parked row-group (compact: 576 bytes per record)
+    auto park = [&](float * base, int ci, const Terms & T) {
+        if (COMPACT) {
+            float * rec = base + (size_t) ci * 144;
+            *(float2 *) (rec + lane * 2) = make_float2(T.fs, T.pm);
+            if ((lane & 7) == 0) *(float2 *) (rec + 128 + r8 * 2) = make_float2(T.d, T.dmin);
+        } else ((float4 *) base)[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+    };
 #pragma unroll
     for (int m = 0; m < MA; ++m) {
-        float4 * P = (float4 *) (part0 + (size_t) m * rg_floats);
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             pin_rec(ring[m * NBW + j]);
             const Terms T = block_terms(ring[m * NBW + j], i0 + j, lane, q8, S, yd);
-            P[(i0 + j) * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+            park(part0 + (size_t) m * rg_floats, i0 + j, T);
         }
     }
     {
-        float4 * P = (float4 *) (part0 + (size_t) MA * rg_floats);
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
             pin_rec(ringL[j]);
             const Terms T = block_terms(ringL[j], i0 + j, lane, q8, S, yd);
-            P[(i0 + j) * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);
+            park(part0 + (size_t) MA * rg_floats, i0 + j, T);
         }
     }
     TL_STAMP(pa.tl, 3);
     __syncthreads();
     TL_STAMP(pa.tl, 4);
     if (wave <= MA) {                                        // one chain per wave, in the reference's order (split_stream)
-        const float4 * P = (const float4 *) (part0 + (size_t) wave * rg_floats);
+        const float * Pf = part0 + (size_t) wave * rg_floats;
+        const float4 * P = (const float4 *) Pf;
         const bool lastw = wave == MA;
         RowAcc A = { 0.f, 0.f };
         float val;
+        auto fetch8 = [&](int i, float4 (&t)[8]) {           // terms of super-blocks i .. i + 7 as {d, fs, dmin, pm}
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (COMPACT) {
+                    const float * rec = Pf + (size_t) (i + u) * 144;
+                    const float2 fp = *(const float2 *) (rec + lane * 2), dd = *(const float2 *) (rec + 128 + r8 * 2);
+                    t[u] = make_float4(dd.x, fp.x, dd.y, fp.y);
+                } else t[u] = P[(i + u) * 64 + lane];
+            }
+        };
         if (SAME || !lastw) {
             for (int i = 0; i < nb; i += 8) {
                 float4 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+                fetch8(i, t);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) chain_step<TA>(A, t[u].x, t[u].y, t[u].z, t[u].w);
             }
@@ -104,8 +127,7 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
         } else {
             for (int i = 0; i < nb; i += 8) {
                 float4 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = P[(i + u) * 64 + lane];
+                fetch8(i, t);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) chain_step<TB>(A, t[u].x, t[u].y, t[u].z, t[u].w);
             }
@@ -119,8 +141,8 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
         TL_STAMP(pa.tl, 5);
     }
 }
-template <int TA, int TB, int NBW, int MA>
-__global__ void __launch_bounds__(512) matvec_split_mixed_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+template <int TA, int TB, int NBW, int MA, bool COMPACT = false, int NW = 8>
+__global__ void __launch_bounds__(64 * NW) matvec_split_mixed_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
     BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TL_STAMP(a.tl, 0);
@@ -130,15 +152,15 @@ __global__ void __launch_bounds__(512) matvec_split_mixed_kernel(BAMD_LEAD_PARAM
     BAMD_PRO_ISSUE_NB(ap, pa, BAMD_NB1(NBW));
     float * part0 = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double));
     const int g_last = MA * (int) gridDim.x + (int) blockIdx.x;       // index of this workgroup's last row-group in the concatenated segments
-    if (g_last < (a.seg[0].nrows >> 3)) split_mixed_body<TA, TA, NBW, MA>(a, pa, ap, part0, g_last);
-    else                                split_mixed_body<TA, TB, NBW, MA>(a, pa, ap, part0, g_last);
+    if (g_last < (a.seg[0].nrows >> 3)) split_mixed_body<TA, TA, NBW, MA, COMPACT>(a, pa, ap, part0, g_last);
+    else                                split_mixed_body<TA, TB, NBW, MA, COMPACT>(a, pa, ap, part0, g_last);
     TL_STAMP(a.tl, 7);
 }
-template <int TA, int TB, int NBW, int MA>
+template <int TA, int TB, int NBW, int MA, bool COMPACT = false, int NW = 8>
 static void launch_mixed_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
-    const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (MA + 1) * nb * 256 * 4;
-    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a);
+    const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (MA + 1) * nb * (COMPACT ? 576 : 1024);
+    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA, COMPACT, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 // fused QKV launch with two differently typed segments; false: shape not covered (mode A takes it)
 bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s) {
@@ -148,6 +170,18 @@ bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, 
     const int nrg0 = a.seg[0].nrows >> 3, nrg1 = a.seg[1].nrows >> 3;
     if ((nb & 7) != 0 || nb > 8 * BAMD_ACT_BATCH || t0 == t1 || grid < 1 || (nrg0 + nrg1) % grid) return false;
     const int cnt = (nrg0 + nrg1) / grid, nbw = nb >> 3;
+    if (cnt == 5 && nrg0 >= 4 * grid && nbw == 4) {                             // the Llama-3-70B shape: K = 8192, five row-groups per workgroup (four of wq | wk, the fifth wk or wv)
+        // MEASURED AND NOT USED BY DEFAULT (round 4, MI355X, a 10-layer stage at the 70B widths, ms per token): one wave per row-group (mode A) 1.260, this
+        // split-K instance on eight waves (20 records per wave in registers) 1.275, on sixteen waves (10 records, 128 VGPRs) 1.293 — the prologue, the
+        // terms of a wave's records and a 32-step chain per workgroup cost more than five of eight waves streaming 32 records each.  BAMD_QKV70_WAVES=8 / 16
+        // selects it for the record (tests/test_gpu_fullsize_ref.py::test_config4_70b_stage runs bit-exact through either).
+        static const int nw70 = [] { const char * e = getenv("BAMD_QKV70_WAVES"); return e ? atoi(e) : 0; }();
+        if (nw70 != 8 && nw70 != 16) return false;
+#define BAMD_MX70(TA_, TB_) if (t0 == TA_ && t1 == TB_) { if (nw70 == 16) launch_mixed_inst<TA_, TB_, 2, 4, true, 16>(a, grid, s); else launch_mixed_inst<TA_, TB_, 4, 4, true>(a, grid, s); return true; }
+        BAMD_MX70(BAMD_Q4_K, BAMD_Q6_K) BAMD_MX70(BAMD_Q4_K, BAMD_Q5_K)
+#undef BAMD_MX70
+        return false;
+    }
     if (cnt != 3 || nrg0 < 2 * grid || nbw != 2) return false;                  // the Llama-3-8B / Mistral-7B shape: K = 4096, three row-groups per workgroup
 #define BAMD_MX(TA_, TB_) if (t0 == TA_ && t1 == TB_) { launch_mixed_inst<TA_, TB_, 2, 2>(a, grid, s); return true; }
     BAMD_MX(BAMD_Q4_K, BAMD_Q6_K) BAMD_MX(BAMD_Q4_K, BAMD_Q5_K) BAMD_MX(BAMD_Q5_K, BAMD_Q6_K)

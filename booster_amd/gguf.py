@@ -111,10 +111,12 @@ class GGUFWriter:
     def add_arr_str(self, k, v): self.kv.append((k, T_ARR, (T_STR, list(v))))
     def add_arr(self, k, et, v): self.kv.append((k, T_ARR, (et, list(v))))
 
-    def add_tensor(self, name, shape, ttype, data):
+    def add_tensor(self, name, shape, ttype, data, patch=None):
+        """patch: (byte offsets, xor value) applied while the tensor is written — several tensors may share ONE data array (the multi-GB synthetic
+        models reuse a layer's bytes) and still differ in the file"""
         data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
         assert data.size == tensor_nbytes(ttype, shape), (name, data.size, tensor_nbytes(ttype, shape))
-        self.tensors.append((name, list(shape), ttype, data))
+        self.tensors.append((name, list(shape), ttype, data, patch))
 
     @staticmethod
     def _s(s):
@@ -137,7 +139,7 @@ class GGUFWriter:
                 out += struct.pack(_SCALAR_FMT[t], v)
         off = 0
         offs = []
-        for name, shape, ttype, data in self.tensors:
+        for name, shape, ttype, data, _patch in self.tensors:
             out += self._s(name) + struct.pack("<I", len(shape))
             for d in shape:
                 out += struct.pack("<Q", d)
@@ -148,9 +150,16 @@ class GGUFWriter:
         out += b"\0" * pad
         with open(path, "wb") as f:
             f.write(out)
-            for (name, shape, ttype, data) in self.tensors:
+            for (name, shape, ttype, data, patch) in self.tensors:
+                start = f.tell()
                 f.write(memoryview(data))
                 f.write(b"\0" * ((-data.size) % DEFAULT_ALIGNMENT))
+                if patch is not None:
+                    end = f.tell()
+                    offs, x = patch
+                    for o in offs:
+                        f.seek(start + int(o)); f.write(bytes([int(data[int(o)]) ^ (int(x) & 0xff)]))
+                    f.seek(end)
 
 
     def write_split(self, path_prefix, n_split):
@@ -229,6 +238,18 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
             _cache[key] = random_kquant_tensor(t, cols, rows, rng, amp)
         return _cache[key]
 
+    def layer_patch(t, cols, rows, il):
+        """reuse_layers: the layers share their bytes in memory, but NOT in the file — layer il has (il + 1) XORed into one quant byte of 64 blocks
+        spread over each of its matrices (rows 0, rows/64, ...: first block of the row, a byte of the low-bit quants: any value is a well-formed
+        quant).  A loader that aliases one layer onto another — a layer-index or a > 4 GiB offset slip — then reads different weights and the
+        full-size fixtures (every logit digest of the reference's run) catch it; generation stays O(1) per layer."""
+        if not reuse_layers:
+            return None
+        bb = GGML_TYPES[t][1]; nb = cols // 256
+        qoff = {Q4_K: 16, Q5_K: 48, Q6_K: 0}[t]                # qs / qs / ql
+        n = min(64, rows)
+        return ([(k * rows // n) * nb * bb + qoff + (k % 32) for k in range(n)], il + 1)
+
     type_fn = type_fn or (lambda name, il: q4_k_m_type(name, il, L))
     hd = E // H
     w = GGUFWriter()
@@ -291,11 +312,11 @@ def write_synthetic_llama(path, E, H, Hkv, L, F, V, theta=500000.0, eps=1e-5, n_
         for nm, rows, cols, amp in (("attn_q", E, E, 2.0), ("attn_k", Hkv * hd, E, 2.0), ("attn_v", Hkv * hd, E, 1.0),
                                     ("attn_output", E, E, 1.0)):
             t = type_fn(nm, il)
-            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm), layer_patch(t, cols, rows, il))
         w.add_tensor(p + "ffn_norm.weight", [E], F32, norm())
         for nm, rows, cols, amp in (("ffn_gate", F, E, 1.5), ("ffn_up", F, E, 1.5), ("ffn_down", E, F, 1.0)):
             t = type_fn(nm, il)
-            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm))
+            w.add_tensor(p + nm + ".weight", [cols, rows], t, kq(t, cols, rows, amp, nm), layer_patch(t, cols, rows, il))
     if n_split > 1:                  # `path` is then the prefix; returns the shard paths (open the first)
         return w.write_split(path, n_split)
     w.write(path)

@@ -245,10 +245,36 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
                 config=dict(workload="%s shapes (synthetic GGUF), greedy batch-1 decode of ONE sequence, layer-split over %d MI355X "
                                      "(Booster's gpus: split), 128-token prompt, n_ctx %d" % (model_name, N, n_ctx),
                             parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state [n_embd] per boundary per token" % N,
-                            layer_ranges=ranges, sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
+                            rccl_ranks=N, layer_ranges=ranges, sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
                             pods_tokens_per_s=round(N * steps / dt_pods, 2),
                             note="value = one request through all stages (stages idle in turn: the reference's batch-1 behaviour); "
                                  "pods_tokens_per_s = N independent sequences in flight, every stage busy"),
                 roofline=dict(bound="hbm", achieved=slow["achieved_GBps"], peak=8000.0, unit="GB/s", frac=round(slow["achieved_GBps"] / 8000.0, 4), traffic=None,
                               kernel="slowest stage: weight bytes of its layer slice / its stage time per token (HIP events on the stage stream)",
                               stages=stages))
+
+
+def run_plumbing_check(N, rank, prompt, warmup, steps, dist, stage_cls, n_layer=5):
+    """bench.py --backend gloo: everything of the N > 1 leg EXCEPT the GPU stage — launch, rendezvous, layer ranges, the round schedule with its
+    two-phase use (warm-up, then K timed steps from the carried token), max-over-ranks timing, rank 0's JSON — on a deterministic CPU stand-in
+    for the stage (tests/test_pipeline_gloo.py: FakeStage).  `value` is the stand-in's rate and means nothing; `config.fed_tokens` lets the
+    test compare the pipelined tokens with a sequential evaluation."""
+    import torch
+    ranges = split_layers(n_layer, N)
+    stage = stage_cls(list(range(*ranges[rank])), rank == 0, rank == N - 1)
+    dist.barrier()
+    fed = run_pipeline(stage, dist, rank, N, prompt, warmup + 1, 1)
+    pos0 = len(prompt) + warmup
+    carry = [fed[0][-1] if rank == 0 else 0]
+    dist.barrier()
+    t0 = time.perf_counter()
+    fed2 = run_pipeline(stage, dist, rank, N, carry, steps, 1, pos_offset=pos0)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return dict(value=round(steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="strong",
+                config=dict(workload="PLUMBING CHECK on CPU (gloo): the layer-split schedule over %d ranks with a deterministic stand-in stage — not a measurement" % N,
+                            parallelism="layer-split pp%d" % N, gloo_ranks=N, layer_ranges=ranges, fed_tokens=(fed[0] + fed2[0]) if rank == 0 else []),
+                roofline=None)
