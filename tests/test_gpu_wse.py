@@ -92,3 +92,41 @@ def test_config2_8b_decode_on_the_engine_matches_reference(bamd):
         ctx.close(); m.close()
     finally:
         bamd.set_wse(0)
+
+
+def _run_on_engine(bamd, cfg, stepwise, expect_active):
+    import test_gpu_fullsize_ref as fr
+    bamd.set_wse(1)
+    try:
+        fx = fr.load_fixture(cfg)
+        _, n_prompt, n_decode, n_ctx = fr.gen.CONFIGS[cfg]
+        m = bamd.Model(fr.model_for(cfg, fx)); ctx = bamd.Context(m, n_ctx)
+        prompt = [(7919 * i + 13) % m.n_vocab for i in range(n_prompt)]
+        fr.check_step(fx, 0, ctx.decode(prompt, 0), cfg + " prompt")
+        n_past = n_prompt
+        for k in range(1, stepwise + 1):
+            lg = ctx.decode([int(fx["tokens"][k - 1])], n_past); n_past += 1
+            fr.check_step(fx, k, lg, cfg + " decode, engine requested")
+        active, why = ctx.wse_active()
+        assert active == expect_active, (active, why)
+        rest = n_decode - stepwise
+        out, _ = ctx.generate_greedy(n_past, rest)
+        assert list(out[:rest + 1]) == [int(t) for t in fx["tokens"][stepwise:n_decode + 1]]
+        fr.check_step(fx, n_decode, ctx.last_logits(), cfg + " last greedy step, engine requested")
+        ctx.close(); m.close()
+        return why
+    finally:
+        bamd.set_wse(0)
+
+
+def test_config4_70b_stage_on_the_engine_matches_reference(bamd):
+    """ten layers at the Llama-3-70B widths (K = 8192 / 28672, 64 query heads on 64 workgroups, Q5_K / Q6_K attn_v: CUs whose QKV run crosses a type
+    boundary get two pieces; ffn_down: twelve blocks of the hidden vector per consumer wave, two sweeps) on the engine, against the genuine reference"""
+    _run_on_engine(bamd, "70b_stage", 4, True)
+
+
+def test_engine_declines_shapes_without_a_program_and_the_launch_sequence_answers(bamd):
+    """Llama-2-7B: n_ff = 11008 = 43 super-blocks per ffn_down row — no engine program (8-record term chunks): with the engine requested the context
+    says why, runs the launch sequence, and still reproduces the reference"""
+    why = _run_on_engine(bamd, "l2_7b", 3, False)
+    assert "multiple of 8" in why
