@@ -552,7 +552,11 @@ static int wse_init(bamd_context * c) {
     if (m->hd % 64 || m->hd > 256) { w.why = "head_dim not 64 / 128 / 192 / 256"; return 1; }
     const size_t attn_lds = (size_t) ld * 8 + (size_t) 3 * m->hd * 4;
     if (bamd_wse_plan_build(&w.plan, L.data(), 0, nl, m->n_cu, m->E, m->H, m->Hkv, m->hd, m->F, nullptr, 0, m->V, attn_lds, g_wse_nc, BAMD_WSE_LDS_LIMIT)) { w.why = w.plan.why; return 1; }
-    if (bamd_wse_setup(m->hd)) { w.why = "the device refused the engine kernel's LDS size"; return 1; }
+    {
+        size_t static_lds = 0;
+        if (bamd_wse_setup(m->hd, &static_lds)) { w.why = "the device refused the engine kernel's LDS size"; bamd_wse_plan_free(&w.plan); return 1; }
+        if (w.plan.lds_bytes + static_lds > 160 * 1024) { w.why = "the engine's LDS plan plus the kernel's static LDS exceed 160 KiB"; bamd_wse_plan_free(&w.plan); return 1; }
+    }
     const size_t ob = (size_t) w.plan.n_cu * w.plan.ops_per_cu * sizeof(bamd_wse_op);
     if (dev_alloc(c->allocs, (void **) &w.d_ops, ob)) return 1;
     HIPC(hipMemcpy(w.d_ops, w.plan.ops, ob, hipMemcpyHostToDevice));

@@ -112,5 +112,5 @@ void bamd_wse_plan_free(bamd_wse_plan * plan);
 int bamd_wse_plan_single(bamd_wse_plan * plan, const bamd_wse_mat * wA, const bamd_wse_mat * wB, uint64_t normw, int epi, int n_cu, int nc, int lds_limit);
 // 0 = launched, 1 = refused
 int bamd_launch_wse(const bamd_wse_args & a, int n_cu, size_t lds_bytes, hipStream_t s);
-int bamd_wse_setup(int head_dim);      // once per head size, outside any stream capture (raises the kernels' dynamic-LDS limit)
+int bamd_wse_setup(int head_dim, size_t * static_lds = nullptr);      // once per head size, outside any stream capture (raises the kernels' dynamic-LDS limit; static_lds: the instance's static LDS bytes)
 int bamd_wse_selftest_launch(const uint8_t * src, uint32_t * out, hipStream_t s);

@@ -589,9 +589,16 @@ int bamd_wse_selftest_launch(const uint8_t * src, uint32_t * out, hipStream_t s)
 // BAMD_WSE_LDS_LIMIT of the planner).  Not allowed while a stream is being captured, so the
 // host calls this when it plans (head_dim = 0: programs without attention ops)
 static bool g_wse_attr[2][5] = { { false, false, false, false, false }, { false, false, false, false, false } };
-int bamd_wse_setup(int head_dim) {
+int bamd_wse_setup(int head_dim, size_t * static_lds) {
     const int lg = head_dim >> 6;
     if (lg < 0 || lg > 4 || (head_dim & 63)) return 1;
+    if (static_lds) {                                      // the instance's static LDS (the arrays of attn_fused_body): the planner's budget must leave room for it
+        hipFuncAttributes fa;
+        const void * fn = lg == 0 ? (const void *) wse_kernel<0, 768> : lg == 1 ? (const void *) wse_kernel<1, 768> : lg == 2 ? (const void *) wse_kernel<2, 768> :
+                          lg == 3 ? (const void *) wse_kernel<3, 768> : (const void *) wse_kernel<4, 768>;
+        if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void) hipGetLastError(); return 1; }
+        *static_lds = fa.sharedSizeBytes;
+    }
 #define WSE_ATTR(LG_) do { \
         if (!g_wse_attr[0][LG_] && hipFuncSetAttribute((const void *) wse_kernel<LG_, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2560) != hipSuccess) { (void) hipGetLastError(); return 1; } \
         if (!g_wse_attr[1][LG_] && hipFuncSetAttribute((const void *) wse_kernel<LG_, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2560) != hipSuccess) { (void) hipGetLastError(); return 1; } \
