@@ -4,7 +4,7 @@
 //
 // Intra-CU hand-overs are LDS words (the LDS of a CU is one in-order unit: a wave's data writes are visible before its later flag write):
 //   filled       = number of slots whose DMA has landed, in program order             (loader -> consumers; slot g lives at ring position g % ns)
-//   freec[slot] += 1 per record copied out of the slot into registers               (consumers -> loader; monotonic)
+//   freec[slot] += 1 per record whose LDS reads have been issued                     (consumers -> loader; monotonic; expect[slot] is the loader's own tally)
 //   chunk[c]    += 1 per record parked in term chunk c (8 records)                  (consumers -> chainers; the chainer that owns the chunk resets it)
 //   rel[c]       = how many times term chunk c has been read and handed back        (chainers -> consumers: record g may be parked when rel >= g / tr)
 //   pieces[k]    = pieces chainer k has finished                                    (chainers -> consumers: the attention scratch aliases the term ring)
@@ -18,12 +18,11 @@
 #define WSE_SPINS_LDS (1u << 21)       /* bounded waits: ~0.2 s of LDS polling / ~1 s of granule polling, then give up (err) and run on */
 #define WSE_SPINS_GLB (1u << 20)
 
-enum { W_FILL = 0, W_FREE = 16, W_EXPECT = 32, W_CHAIN_DONE = 48, W_CBAR = 49, W_CBAR8 = 50, W_ABORT = 51, W_GATHERING = 52, W_FILLED = 53, W_PIECES = 56, W_CHUNK = 64, W_REL = 80,
+enum { W_FREE = 16, W_EXPECT = 32, W_CBAR = 49, W_CBAR8 = 50, W_ABORT = 51, W_GATHERING = 52, W_FILLED = 53, W_PIECES = 56, W_CHUNK = 64, W_REL = 80,
        W_RED_BYTES = 384, W_STASH_BYTES = 512 };       /* words of the control block; red: 16 doubles; stash: BAMD_WSE_STASH floats */
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t * w) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void lds_st(uint32_t * w, uint32_t v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wse_fail(const bamd_wse_args & a, uint32_t * misc, uint32_t code) {
     if ((threadIdx.x & 63) == 0) {
         lds_st(misc + W_ABORT, 1u);
