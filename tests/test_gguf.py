@@ -101,3 +101,24 @@ def test_model_header_is_validated_before_any_device(tmp_path):
     assert load_error(blob[: len(blob) // 2]) != ""                  # truncated file
     if booster_amd.device_count() <= 0:
         assert "no HIP device" in load_error(blob)                    # the well-formed file: refused only for want of a GPU
+
+
+def test_reused_layers_differ_in_the_file(tmp_path):
+    """the multi-GB synthetic models generate a layer's bytes once (reuse_layers) but must NOT be byte-identical layer to layer in the file: the writer XORs
+    (layer + 1) into one quant byte of up to 64 blocks of every matrix, so that a loader aliasing one layer onto another shows in the full-size fixtures.
+    The patched bytes are low-bit quants (any value is a well-formed quant): scales and f16 block scales are untouched."""
+    import numpy as np
+    from booster_amd import gguf
+    p = str(tmp_path / "lid.gguf")
+    gguf.write_synthetic_llama(p, E=512, H=8, Hkv=2, L=4, F=768, V=512, seed=7, reuse_layers=True, type_fn=lambda name, il: {"attn_v": gguf.Q6_K, "ffn_down": gguf.Q5_K}.get(name, gguf.Q4_K))
+    r = gguf.GGUFReader(p)
+    qoff = {gguf.Q4_K: (16, 144), gguf.Q5_K: (48, 176), gguf.Q6_K: (0, 210)}
+    for nm in ("attn_q", "attn_k", "attn_v", "attn_output", "ffn_gate", "ffn_up", "ffn_down"):
+        t = [r.tensors["blk.%d.%s.weight" % (i, nm)] for i in range(4)]
+        d = [np.asarray(x["data"]) for x in t]
+        lo, bb = qoff[t[0]["type"]]
+        for i in range(4):
+            for j in range(i + 1, 4):
+                diff = np.flatnonzero(d[i] != d[j])
+                assert 1 <= diff.size <= 64, (nm, i, j, diff.size)
+                assert ((diff % bb) >= lo).all() and ((diff % bb) < lo + 128).all(), "a patched byte is not a low-bit quant"
