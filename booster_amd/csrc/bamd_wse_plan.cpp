@@ -89,22 +89,24 @@ struct Planner {
             cu[c].ops.push_back(op);
         }
     }
+    int tr_force = 0;                                      // experiments (BAMD_WSE_TR): term-ring records, a power of two (0: 32, or more when the ring has 8 slots)
     int finish(bamd_wse_plan * plan, size_t attn_lds, int lds_limit) {
         size_t mx = 0;
         for (auto & P : cu) mx = std::max(mx, P.ops.size());
         plan->n_cu = n_cu; plan->nc = nc; plan->ops_per_cu = (int) mx + 1; plan->tl_ops = tl_ops;
         // LDS: ring | act 0 | act 1 | term ring (the attention scratch aliases it: the consumers wait for the chainer before an ATTN op) | control words
         const size_t fixed = act_need[0] + act_need[1] + BAMD_WSE_MISC_BYTES;
-        int tr = 32;
+        int tr = tr_force >= 8 && tr_force <= BAMD_WSE_MAX_TERMS && !(tr_force & (tr_force - 1)) ? tr_force : 32;
         size_t terms = std::max((size_t) tr * BAMD_WSE_TERM_BYTES, (attn_lds + 15) & ~(size_t) 15);
         long ring = (long) lds_limit - (long) fixed - (long) terms;
         int ns = (int) (ring / BAMD_WSE_SLOT);
-        if (ns > 8) {                         // room to spare: a deeper term ring (a power of two: the kernel masks record numbers)
+        if (ns > 8 && !tr_force) {            // room to spare: a deeper term ring (a power of two: the kernel masks record numbers)
             ns = 8;
             const size_t room = ((size_t) lds_limit - fixed - (size_t) ns * BAMD_WSE_SLOT) / BAMD_WSE_TERM_BYTES;
             tr = room >= 128 ? 128 : room >= 64 ? 64 : 32;
             terms = std::max((size_t) tr * BAMD_WSE_TERM_BYTES, (attn_lds + 15) & ~(size_t) 15);
         }
+        if (ns > 8) ns = 8;
         if (ns < 3) { snprintf(plan->why, sizeof plan->why, "LDS: %zu B of activations + %zu B of terms leave %d ring slots", fixed, terms, ns); return 1; }
         plan->ns = ns; plan->tr = tr;
         plan->off_act[0] = (uint32_t) ((size_t) ns * BAMD_WSE_SLOT); plan->off_act[1] = plan->off_act[0] + (uint32_t) act_need[0];
@@ -124,6 +126,7 @@ int bamd_wse_plan_build(bamd_wse_plan * plan, const bamd_wse_layer * L, int l0, 
     memset(plan, 0, sizeof *plan);
     (void) E; (void) F; (void) V; (void) Hkv; (void) hd;
     Planner pl; pl.n_cu = n_cu; pl.nc = nc; pl.cu.resize((size_t) n_cu);
+    { const char * e = getenv("BAMD_WSE_TR"); pl.tr_force = e ? atoi(e) : 0; }
     bool ok = true;
     if (H > n_cu) { snprintf(plan->why, sizeof plan->why, "more query heads than CUs"); return 1; }
     if (l1 - l0 > 250) { snprintf(plan->why, sizeof plan->why, "more than 250 layers in one program (8-bit tags)"); return 1; }

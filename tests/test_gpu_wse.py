@@ -130,3 +130,32 @@ def test_engine_declines_shapes_without_a_program_and_the_launch_sequence_answer
     says why, runs the launch sequence, and still reproduces the reference"""
     why = _run_on_engine(bamd, "l2_7b", 3, False)
     assert "multiple of 8" in why
+
+
+def test_engine_soak_equals_launch_sequence(bamd):
+    """several hundred consecutive engine steps per context, four prompts, against the launch sequence's greedy tokens and final logits on the same model: a stale granule,
+    a tag that repeats, a ring slot refilled too early or a term chunk released twice would change a token somewhere (every run re-uses the granule vectors, the tags advance
+    with the device step and the host serial).  Positions stay below the single-launch attention's limit, where the engine is active."""
+    import test_gpu_fullsize_ref as fr
+    fx = fr.load_fixture("8b")
+    path = fr.model_for("8b", fx)
+    V = 128256
+    runs = []
+    for on in (0, 1):
+        bamd.set_wse(on)
+        try:
+            m = bamd.Model(path); ctx = bamd.Context(m, 512)
+            res = []
+            for seed in range(4):
+                prompt = [(104729 * i + 7 * seed + 1) % V for i in range(24 + 8 * seed)]
+                ctx.decode(prompt, 0)
+                out, _ = ctx.generate_greedy(len(prompt), 380)
+                res.append((out.copy(), ctx.last_logits().view(np.uint32).copy()))
+            if on:
+                assert ctx.wse_active()[0]
+            ctx.close(); m.close()
+            runs.append(res)
+        finally:
+            bamd.set_wse(0)
+    for (ta, la), (tb, lb) in zip(*runs):
+        assert np.array_equal(ta, tb) and np.array_equal(la, lb)
