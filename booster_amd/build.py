@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libbooster_amd.so")
-SOURCES = ["bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_attention_mfma.hip", "bamd_colaunch.hip", "bamd_wse.hip", "bamd_wse_plan.cpp", "bamd_prefill.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
-HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_wse.h", "bamd_device.h", "bamd_matvec_core.h", "bamd_attn_fused.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
+SOURCES = ["bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_attention_mfma.hip", "bamd_colaunch.hip", "bamd_wse.hip", "bamd_wse_plan.cpp", "bamd_prefill.hip", "bamd_prefill2.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
+HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_wse.h", "bamd_device.h", "bamd_matvec_core.h", "bamd_attn_fused.h", "bamd_mfma_common.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
 # -ffp-contract=off: the numerics contract (bit-parity with the reference CPU path) forbids implicit FMA fusion.
 # -fno-slp-vectorize (decode kernels only, NO_SLP): SLP packs neighbouring f32 multiplies into v_pk_mul_f32, whose operands need
 # even-aligned register pairs: the copies it adds sit right behind the loads (a full s_waitcnt before the weight ring could be

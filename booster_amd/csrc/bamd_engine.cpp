@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,6 +29,9 @@ static thread_local std::string g_err;
 static int g_prefill_batch = [] { const char * e = getenv("BAMD_PREFILL_BATCH"); return (e && e[0] == '0') ? 0 : 1; }();
 // BAMD_PREFILL_MFMA=0: Q4_K mat-muls of the batched prefill on the integer-dot kernel instead of the MFMA kernel (same bits)
 static int g_prefill_mfma = [] { const char * e = getenv("BAMD_PREFILL_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
+// BAMD_PREFILL_V=1: the round-2 MFMA kernels (bamd_prefill.hip: every wave expands its own 16 rows); default 2: bamd_prefill2.hip (fragments built once per
+// workgroup, load-time side tables).  Same bits; a matrix without a side table (allocation failed) takes the round-2 kernel
+static int g_prefill_v = [] { const char * e = getenv("BAMD_PREFILL_V"); return (e && e[0] == '1') ? 1 : 2; }();
 // BAMD_STAGE_GRAPH=0: bamd_stage_step enqueues its kernels one by one instead of replaying a captured hipGraph
 static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
@@ -103,6 +107,8 @@ struct DevMat {                      // one quantised matrix resident in HBM
 struct DevLayer {
     float * attn_norm = nullptr, * ffn_norm = nullptr;
     DevMat wq, wk, wv, wo, wg, wu, wd;
+    // prefill side tables (bamd_prefill2.hip), built at the first batched evaluation: one per QKV segment as enqueue_prefill_batch merges them, wo, gate, up, down
+    void * aux_qkv[3] = { nullptr, nullptr, nullptr }, * aux_o = nullptr, * aux_g = nullptr, * aux_u = nullptr, * aux_d = nullptr;
 };
 
 struct bamd_model {
@@ -120,6 +126,7 @@ struct bamd_model {
     int n_cu = 256;
     std::unique_ptr<GgufFile> file;  // stays mapped (bamd_model_tensor_raw)
     std::vector<void *> allocs;
+    std::mutex aux_mu; bool aux_tried = false; int64_t aux_bytes = 0;
 };
 
 struct bamd_context {
@@ -790,7 +797,36 @@ static bool prefill_batch_supported(const bamd_context * c, int pos_hi) {
         if (!ok(ly.wq.type, m->E) || !ok(ly.wk.type, m->E) || !ok(ly.wv.type, m->E) || !ok(ly.wo.type, m->E) || !ok(ly.wg.type, m->E) || !ok(ly.wu.type, m->E) || !ok(ly.wd.type, m->F)) return false;
     return true;
 }
+// prefill side tables of every layer matrix (bamd_prefill2.hip), built once per model at the first batched evaluation.  The QKV segments are the ones
+// enqueue_prefill_batch forms (equal-typed neighbours of the fused wq | wk | wv stream merge into one matrix).  An allocation that fails leaves that
+// pointer null: the matrix then runs on the round-2 kernel.
+static void ensure_prefill_aux(bamd_model * m, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(m->aux_mu);
+    if (m->aux_tried || g_prefill_v != 2 || !g_prefill_mfma) return;
+    m->aux_tried = true;
+    auto make = [&](const void * stream, int type, int nrows_pad, int K) -> void * {
+        const size_t b = bamd_prefill_aux_bytes(type, nrows_pad, K);
+        void * p = nullptr;
+        if (!b || hipMalloc(&p, b) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        m->allocs.push_back(p); m->aux_bytes += (int64_t) b;
+        bamd_launch_prefill_aux(stream, type, nrows_pad, K, p, s);
+        return p;
+    };
+    for (DevLayer & ly : m->layers) {
+        struct Seg { const void * w; int type, nrows; } seg[3]; int n = 1;
+        seg[0] = { ly.wq.stream, ly.wq.type, ly.wq.nrows_pad };
+        if (ly.wk.type == ly.wq.type) seg[0].nrows += ly.wk.nrows_pad; else seg[n++] = { ly.wk.stream, ly.wk.type, ly.wk.nrows_pad };
+        if (ly.wv.type == ly.wk.type) seg[n - 1].nrows += ly.wv.nrows_pad; else seg[n++] = { ly.wv.stream, ly.wv.type, ly.wv.nrows_pad };
+        for (int i = 0; i < n; ++i) ly.aux_qkv[i] = make(seg[i].w, seg[i].type, seg[i].nrows, m->E);
+        ly.aux_o = make(ly.wo.stream, ly.wo.type, ly.wo.nrows_pad, m->E);
+        ly.aux_g = make(ly.wg.stream, ly.wg.type, ly.wg.nrows_pad, m->E);
+        ly.aux_u = make(ly.wu.stream, ly.wu.type, ly.wu.nrows_pad, m->E);
+        ly.aux_d = make(ly.wd.stream, ly.wd.type, ly.wd.nrows_pad, m->F);
+    }
+    hipStreamSynchronize(s);
+}
 static int ensure_batch_buffers(bamd_context * c) {
+    ensure_prefill_aux(c->m, c->stream);
     if (c->bcap) return 0;
     bamd_model * m = c->m;
     const size_t T = BAMD_PREFILL_CAP, Ekv = (size_t) m->Hkv * m->hd;
@@ -802,16 +838,21 @@ static int ensure_batch_buffers(bamd_context * c) {
     c->bcap = (int) T;
     return 0;
 }
-// one batched mat-mul: Q4_K segments on the MFMA kernel, the rest on the integer-dot kernel (identical bits either way)
-static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_t s) {
+// one batched mat-mul: K-quant segments on the matrix-core kernels (round-5 kernel where the segment has a side table), the rest on the integer-dot kernel
+// (identical bits either way).  aux[i]: side table of segment i (null: none)
+static int mm_mfma(const bamd_mv_seg & sg, const void * aux, int nv, int K, const void * blob16, int T, float * out, const float * res, int epi, int ldo, hipStream_t s) {
+    if (aux && g_prefill_v == 2) return bamd_launch_matmul_mfma2(sg.w, aux, sg.type, nv, sg.nrows, K, blob16, T, out, res, epi, ldo, s);
+    return bamd_launch_matmul_mfma(sg.w, sg.type, nv, sg.nrows, K, blob16, T, out, res, epi, ldo, s);
+}
+static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_t s, const void * const * aux) {
     bamd_model * m = c->m;
     const bool mfma_ok = g_prefill_mfma;
     if (epi == BAMD_EPI_SILU_MUL) {
         if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q5_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
             const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
-            if (bamd_launch_matmul_mfma(a.seg[0].w, a.seg[0].type, nv, a.seg[0].nrows, a.K, c->bblob16, T, a.seg[0].out, nullptr, BAMD_EPI_STORE, a.ldo, s)) return 1;   // gate -> h
+            if (mm_mfma(a.seg[0], aux[0], nv, a.K, c->bblob16, T, a.seg[0].out, nullptr, BAMD_EPI_STORE, a.ldo, s)) return 1;   // gate -> h
             // up, with h = silu(gate) * up as its epilogue (every element is read and rewritten by the one lane that owns it)
-            if (bamd_launch_matmul_mfma(a.seg[1].w, a.seg[1].type, nv, a.seg[1].nrows, a.K, c->bblob16, T, a.seg[0].out, a.seg[0].out, BAMD_EPI_SILU_MUL, a.ldo, s)) return 1;
+            if (mm_mfma(a.seg[1], aux[1], nv, a.K, c->bblob16, T, a.seg[0].out, a.seg[0].out, BAMD_EPI_SILU_MUL, a.ldo, s)) return 1;
             return 0;
         }
         return bamd_launch_matmul_batch(a, epi, m->n_cu, s);
@@ -821,7 +862,7 @@ static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_
         if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q5_K || a.seg[i].type == BAMD_Q6_K)) {
             const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
             const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
-            if (bamd_launch_matmul_mfma(a.seg[i].w, a.seg[i].type, nv, a.seg[i].nrows, a.K, c->bblob16, T, a.seg[i].out, res, res ? BAMD_EPI_ADD : BAMD_EPI_STORE, a.ldo, s)) return 1;
+            if (mm_mfma(a.seg[i], aux[i], nv, a.K, c->bblob16, T, a.seg[i].out, res, res ? BAMD_EPI_ADD : BAMD_EPI_STORE, a.ldo, s)) return 1;
         } else rest.seg[rest.nseg++] = a.seg[i];
     }
     if (rest.nseg) {
@@ -852,7 +893,7 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         if (ly.wv.type == ly.wk.type) { a.seg[a.nseg - 1].nrows += ly.wv.nrows; a.seg[a.nseg - 1].nvalid += ly.wv.nrows; }
         else { seg_of(a.seg[a.nseg], ly.wv, c->bqkv + E + Ekv); a.nseg++; }
         a.blob = c->bblob; a.K = E; a.T = T; a.ldo = ldq;
-        if (batch_mm(c, a, BAMD_EPI_STORE, T, s)) return fail("batched mat-mul: unsupported shape");
+        if (batch_mm(c, a, BAMD_EPI_STORE, T, s, ly.aux_qkv)) return fail("batched mat-mul: unsupported shape");
         // RoPE, KV store, attention with the T>1 semantics                  (llama.cpp:8837-8849, :8318-8353)
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->bqkv; t.k = c->bqkv + E; t.v = c->bqkv + E + Ekv; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.out = c->batt;
@@ -876,17 +917,17 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         bamd_launch_quantize_batch(c->batt, nullptr, 0.f, E, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wo, c->bx2); a.nseg = 1; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = E; a.res = c->bx;
-        if (batch_mm(c, a, BAMD_EPI_ADD, T, s)) return fail("batched mat-mul: unsupported shape");
+        { const void * ax[3] = { ly.aux_o, nullptr, nullptr }; if (batch_mm(c, a, BAMD_EPI_ADD, T, s, ax)) return fail("batched mat-mul: unsupported shape"); }
         // h = silu(Wg . a) * (Wu . a)
         bamd_launch_quantize_batch(c->bx2, ly.ffn_norm, m->eps, E, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wg, c->bh); seg_of(a.seg[1], ly.wu, c->bh); a.nseg = 2; a.blob = c->bblob; a.K = E; a.T = T; a.ldo = F;
-        if (batch_mm(c, a, BAMD_EPI_SILU_MUL, T, s)) return fail("batched mat-mul: unsupported shape");
+        { const void * ax[3] = { ly.aux_g, ly.aux_u, nullptr }; if (batch_mm(c, a, BAMD_EPI_SILU_MUL, T, s, ax)) return fail("batched mat-mul: unsupported shape"); }
         // x = x2 + Wd . h
         bamd_launch_quantize_batch(c->bh, nullptr, 0.f, F, T, c->bblob, c->bblob16, s);
         memset(&a, 0, sizeof a);
         seg_of(a.seg[0], ly.wd, c->bx); a.nseg = 1; a.blob = c->bblob; a.K = F; a.T = T; a.ldo = E; a.res = c->bx2;
-        if (batch_mm(c, a, BAMD_EPI_ADD, T, s)) return fail("batched mat-mul: unsupported shape");
+        { const void * ax[3] = { ly.aux_d, nullptr, nullptr }; if (batch_mm(c, a, BAMD_EPI_ADD, T, s, ax)) return fail("batched mat-mul: unsupported shape"); }
     }
     if (m->with_output) HIPC(hipMemcpyAsync(c->x, c->bx + (size_t) (T - 1) * E, (size_t) E * 4, hipMemcpyDeviceToDevice, s));
     else HIPC(hipMemcpyAsync(hidden_out, c->bx, (size_t) T * E * 4, hipMemcpyDeviceToDevice, s));
@@ -1487,7 +1528,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int ty
                                    const float * residual, float * y, int mode) {
     return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, mode);
 }
-// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = MFMA kernel (Q4_K)
+// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = round-2 MFMA kernel, 2 = round-5 MFMA kernel
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int type, const void * w_raw, int nrows, int k, const float * x, int T, const float * norm_w,
                                                                               float eps, const float * residual, float * y, int impl) {
     if (need_device()) return 1;
@@ -1502,7 +1543,12 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     HIPC(hipMemset(str, 0, wbp));
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
-    if (impl == 1) {
+    if (impl == 2) {                                                // round-5 kernel: side table built here, as the engine builds it at the first batched evaluation
+        void * aux = t.up(nullptr, bamd_prefill_aux_bytes(type, nrows_pad, k));
+        if (!aux) return fail("device alloc failed");
+        bamd_launch_prefill_aux(str, type, nrows_pad, k, aux, nullptr);
+        if (bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
+    } else if (impl == 1) {
         if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
     } else {
         bamd_mm_args a; memset(&a, 0, sizeof a);

@@ -90,6 +90,12 @@ void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, in
 // BAMD_EPI_SILU_MUL: out = silu(res) * y (res = the gate projection, may alias out).  1 = type / shape not supported
 int  bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int epi,
                              int ldo, hipStream_t s);
+// round 5 (bamd_prefill2.hip): the same mat-mul with the A fragments built once per 64-row x 64-token workgroup; aux = the matrix's load-time side
+// table (bamd_prefill_aux_bytes bytes, filled by bamd_launch_prefill_aux from the wave-stream copy).  1 = type / shape not supported or no table
+size_t bamd_prefill_aux_bytes(int type, int nrows_pad, int K);
+void bamd_launch_prefill_aux(const void * w_stream, int type, int nrows_pad, int K, void * aux, hipStream_t s);
+int  bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res,
+                              int epi, int ldo, hipStream_t s);
 int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported

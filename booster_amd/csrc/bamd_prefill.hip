@@ -1,6 +1,7 @@
 // bamd_prefill.hip — batched prefill: per-token Q8_K quantisation into global blobs, the exact MFMA mat-mul kernels (Q4_K, Q6_K),
 // the integer-dot batched mat-mul (any K-quant), batched embedding, silu*up.  Helpers: bamd_device.h.
 #include "bamd_device.h"
+#include "bamd_mfma_common.h"
 #include <type_traits>
 
 // ===========================================================================================================
@@ -128,25 +129,6 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
 // then run on the VALU in the reference's order (ggml-quants.c:6937-6978) — bit-identical to the integer-dot kernels above.
 // MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3);
 // C/D rows 4g + i, token m (cdna_hip_programming.md, fragment layout).  One wave = 16 rows x 16 tokens over the whole K.
-typedef _Float16 bamd_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 bamd_h4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void * bamd_lds_vp;
-typedef const __attribute__((address_space(1))) void * bamd_glb_vp;
-// global -> LDS copy without registers: each active lane moves 16 (4) bytes from ITS global address to LDS base + lane * 16 (4).
-// Issued through inline asm on purpose: for the builtin the compiler cannot tell the destination buffer from the buffer being read
-// (both index the same dynamic LDS array) and puts s_waitcnt vmcnt(0) in front of the next LDS read, which serialises the copy with
-// the math it is meant to overlap.  The asm is invisible to the wait-count pass, so the consumer side waits explicitly
-// (lds_dma_wait before the barrier that publishes the stage); the compiler's own counted waits stay valid (completion is in order).
-__device__ __forceinline__ void lds_dma16(const void * gsrc, void * lds_wave_base) {
-    uint32_t keep; const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t) (size_t) (bamd_lds_vp) lds_wave_base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const void * gsrc, void * lds_wave_base) {
-    uint32_t keep; const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t) (size_t) (bamd_lds_vp) lds_wave_base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-// vmcnt(0) as the BUILTIN (imm: vmcnt 0, expcnt 7, lgkmcnt 15): the wait-count pass sees it and does not repeat it behind the next issue
-__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 // four i16-pair dot products -> float in one asm block: VOP3P v_dot2_i32_i16 d, a, b, 0 (the builtin becomes v_dot2c + a zero-init move per
 // product), the conversions four instructions behind their dots (a DOT result needs 3 wait states before a VALU read; inline asm is
 // not hazard-checked)
@@ -157,7 +139,6 @@ __device__ __forceinline__ void dot2x4_f32(const uint32_t (&m)[4], const uint32_
         : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
         : "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]));
 }
-typedef float bamd_f4 __attribute__((ext_vector_type(4)));
 struct bamd_mma_args {
     const uint8_t * w; float * out; const float * res;      // Q4_K wave-stream; out / res [T][ldo]
     const uint8_t * blob16; int K, T, nrows, nrows_pad, ldo;

@@ -88,6 +88,8 @@ def test_mul_mat_batch_sweep(bamd, po, i, t, K, rows, T, norm, resid):
     mfma = bamd.op_mul_mat_batch(t, W, rows, K, X, norm_w=w, eps=1e-5, residual=res, impl=1)
     idot = bamd.op_mul_mat_batch(t, W, rows, K, X, norm_w=w, eps=1e-5, residual=res, impl=0)
     assert np.array_equal(bits(mfma), bits(idot)), "case %d: MFMA and integer-dot kernels differ (type %d K %d rows %d T %d)" % (i, t, K, rows, T)
+    mfma2 = bamd.op_mul_mat_batch(t, W, rows, K, X, norm_w=w, eps=1e-5, residual=res, impl=2)
+    assert np.array_equal(bits(mfma2), bits(idot)), "case %d: round-5 MFMA and integer-dot kernels differ (type %d K %d rows %d T %d)" % (i, t, K, rows, T)
     for tok in sorted(set([0, T // 2, T - 1])):
         a = X[tok] if w is None else (po.rms_norm(X[tok], 1e-5) * w).astype(np.float32)
         want = po.mul_mat_q(t, W, rows, K, a, nthreads=8)[0]
