@@ -168,11 +168,9 @@ def main():
         assert world == N, "WORLD_SIZE %d but --gpus %d" % (world, N)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from test_pipeline_gloo import FakeStage, V as FAKE_V
         from booster_amd import pipeline
-        result = pipeline.run_plumbing_check(N, rank, [3, 1, 4, 1, 5], args.warmup, args.steps, dist, FakeStage)
-        emit(rank, dist, result, "plumbing check (stand-in stage, vocabulary %d)" % FAKE_V, N, args.steps, args.warmup)
+        result = pipeline.run_plumbing_check(N, rank, [3, 1, 4, 1, 5], args.warmup, args.steps, dist, pipeline.FakeStage)
+        emit(rank, dist, result, "plumbing check (stand-in stage, vocabulary %d)" % pipeline.FakeStage.V, N, args.steps, args.warmup)
         return
     import booster_amd
     from booster_amd import build as bbuild

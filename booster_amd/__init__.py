@@ -56,6 +56,7 @@ def lib():
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]; L.bamd_profile_step_kinds.argtypes = [vp, ci, vp, vp, vp]
         L.bamd_timeline_step.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
         L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
+        L.bamd_set_prefill_version.argtypes = [ci]; L.bamd_set_prefill_version.restype = None
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
         L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp, ci]
@@ -86,6 +87,11 @@ def _p(a):
 def set_prefill_batch(on):
     """True (default): prompts of 2..512 tokens go through the batched prefill kernels; False: token by token (same bits)."""
     lib().bamd_set_prefill_batch(int(on))      # 2: batched without the MFMA kernel
+
+
+def set_prefill_version(v):
+    """2 (default): the round-5 matrix-core prefill kernels (bamd_prefill2.hip, load-time side tables); 1: the round-2 kernels (bamd_prefill.hip).  Same bits."""
+    lib().bamd_set_prefill_version(int(v))
 
 
 def device_count():
@@ -265,7 +271,7 @@ def op_mul_mat_vec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=Non
 
 
 def op_mul_mat_batch(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, impl=0):
-    """Y[t] = W . Q8_K(x[t]) for T rows at once through the prefill kernels: impl 0 = integer-dot kernel, 1 = MFMA kernel (Q4_K)."""
+    """Y[t] = W . Q8_K(x[t]) for T rows at once through the prefill kernels: impl 0 = integer-dot kernel, 1 = round-2 MFMA kernel, 2 = round-5 MFMA kernel (3: its eight-wave Q4_K / Q5_K layout)."""
     w_raw = np.ascontiguousarray(w_raw, np.uint8); x = np.ascontiguousarray(x, np.float32)
     T = x.shape[0]
     nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)

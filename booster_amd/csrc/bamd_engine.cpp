@@ -32,6 +32,7 @@ static int g_prefill_mfma = [] { const char * e = getenv("BAMD_PREFILL_MFMA"); r
 // BAMD_PREFILL_V=1: the round-2 MFMA kernels (bamd_prefill.hip: every wave expands its own 16 rows); default 2: bamd_prefill2.hip (fragments built once per
 // workgroup, load-time side tables).  Same bits; a matrix without a side table (allocation failed) takes the round-2 kernel
 static int g_prefill_v = [] { const char * e = getenv("BAMD_PREFILL_V"); return (e && e[0] == '1') ? 1 : 2; }();
+extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_version(int v) { g_prefill_v = v == 1 ? 1 : 2; }   // tests: the same fixture through both kernel generations
 // BAMD_STAGE_GRAPH=0: bamd_stage_step enqueues its kernels one by one instead of replaying a captured hipGraph
 static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
@@ -1528,7 +1529,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int ty
                                    const float * residual, float * y, int mode) {
     return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, mode);
 }
-// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = round-2 MFMA kernel, 2 = round-5 MFMA kernel
+// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = round-2 MFMA kernel, 2 = round-5 MFMA kernel (3: its eight-wave Q4_K / Q5_K layout)
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int type, const void * w_raw, int nrows, int k, const float * x, int T, const float * norm_w,
                                                                               float eps, const float * residual, float * y, int impl) {
     if (need_device()) return 1;
@@ -1543,11 +1544,14 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     HIPC(hipMemset(str, 0, wbp));
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
-    if (impl == 2) {                                                // round-5 kernel: side table built here, as the engine builds it at the first batched evaluation
+    if (impl == 2 || impl == 3) {                                   // round-5 kernels (3: the eight-wave Q4_K / Q5_K layout): side table built here, as the engine builds it at the first batched evaluation
+        bamd_launch_prefill_waves(impl == 3 ? 8 : 16);
         void * aux = t.up(nullptr, bamd_prefill_aux_bytes(type, nrows_pad, k));
         if (!aux) return fail("device alloc failed");
         bamd_launch_prefill_aux(str, type, nrows_pad, k, aux, nullptr);
-        if (bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
+        const int rc2 = bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr);
+        bamd_launch_prefill_waves(16);
+        if (rc2) return fail("MFMA path: unsupported type/shape");
     } else if (impl == 1) {
         if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
     } else {

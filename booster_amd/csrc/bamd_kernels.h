@@ -96,6 +96,7 @@ size_t bamd_prefill_aux_bytes(int type, int nrows_pad, int K);
 void bamd_launch_prefill_aux(const void * w_stream, int type, int nrows_pad, int K, void * aux, hipStream_t s);
 int  bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res,
                               int epi, int ldo, hipStream_t s);
+void bamd_launch_prefill_waves(int waves);        // Q4_K / Q5_K workgroup layout of bamd_launch_matmul_mfma2: 16 (default) or 8 waves
 int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported

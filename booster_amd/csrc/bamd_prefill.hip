@@ -18,7 +18,7 @@
 // f16 copy of a token's Q8_K row for the MFMA path.  Per super-block BAMD_B16_REC = 608 B (560 used): 8 (e) x 4 (g) groups of 8 halves — group
 // (e, g) = the int8 of sub-blocks 2g and 2g+1, chunk e, as exact f16: one 16-byte B operand of v_mfma_f32_16x16x32_f16 per lane —
 // then, per pair l of sub-blocks, the four halves {S_h(2l), S_h(2l+1), S_l(2l), S_l(2l+1)} of the block sums split as S = 2 S_h + S_l
-// (the B operand of the Q4_K min-term MFMA), then the four i16 pairs (S_2l, S_2l+1) (Q5_K); after the nb super-blocks, yd[nb] f32.
+// (the B operand of the Q4_K min-term MFMA), then the four i16 pairs (S_2l, S_2l+1) (Q5_K), then the block scale d_y (f32, byte 560); after the nb super-blocks, yd[nb] f32 again.
 template <bool NORM>
 __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __restrict__ x, const float * __restrict__ nw, float eps, int K,
                                                              uint8_t * __restrict__ blob, uint8_t * __restrict__ blob16) {
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __res
             *(uint32_t *) (o + (size_t) ci * BAMD_B16_REC + 544 + l * 4) = ((uint32_t) sa & 0xffffu) | ((uint32_t) sb << 16);
         }
         float * oyd = (float *) (o + (size_t) nb * BAMD_B16_REC);
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) oyd[i] = yd[i];
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) { oyd[i] = yd[i]; *(float *) (o + (size_t) i * BAMD_B16_REC + 560) = yd[i]; }   // d_y also inside the record (bamd_prefill2.hip: no separate copy)
     }
 }
 

@@ -22,26 +22,31 @@
 #include "bamd_device.h"
 #include "bamd_mfma_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef _Float16 bamd_h2 __attribute__((ext_vector_type(2)));
 union bamd_h2u { uint32_t u; bamd_h2 h; };
 
 struct bamd_mma2_args {
     const uint8_t * w;               // wave-stream records of the matrix (bamd_formats.h)
-    const uint8_t * ph;              // prefill aux, builder part:  [row tile][super-block][64 lanes][16 B]
+    const uint8_t * ph;              // prefill aux, builder part:  [row block of 64][super-block]([e-half], Q6_K)[4 row tiles][64 MFMA lanes][16 B]
     const uint8_t * ch;              // prefill aux, consumer part: [row block of 64][super-block][4 row tiles][X_CH_RT B]
     float * out; const float * res;  // [T][ldo]
     const uint8_t * blob16;          // f16 activation records (quantize_batch_kernel)
     int K, T, nrows, nrows_pad, ldo;
+    unsigned long long * dbg;        // -DX_TIMING builds: per-wave phase clocks of workgroup (0, 0) (tools/prefill_phase.py); else unused
 };
 
 // LDS map (byte offsets).  Both copies of every region lie within 64 KiB of the region's first copy, so one base register per region
 // serves both buffers through the 16-bit offset field of the DS instructions (the buffer in use is a compile-time parity of the step).
-#define X_AF_BYTES 32768                                   /* A fragments of one super-block: 4 row tiles x 8 e x 1 KiB */
+#define X_FR 1040                                          /* bytes between fragments: 1 KiB + 16 — the builder's 16-byte stores of eight lanes (one row, e = 0..7) then fall on eight
+                                                              different bank quads (260 dwords = 4 mod 64); a fragment itself stays contiguous (lane * 16) for the consumers' ds_read_b128 */
+#define X_AF_BYTES (32 * X_FR)                             /* A fragments of one super-block: 4 row tiles x 8 fragments */
 #define X_BS_BYTES (64 * BAMD_B16_REC)                     /* 64 token records of one super-block (38 912 B) */
 #define X_CH4_RT 640                                       /* Q4_K / Q5_K consumer header of a row tile: 16 x {d, dmin} f32 + 16 x 4 x 8 B of min operands */
 #define X_CH6_RT 64                                        /* Q6_K: 16 x d f32 */
 #define X_CH_MAX (4 * X_CH4_RT)
+#define X3_CHS 3072                                        /* Q4_K / Q5_K consumer headers of a row block and super-block in the side table: 4 x 640 B, padded to three DMA instructions */
 #define X_BLK (X_BS_BYTES + X_CH_MAX + 256 + 32)           /* records | headers | 64 d_y | 32 bytes of zeros: 41 760 B */
 #define X_AF0 0
 #define X_BLK0 (2 * X_AF_BYTES)
@@ -70,8 +75,8 @@ __global__ void __launch_bounds__(64) prefill_aux_q4k_kernel(const uint8_t * __r
     o0.h = (bamd_h2) { s_lo, s_lo }; o1.h = (bamd_h2) { (_Float16) -1024.f * s_lo, (_Float16) -1024.f * s_lo };
     if (Q5) { o2.h = (bamd_h2) { s_hi, s_hi }; o3.h = (bamd_h2) { (_Float16) -1024.f * s_hi, (_Float16) -1024.f * s_hi }; }
     else    { o2.h = (bamd_h2) { (_Float16) 0.0625f * s_hi, (_Float16) 0.0625f * s_hi }; o3.h = (bamd_h2) { (_Float16) -64.f * s_hi, (_Float16) -64.f * s_hi }; }
-    *(uint4 *) (ph + ((size_t) rtile * nb + ci) * 1024 + lane * 16) = (uint4) { o0.u, o1.u, o2.u, o3.u };
-    uint8_t * c = ch + (((size_t) (rtile >> 2) * nb + ci) * 4 + (rtile & 3)) * X_CH4_RT;
+    *(uint4 *) (ph + (((size_t) (rtile >> 2) * nb + ci) * 4 + (rtile & 3)) * 1024 + lane * 16) = (uint4) { o0.u, o1.u, o2.u, o3.u };
+    uint8_t * c = ch + ((size_t) (rtile >> 2) * nb + ci) * X3_CHS + (rtile & 3) * X_CH4_RT;
     if (g == 0) { float2 dd; dd.x = h2f(hd.x & 0xffffu); dd.y = h2f(hd.x >> 16); *(float2 *) (c + m * 8) = dd; }
     {   // min operands of pair l = g: {2 m_2l, 2 m_2l+1, m_2l, m_2l+1}
         const uint32_t mw = ((g >> 1) ? mn47 : mn03) >> (16 * (g & 1));
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(64) prefill_aux_q6k_kernel(const uint8_t * __r
         const int s0 = (int) (int8_t) (wv & 0xffu), s1 = (int) (int8_t) ((wv >> 8) & 0xffu);
         const _Float16 a0 = (_Float16) (float) (s0 & ~15), l0 = (_Float16) (float) (s0 & 15), a1 = (_Float16) (float) (s1 & ~15), l1 = (_Float16) (float) (s1 & 15);
         bamd_h2u o0, o1, o2, o3; o0.h = (bamd_h2) { a0, a0 }; o1.h = (bamd_h2) { l0, l0 }; o2.h = (bamd_h2) { a1, a1 }; o3.h = (bamd_h2) { l1, l1 };
-        *(uint4 *) (ph + (((size_t) rtile * nb + ci) * 2 + h) * 1024 + lane * 16) = (uint4) { o0.u, o1.u, o2.u, o3.u };
+        *(uint4 *) (ph + ((((size_t) (rtile >> 2) * nb + ci) * 2 + h) * 4 + (rtile & 3)) * 1024 + lane * 16) = (uint4) { o0.u, o1.u, o2.u, o3.u };
     }
     if (g == 0) *(float *) (ch + (((size_t) (rtile >> 2) * nb + ci) * 4 + (rtile & 3)) * X_CH6_RT + m * 4) = h2f(d16);
 }
@@ -145,32 +150,30 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a)
     const size_t b16 = BAMD_BLOB16_BYTES(nb);
     const uint32_t lds0 = (uint32_t) (size_t) (bamd_lds_vp) smem;
     XStage<160> stg; stg.plan(tid, wave, lane, t0, a.T, b16, nb);
-    const uint8_t * chb = a.ch + (size_t) rb * nb * (4 * X_CH4_RT);
-#define X_STAGE(ci_, b_) stg.issue(a.blob16 + (size_t) (ci_) * BAMD_B16_REC, chb + (size_t) (ci_) * (4 * X_CH4_RT), a.blob16 + (size_t) (ci_) * 4, lds0 + X_BLK0 + (uint32_t) (b_) * X_BLK, wave, lane)
-    // builder: raw nibble dwords of fragments e = 4 tp + j (j = 0..3) of row tile rt, and the lane's scale operands
-    const int rg0 = (live ? rtg : rb * 4) * 2;
-    const bool two = (rg0 + 1) * 8 < a.nrows_pad;                   // a last tile of 8 (padded) rows reads its first record group twice (rows 8..15 are never stored)
-    const uint8_t * wrec = a.w + (size_t) rg0 * nb * RECB;
-    const uint32_t vraw = ((m >= 8 && two) ? (uint32_t) nb * RECB : 0u) + (uint32_t) ((m & 7) * 8 + 4 * tp) * 16u + (uint32_t) g * 4u;
-    const uint32_t vqh = ((m >= 8 && two) ? (uint32_t) nb * RECB : 0u) + 1024u + (uint32_t) ((m & 7) * 8 + 4 * tp) * 4u;
-    const uint8_t * phb = a.ph + (size_t) rtg * nb * 1024 + (size_t) lane * 16;
-    uint32_t raw[2][4], qh[2][4]; uint4 sc[2];
+    const uint8_t * chb = a.ch + (size_t) rb * nb * X3_CHS;
+#define X_STAGE(ci_, b_) stg.issue(a.blob16 + (size_t) (ci_) * BAMD_B16_REC, chb + (size_t) (ci_) * X3_CHS, a.blob16 + (size_t) (ci_) * 4, lds0 + X_BLK0 + (uint32_t) (b_) * X_BLK, wave, lane)
+    // builder, in the wave-stream's own lane order: wave (rt, q = tp) takes record group q of the row tile — lane (r = lane >> 3, e = lane & 7) loads the
+    // 16 bytes of (row 8q + r, chunk e) with ONE coalesced 1-KiB request per wave and super-block; its dword g holds sub-blocks 2g / 2g+1 = the eight
+    // halves of MFMA lane (m = 8q + r, g) of fragment e.  Four 16-byte stores per lane and super-block, scale operands of (row, g) from the side table.
+    const int br = lane >> 3, be = lane & 7;
+    const int rgq = 2 * (live ? rtg : rb * 4) + tp;
+    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;          // a last tile of 8 (padded) rows: its first record group twice (rows 8..15 are never stored)
+    const uint8_t * wrec = a.w + (size_t) rgc * nb * RECB + (size_t) lane * 16;
+    const uint8_t * wqh = a.w + (size_t) rgc * nb * RECB + 1024 + (size_t) lane * 4;
+    const uint8_t * phb = a.ph + (size_t) rb * nb * 4096 + (size_t) rt * 1024 + (size_t) (8 * tp + br) * 16;
+    uint4 raw[2]; uint32_t qh[2]; uint4 sc[2][4];
     auto load_set = [&](int ci, auto set_tag) {
         constexpr int S = decltype(set_tag)::value;
-        const uint8_t * r = wrec + (size_t) ci * RECB;
+        raw[S] = *(const uint4 *) (wrec + (size_t) ci * RECB);
+        if (Q5) qh[S] = *(const uint32_t *) (wqh + (size_t) ci * RECB);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            raw[S][j] = *(const uint32_t *) (r + vraw + j * 16);
-            if (Q5) qh[S][j] = *(const uint32_t *) (r + vqh + j * 4);
-        }
-        sc[S] = *(const uint4 *) (phb + (size_t) ci * 1024);
+        for (int g = 0; g < 4; ++g) sc[S][g] = *(const uint4 *) (phb + (size_t) ci * 4096 + g * 256);
     };
-    // one fragment = two halves of work: (1) nibbles -> f16 images 1024 + n, (2) x scale, store
+    // one fragment piece = two halves of work: (1) nibbles -> f16 images 1024 + n, (2) x scale, store
     bamd_h2u c0, c1, c2, c3;
-    const uint32_t qs0 = 2u * (uint32_t) g, qs1 = qs0 + 1u;
-    auto build_a = [&](uint32_t wq, uint32_t q) {
+    auto build_a = [&](uint32_t wq, uint32_t q, int g) {
         uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;      // Q4_K: the high nibbles stay in place (16 n; the scale operand is s / 16)
-        if (Q5) { lo |= ((q >> qs0) & 0x01010101u) << 4; hi |= ((q >> qs1) & 0x01010101u) << 4; }  // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
+        if (Q5) { lo |= ((q >> (2 * g)) & 0x01010101u) << 4; hi |= ((q >> (2 * g + 1)) & 0x01010101u) << 4; }  // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
         c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
         c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
     };
@@ -180,9 +183,10 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a)
         a2.h = __builtin_elementwise_fma(c2.h, s1.h, n1.h); a3.h = __builtin_elementwise_fma(c3.h, s1.h, n1.h);
         *(uint4 *) dst = (uint4) { a0.u, a1.u, a2.u, a3.u };
     };
+    auto rawg = [&](const uint4 & v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; };
     // per-lane LDS addresses (first copy of each region)
-    unsigned char * afw = smem + X_AF0 + rt * 8192 + (4 * tp) * 1024 + lane * 16;                  // where this wave writes its fragments
-    const unsigned char * afr = smem + X_AF0 + rt * 8192 + lane * 16;                              // where it reads the tile's eight
+    unsigned char * afw = smem + X_AF0 + (rt * 8 + be) * X_FR + (8 * tp + br) * 16;                // where this lane writes: fragment be, MFMA lane (8 tp + br, g) at + g * 256
+    const unsigned char * afr = smem + X_AF0 + rt * 8 * X_FR + lane * 16;                          // where the wave reads the tile's eight fragments
     const unsigned char * bop = smem + X_BLK0 + (size_t) ((2 * tp) * 16 + m) * BAMD_B16_REC + g * 16;      // B operands of token tile 0 (tile 1: + 16 records)
     const unsigned char * bmn = smem + X_BLK0 + (size_t) ((2 * tp) * 16 + m) * BAMD_B16_REC + 512 + (Q5 ? g * 8 : 0);
     const unsigned char * chd = smem + X_BLK0 + X_CH_OFF + rt * X_CH4_RT + g * 32;                 // {d, dmin} of rows 4g .. 4g+3
@@ -203,7 +207,7 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a)
     load_set(0, std::integral_constant<int, 0>());
     load_set(nb > 1 ? 1 : 0, std::integral_constant<int, 1>());
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { build_a(raw[0][j], Q5 ? qh[0][j] : 0u); build_b(sc[0], afw + j * 1024); }
+    for (int g = 0; g < 4; ++g) { build_a(rawg(raw[0], g), Q5 ? qh[0] : 0u, g); build_b(sc[0][g], afw + g * 256); }
     lds_dma_wait();
     __syncthreads();
     auto step = [&](const int ci, auto cur_tag) {
@@ -227,14 +231,14 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a)
             // software pipeline over e: the LDS operands of e + 2 are requested at the top of iteration e, the MFMA results of e - 1 are folded
             // into the chains in iteration e, and half a fragment of the NEXT super-block is built in every iteration
             bamd_h8 Aq[3], Bq[3][2]; bamd_f4 sprev[2];
-#define X_LDA(e_) (*(const bamd_h8 *) (afr + CUR * X_AF_BYTES + (e_) * 1024))
+#define X_LDA(e_) (*(const bamd_h8 *) (afr + CUR * X_AF_BYTES + (e_) * X_FR))
 #define X_LDB(e_, n_) (*(const bamd_h8 *) (bop + CUR * X_BLK + (n_) * (16 * BAMD_B16_REC) + (e_) * 64))
 #pragma unroll
             for (int e = 0; e < 2; ++e) { Aq[e] = X_LDA(e); Bq[e][0] = X_LDB(e, 0); Bq[e][1] = X_LDB(e, 1); }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e + 2 < 8) { Aq[(e + 2) % 3] = X_LDA(e + 2); Bq[(e + 2) % 3][0] = X_LDB(e + 2, 0); Bq[(e + 2) % 3][1] = X_LDB(e + 2, 1); }
-                if ((e & 1) == 0) build_a(raw[NXT][e >> 1], Q5 ? qh[NXT][e >> 1] : 0u);
+                if ((e & 1) == 0) build_a(rawg(raw[NXT], e >> 1), Q5 ? qh[NXT] : 0u, e >> 1);
                 bamd_f4 si[2];
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a)
                         for (int i = 0; i < 4; ++i) acc[n][e - 1][i] = fmaf(D[n][i], sprev[n][i], acc[n][e - 1][i]);
                     }
                 }
-                if (e & 1) build_b(sc[NXT], afw + NXT * X_AF_BYTES + (e >> 1) * 1024);
+                if (e & 1) build_b(sc[NXT][e >> 1], afw + NXT * X_AF_BYTES + (e >> 1) * 256);
                 sprev[0] = si[0]; sprev[1] = si[1];
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -333,48 +337,47 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
     XStage<16> stg; stg.plan(tid, wave, lane, t0, a.T, b16, nb);
     const uint8_t * chb = a.ch + (size_t) rb * nb * (4 * X_CH6_RT);
 #define X_STAGE(ci_, b_) stg.issue(a.blob16 + (size_t) (ci_) * BAMD_B16_REC, chb + (size_t) (ci_) * (4 * X_CH6_RT), a.blob16 + (size_t) (ci_) * 4, lds0 + X_BLK0 + (uint32_t) (b_) * X_BLK, wave, lane)
-    // builder: fragments e = 4 h + 2 tp + j (j = 0, 1) of half step h: per lane and fragment the ql dwords of sub-blocks 2g / 2g+1 (stream lane
-    // (m & 7, e), dwords 2 (g >> 1) and + 1) and the qh dword (g >> 1); the shift 4 (g & 1) picks the nibble, the rotations the two high bits
-    const int rg0 = (live ? rtg : rb * 4) * 2;
-    const bool two = (rg0 + 1) * 8 < a.nrows_pad;
-    const uint8_t * wrec = a.w + (size_t) rg0 * nb * 1680;
-    const uint32_t vrow = (m >= 8 && two) ? (uint32_t) nb * 1680u : 0u;
-    const uint32_t vql = vrow + (uint32_t) ((m & 7) * 8 + 2 * tp) * 16u + (uint32_t) (g >> 1) * 8u;
-    const uint32_t vqh = vrow + 1024u + (uint32_t) ((m & 7) * 8 + 2 * tp) * 8u + (uint32_t) (g >> 1) * 4u;
-    const uint8_t * phb = a.ph + (size_t) rtg * nb * 2048 + (size_t) lane * 16;
-    uint2 ql[2][2]; uint32_t qh[2][2]; uint4 sc[2];
+    // builder (as in the Q4_K kernel: the stream's own rows, one record group per wave): wave (rt, q = tp), lane (p = lane >> 5, r = (lane >> 2) & 7, el = lane & 3)
+    // takes, per half step, chunk e = 4 H + el of row 8q + r and builds the pieces of MFMA lanes (8q + r, g = 2p + j), j = 0, 1: the ql dwords 2p, 2p + 1
+    // (sub-blocks 2g / 2g+1 sit in the low (j = 0) or high (j = 1) nibbles) and the qh dword p of stream lane (r, e).  Eight consecutive lanes = two rows x
+    // four fragments: their 16-byte stores fall on eight different bank quads (fragment pairs 2 x X_FR bytes apart).
+    const int bp = lane >> 5, br = (lane >> 2) & 7, bel = lane & 3;
+    const int rgq = 2 * (live ? rtg : rb * 4) + tp;
+    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;
+    const uint8_t * wql = a.w + (size_t) rgc * nb * 1680 + (size_t) ((br * 8 + bel) * 16 + bp * 8);
+    const uint8_t * wqh = a.w + (size_t) rgc * nb * 1680 + 1024 + (size_t) ((br * 8 + bel) * 8 + bp * 4);
+    const uint8_t * phb = a.ph + (size_t) rb * nb * 8192 + (size_t) rt * 1024 + (size_t) ((2 * bp) * 256 + (8 * tp + br) * 16);
+    uint2 ql[2]; uint32_t qh[2]; uint4 sc[2][2];
     auto load_set = [&](int hs, auto set_tag) {                // operands of half step hs = 2 ci + h
         constexpr int S = decltype(set_tag)::value;
         const int ci = hs >> 1, h = hs & 1;
-        const uint8_t * r = wrec + (size_t) ci * 1680 + h * 64;                       // e = 4h + ...: 4 stream lanes = 64 B of ql, 32 B of qh further on
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { ql[S][j] = *(const uint2 *) (r + vql + j * 16); qh[S][j] = *(const uint32_t *) (r - h * 32 + vqh + j * 8); }
-        sc[S] = *(const uint4 *) (phb + (size_t) hs * 1024);
+        ql[S] = *(const uint2 *) (wql + (size_t) ci * 1680 + h * 64);
+        qh[S] = *(const uint32_t *) (wqh + (size_t) ci * 1680 + h * 32);
+        sc[S][0] = *(const uint4 *) (phb + (size_t) hs * 4096); sc[S][1] = *(const uint4 *) (phb + (size_t) hs * 4096 + 256);
     };
-    const uint32_t sh = 4u * (uint32_t) (g & 1);
-    const uint32_t rotA = (28u + sh) & 31u, rotB = (30u + sh) & 31u;
     const bamd_h2 k1056 = { (_Float16) -1056.f, (_Float16) -1056.f };
     bamd_h2u v0, v1, v2, v3;
-    auto build_a = [&](const uint2 & q, uint32_t hq) {
-        // the two high bits of a quant sit at bits sh, sh + 1 (sub-block 2g) / sh + 2, sh + 3 (2g + 1) of their byte of hq and belong at bits 4, 5:
+    auto build_a = [&](const uint2 & q, uint32_t hq, int j) {
+        // the two high bits of a quant sit at bits sh, sh + 1 (sub-block 2g) / sh + 2, sh + 3 (2g + 1) of their byte of hq (sh = 4 j) and belong at bits 4, 5:
         // a ROTATION of the dword (what wraps around lands outside the mask 0x30 of every byte), then one and-or
-        const uint32_t uA = (__builtin_amdgcn_alignbit(hq, hq, rotA) & 0x30303030u) | ((q.x >> sh) & 0x0f0f0f0fu);
-        const uint32_t uB = (__builtin_amdgcn_alignbit(hq, hq, rotB) & 0x30303030u) | ((q.y >> sh) & 0x0f0f0f0fu);
+        const uint32_t sh = 4u * (uint32_t) j;
+        const uint32_t uA = (__builtin_amdgcn_alignbit(hq, hq, (28u + sh) & 31u) & 0x30303030u) | ((q.x >> sh) & 0x0f0f0f0fu);
+        const uint32_t uB = (__builtin_amdgcn_alignbit(hq, hq, (30u + sh) & 31u) & 0x30303030u) | ((q.y >> sh) & 0x0f0f0f0fu);
         bamd_h2u c;
         c.u = __builtin_amdgcn_perm(0x64646464u, uA, 0x04010400u); v0.h = c.h + k1056;      // (1024 + q) - 1056 = q - 32, exact
         c.u = __builtin_amdgcn_perm(0x64646464u, uA, 0x04030402u); v1.h = c.h + k1056;
         c.u = __builtin_amdgcn_perm(0x64646464u, uB, 0x04010400u); v2.h = c.h + k1056;
         c.u = __builtin_amdgcn_perm(0x64646464u, uB, 0x04030402u); v3.h = c.h + k1056;
     };
-    auto build_b = [&](const uint4 & s, unsigned char * dst) {  // dst: the A_a fragment; A_l 1 KiB behind it
+    auto build_b = [&](const uint4 & s, unsigned char * dst) {  // dst: the A_a fragment; A_l X_FR bytes behind it
         bamd_h2u sa0, sl0, sa1, sl1, x0, x1, x2, x3; sa0.u = s.x; sl0.u = s.y; sa1.u = s.z; sl1.u = s.w;
         x0.h = v0.h * sa0.h; x1.h = v1.h * sa0.h; x2.h = v2.h * sa1.h; x3.h = v3.h * sa1.h;
         *(uint4 *) dst = (uint4) { x0.u, x1.u, x2.u, x3.u };
         x0.h = v0.h * sl0.h; x1.h = v1.h * sl0.h; x2.h = v2.h * sl1.h; x3.h = v3.h * sl1.h;
-        *(uint4 *) (dst + 1024) = (uint4) { x0.u, x1.u, x2.u, x3.u };
+        *(uint4 *) (dst + X_FR) = (uint4) { x0.u, x1.u, x2.u, x3.u };
     };
-    unsigned char * afw = smem + X_AF0 + rt * 8192 + (2 * tp) * 2048 + lane * 16;                  // [row tile][e' = 0..3][a | l][1 KiB]
-    const unsigned char * afr = smem + X_AF0 + rt * 8192 + lane * 16;
+    unsigned char * afw = smem + X_AF0 + (rt * 4 + bel) * (2 * X_FR) + ((2 * bp) * 16 + 8 * tp + br) * 16;     // [row tile][e' = 0..3][a | l][X_FR]: MFMA lane (8 tp + br, 2 bp + j) at + j * 256
+    const unsigned char * afr = smem + X_AF0 + rt * 8 * X_FR + lane * 16;
     const unsigned char * bop = smem + X_BLK0 + (size_t) ((2 * tp) * 16 + m) * BAMD_B16_REC + g * 16;
     const unsigned char * chd = smem + X_BLK0 + X_CH_OFF + rt * X_CH6_RT + g * 16;                 // d of rows 4g .. 4g+3
     const unsigned char * ydp = smem + X_BLK0 + X_YD_OFF + ((2 * tp) * 16 + m) * 4;
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
     load_set(0, std::integral_constant<int, 0>());
     load_set(1, std::integral_constant<int, 1>());
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { build_a(ql[0][j], qh[0][j]); build_b(sc[0], afw + j * 2048); }
+    for (int j = 0; j < 2; ++j) { build_a(ql[0], qh[0], j); build_b(sc[0][j], afw + j * 256); }
     lds_dma_wait();
     __syncthreads();
     const int nhs = 2 * nb;
@@ -410,13 +413,13 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
             }
         }
         bamd_h8 Aa[2], Al[2], Bq[2][2];
-#define X_LDA(e_, p_) (*(const bamd_h8 *) (afr + H * X_AF_BYTES + (e_) * 2048 + (p_) * 1024))
+#define X_LDA(e_, p_) (*(const bamd_h8 *) (afr + H * X_AF_BYTES + (e_) * (2 * X_FR) + (p_) * X_FR))
 #define X_LDB(e_, n_) (*(const bamd_h8 *) (bop + BLK * X_BLK + (n_) * (16 * BAMD_B16_REC) + (4 * H + (e_)) * 64))
         Aa[0] = X_LDA(0, 0); Al[0] = X_LDA(0, 1); Bq[0][0] = X_LDB(0, 0); Bq[0][1] = X_LDB(0, 1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (e + 1 < 4) { Aa[(e + 1) & 1] = X_LDA(e + 1, 0); Al[(e + 1) & 1] = X_LDA(e + 1, 1); Bq[(e + 1) & 1][0] = X_LDB(e + 1, 0); Bq[(e + 1) & 1][1] = X_LDB(e + 1, 1); }
-            if ((e & 1) == 0) build_a(ql[NXT][e >> 1], qh[NXT][e >> 1]);
+            if ((e & 1) == 0) build_a(ql[NXT], qh[NXT], e >> 1);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[n][4 * H + e][i] = fmaf(D[n][i], s2[i], acc[n][4 * H + e][i]);
             }
-            if (e & 1) build_b(sc[NXT], afw + NXT * X_AF_BYTES + (e >> 1) * 2048);
+            if (e & 1) build_b(sc[NXT][e >> 1], afw + NXT * X_AF_BYTES + (e >> 1) * 256);
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef X_LDA
@@ -458,15 +461,252 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
     }
 }
 
+// ==== sixteen waves ===========================================================================================================================
+// The eight-wave kernels above trade vector instructions for LDS traffic and end where the round-2 kernels were.  What the counters say about all of them
+// (profiles/r05_prefill_*): no pipe is saturated and the time follows the TOTAL number of instructions a SIMD issues — scalar, wait and no-op instructions
+// included — at roughly one per five clocks (~4 clocks each plus 16 per MFMA, next to no overlap).  So this kernel is written for instruction count:
+//   * a workgroup is SIXTEEN waves (four per SIMD): four row tiles x four token tiles, ONE 16 x 16 tile per wave (48 accumulator registers, <= 128 VGPRs);
+//     every A fragment is built once and read by four waves, every token record staged once and read by four;
+//   * staging is three full-wave DMA instructions per wave and step, the same straight-line code on every wave: sources are per-wave scalar pointers that
+//     advance by a per-wave stride (records 608 B, consumer headers 3 KiB, builder operands 4 KiB per super-block), destinations per-wave constants; no
+//     clamping at the end of K (the last copies read one super-block past the tables — allocated with that slack — into a block nobody reads again);
+//   * the builder's scale operands travel by DMA as well, two steps ahead, into the operand slot of the block that is being read (its previous content
+//     was consumed one step earlier), so a wave's own loads are 8 bytes of nibbles per lane and step through a buffer descriptor (scalar offset);
+//   * d_y sits inside the token record; the epilogue stores 16 bytes per lane.
+#define X3_BLK (X_BS_BYTES + X3_CHS + 4096 + 32)           /* records (38 KiB) | headers (3 KiB) | operands (4 KiB) | 32 bytes of zeros: 46 112 B */
+#define X3_BLK0 (2 * X_AF_BYTES)
+#define X3_LDS_BYTES (X3_BLK0 + 2 * X3_BLK)                /* 158 784 B */
+#define X3_CH_OFF X_BS_BYTES
+#define X3_PH_OFF (X_BS_BYTES + X3_CHS)
+#define X3_Z_OFF (X3_PH_OFF + 4096)
+// one DMA instruction: m0 <- LDS destination, 1 KiB from (scalar base + per-lane offset)
+__device__ __forceinline__ void x3_dma(const void * sbase, uint32_t voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+#ifndef X_TIMING
+#define X_TIMING 0
+#endif
+#if X_TIMING
+#define X_T(i_) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i_] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define X_T(i_) do { } while (0)
+#endif
+template <int EPI, bool Q5>
+__global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a) {
+    constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
+    const int rt = wave >> 2, tt = wave & 3;
+    const int nb = a.K >> 8;
+    const int rb = blockIdx.y, t0 = blockIdx.x * 64;
+    const int rtg = rb * 4 + rt;
+    const bool live = rtg * 16 < a.nrows_pad;
+    const size_t b16 = BAMD_BLOB16_BYTES(nb);
+    const uint32_t lds0 = (uint32_t) (size_t) (bamd_lds_vp) smem;
+    // ---- stage plan.  A block = 45 KiB-instructions: k = 0..37 records (chunk 64 k + lane of 64 tokens x 38), 38..40 consumer headers, 41..44 builder
+    //      operands.  Wave w issues k = w, 16 + w and k2 = 32 + w (w <= 12; waves 13..15 repeat the operand copies 41..43: same bytes, same place).
+    auto rec_off = [&](int idx) { const int tok = idx / BAMD_B16_Q, q = idx - tok * BAMD_B16_Q; const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1; return (uint32_t) ((size_t) tg * b16 + (size_t) q * 16); };
+    const int k2 = wave <= 12 ? 32 + wave : 28 + wave;
+    const bool rec2 = k2 <= 37, hdr2 = k2 >= 38 && k2 <= 40;
+    const uint32_t so0 = rec_off(tid), so1 = rec_off(1024 + tid);
+    const uint32_t so2 = rec2 ? rec_off(k2 * 64 + lane) : (uint32_t) (((hdr2 ? k2 - 38 : k2 - 41) * 64 + lane) * 16);
+    // sources of the NEXT stage call (the first call stages super-block 0 and the operands of super-block 1)
+    const uint8_t * p01 = a.blob16;
+    const uint8_t * p2 = rec2 ? a.blob16 : hdr2 ? a.ch + (size_t) rb * nb * X3_CHS : a.ph + (size_t) rb * nb * 4096 + 4096;
+    const uint32_t st2 = rec2 ? (uint32_t) BAMD_B16_REC : hdr2 ? (uint32_t) X3_CHS : 4096u;
+    // destinations by the parity of the step that issues the copies: records / headers of ci + 1 -> the OTHER block, operands of ci + 2 -> the block in use
+    const uint32_t blk_a = lds0 + X3_BLK0, blk_b = blk_a + X3_BLK;
+    const uint32_t d0_even = blk_b + (uint32_t) wave * 1024u, d0_odd = blk_a + (uint32_t) wave * 1024u;
+    const uint32_t d2_even = (k2 <= 40 ? blk_b : blk_a) + (uint32_t) k2 * 1024u, d2_odd = (k2 <= 40 ? blk_a : blk_b) + (uint32_t) k2 * 1024u;
+#define X3_STAGE(PAR) do { x3_dma(p01, so0, (PAR) ? d0_odd : d0_even); x3_dma(p01, so1, ((PAR) ? d0_odd : d0_even) + 16384u); x3_dma(p2, so2, (PAR) ? d2_odd : d2_even); \
+                           p01 += BAMD_B16_REC; p2 += st2; } while (0)
+    // ---- builder: wave (rt, tt) = record group q = tt & 1 of the row tile, pieces g = 2 gh + j (gh = tt >> 1, j = 0, 1): lane (r, e) holds dwords 2 gh, 2 gh + 1
+    //      of stream lane (r, e) = the halves of MFMA lanes (8 q + r, 2 gh + j) of fragment e
+    const int br = lane >> 3, be = lane & 7, bq = tt & 1, gh = tt >> 1;
+    const int rgq = 2 * (live ? rtg : rb * 4) + bq;
+    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;            // a last tile of 8 (padded) rows: its first record group twice (rows 8..15 are never stored)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr(a.w + (size_t) rgc * nb * RECB), 0, 0x7fffffff, 0x00020000);
+    const int vraw = lane * 16 + gh * 8, vqh = 1024 + lane * 4;
+    uint2 raw[2]; uint32_t qh[2];
+    auto load_set = [&](int ci, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrs, vraw, ci * (int) RECB, 0); raw[S] = make_uint2(v.x, v.y);
+        if (Q5) qh[S] = __builtin_amdgcn_raw_buffer_load_b32(wrs, vqh, ci * (int) RECB, 0);
+    };
+    bamd_h2u c0, c1, c2, c3;
+    const uint32_t qs0 = 4u * (uint32_t) gh;
+    auto build_a = [&](uint32_t wq, uint32_t q, int j) {
+        uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;      // Q4_K: the high nibbles stay in place (16 n; the scale operand is s / 16)
+        if (Q5) { lo |= ((q >> (qs0 + 2 * j)) & 0x01010101u) << 4; hi |= ((q >> (qs0 + 2 * j + 1)) & 0x01010101u) << 4; }
+        c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
+        c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
+    };
+    auto build_b = [&](const uint4 & s, unsigned char * dst) {
+        bamd_h2u s0, n0, s1, n1, a0, a1, a2, a3; s0.u = s.x; n0.u = s.y; s1.u = s.z; n1.u = s.w;
+        a0.h = __builtin_elementwise_fma(c0.h, s0.h, n0.h); a1.h = __builtin_elementwise_fma(c1.h, s0.h, n0.h);     // (1024 + n) s - 1024 s = n s, one rounding, exact
+        a2.h = __builtin_elementwise_fma(c2.h, s1.h, n1.h); a3.h = __builtin_elementwise_fma(c3.h, s1.h, n1.h);
+        *(uint4 *) dst = (uint4) { a0.u, a1.u, a2.u, a3.u };
+    };
+    // per-lane LDS addresses (first copy of each region)
+    unsigned char * afw = smem + X_AF0 + (rt * 8 + be) * X_FR + ((2 * gh) * 16 + 8 * bq + br) * 16;
+    const unsigned char * afr = smem + X_AF0 + rt * 8 * X_FR + lane * 16;
+    const unsigned char * phl = smem + X3_BLK0 + X3_PH_OFF + rt * 1024 + (2 * gh) * 256 + (8 * bq + br) * 16;
+    const unsigned char * tok = smem + X3_BLK0 + (size_t) (tt * 16 + m) * BAMD_B16_REC;                  // this lane's token record
+    const unsigned char * bop = tok + g * 16;
+    const unsigned char * bmn = tok + 512 + (Q5 ? g * 8 : 0);
+    const unsigned char * chd = smem + X3_BLK0 + X3_CH_OFF + rt * X_CH4_RT + g * 32;
+    const unsigned char * cmn = Q5 ? smem + X3_BLK0 + X3_CH_OFF + rt * X_CH4_RT + 128 + m * 32 + g * 8
+                                   : (g == 0 ? smem + X3_BLK0 + X3_CH_OFF + rt * X_CH4_RT + 128 + m * 32 : smem + X3_BLK0 + X3_Z_OFF);
+    bamd_f4 acc[8], accm[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int l = 0; l < 4; ++l) accm[l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
+    // prologue = the staging half of a step "-1" of odd parity: records / headers of super-block 0 into block a, operands of super-block 1 into block b;
+    // the fragments of super-block 0 are built with operands straight from memory
+    if (tid < 16) *(uint32_t *) (smem + X3_BLK0 + X3_Z_OFF + (tid >> 3) * X3_BLK + (tid & 7) * 4) = 0u;
+    X3_STAGE(1);
+    load_set(0, std::integral_constant<int, 0>());
+    load_set(nb > 1 ? 1 : 0, std::integral_constant<int, 1>());
+    {
+        const uint8_t * p0 = a.ph + (size_t) rb * nb * 4096 + (size_t) rt * 1024 + (size_t) ((2 * gh) * 256 + (8 * bq + br) * 16);
+        const uint4 s0 = *(const uint4 *) p0, s1 = *(const uint4 *) (p0 + 256);
+        build_a(raw[0].x, Q5 ? qh[0] : 0u, 0); build_b(s0, afw);
+        build_a(raw[0].y, Q5 ? qh[0] : 0u, 1); build_b(s1, afw + 256);
+    }
+    lds_dma_wait();
+    __syncthreads();
+#if X_TIMING
+    unsigned long long tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
+#endif
+    auto step = [&](const int ci, auto cur_tag) {
+        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+        X_T(0);
+        float D[4], Dm[4];
+        const bamd_f4 h0 = *(const bamd_f4 *) (chd + CUR * X3_BLK), h1 = *(const bamd_f4 *) (chd + CUR * X3_BLK + 16);
+        const float ydv = *(const float *) (tok + CUR * X3_BLK + 560);
+        D[0] = ydv * h0[0]; D[1] = ydv * h0[2]; D[2] = ydv * h1[0]; D[3] = ydv * h1[2];
+        Dm[0] = (-ydv) * h0[1]; Dm[1] = (-ydv) * h0[3]; Dm[2] = (-ydv) * h1[1]; Dm[3] = (-ydv) * h1[3];
+        {
+            // The step opens with operand reads and MFMAs; the three staging copies and the nibble load of this wave follow the MFMAs of e = 0..3 one by
+            // one (issued together at the top they queue behind the other fifteen waves' copies — the vector memory path takes 64 B per clock — and every
+            // wave sits in its issue stage for 500-1200 clocks before its first MFMA: tools/prefill_phase.py); the fragment pieces of the next
+            // super-block are built beside e = 4..7
+            bamd_h8 Aq[3], Bq[3]; bamd_f4 sprev;
+#define X_LDA(e_) (*(const bamd_h8 *) (afr + CUR * X_AF_BYTES + (e_) * X_FR))
+#define X_LDB(e_) (*(const bamd_h8 *) (bop + CUR * X3_BLK + (e_) * 64))
+            Aq[0] = X_LDA(0); Bq[0] = X_LDB(0); Aq[1] = X_LDA(1); Bq[1] = X_LDB(1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e + 2 < 8) { Aq[(e + 2) % 3] = X_LDA(e + 2); Bq[(e + 2) % 3] = X_LDB(e + 2); }
+                if (e >= 4 && (e & 1) == 0) build_a(e == 4 ? raw[NXT].x : raw[NXT].y, Q5 ? qh[NXT] : 0u, (e >> 1) & 1);
+                const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[e % 3], Bq[e % 3], z, 0, 0, 0);
+                if (e == 0) x3_dma(p01, so0, CUR ? d0_odd : d0_even);
+                if (e == 1) x3_dma(p01, so1, (CUR ? d0_odd : d0_even) + 16384u);
+                if (e == 2) { x3_dma(p2, so2, CUR ? d2_odd : d2_even); p01 += BAMD_B16_REC; p2 += st2; }
+                if (e == 3) load_set(ci + 2 < nb ? ci + 2 : nb - 1, std::integral_constant<int, CUR>());
+                if (e > 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[e - 1][i] = fmaf(D[i], sprev[i], acc[e - 1][i]);
+                }
+                if (e >= 4 && (e & 1)) build_b(*(const uint4 *) (phl + NXT * X3_BLK + ((e >> 1) & 1) * 256), afw + NXT * X_AF_BYTES + ((e >> 1) & 1) * 256);
+                sprev = si;
+                __builtin_amdgcn_sched_barrier(0);
+                if (e == 3) X_T(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[7][i] = fmaf(D[i], sprev[i], acc[7][i]);
+#undef X_LDA
+#undef X_LDB
+        }
+        X_T(2);
+        if (Q5) {
+            union { uint2 u; bamd_h4 h; } av, bv; av.u = *(const uint2 *) (cmn + CUR * X3_BLK); bv.u = *(const uint2 *) (bmn + CUR * X3_BLK);
+            const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+            const bamd_f4 pm = __builtin_amdgcn_mfma_f32_16x16x16f16(av.h, bv.h, z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float t = Dm[i] * pm[i]; accm[0][i] = accm[0][i] + t; }
+        } else {
+            const uint4 ma = *(const uint4 *) (cmn + CUR * X3_BLK), mb = *(const uint4 *) (cmn + CUR * X3_BLK + 16);
+            const uint4 sfa = *(const uint4 *) (bmn + CUR * X3_BLK), sfb = *(const uint4 *) (bmn + CUR * X3_BLK + 16);
+            const uint2 al[4] = { { ma.x, ma.y }, { ma.z, ma.w }, { mb.x, mb.y }, { mb.z, mb.w } };
+            const uint2 bl[4] = { { sfa.x, sfa.y }, { sfa.z, sfa.w }, { sfb.x, sfb.y }, { sfb.z, sfb.w } };
+            bamd_f4 pm[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                union { uint2 u; bamd_h4 h; } av4, bv4; av4.u = al[l]; bv4.u = bl[l];
+                const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+                pm[l] = __builtin_amdgcn_mfma_f32_16x16x16f16(av4.h, bv4.h, z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accm[l][i] = fmaf(Dm[i], pm[l][i], accm[l][i]);
+            }
+        }
+        X_T(3);
+        lds_dma_wait();
+        X_T(4);
+        __syncthreads();
+        X_T(5);
+    };
+    for (int ci = 0; ci < nb; ci += 2) {
+        step(ci, std::integral_constant<int, 0>());
+        if (ci + 1 < nb) step(ci + 1, std::integral_constant<int, 1>());
+    }
+#undef X3_STAGE
+#if X_TIMING
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == (gridDim.y >> 1) && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.dbg[wave * 8 + i] = tacc[i];
+        a.dbg[wave * 8 + 6] = (unsigned long long) nb;
+    }
+#endif
+    if (!live) return;
+    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue: rows 4g .. 4g+3 of token t are 16 consecutive bytes
+    const int t = t0 + tt * 16 + m;
+    float val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = ((acc[0][i] + acc[4][i]) + (acc[2][i] + acc[6][i])) + ((acc[1][i] + acc[5][i]) + (acc[3][i] + acc[7][i]));
+        const float mm = Q5 ? accm[0][i] : (accm[0][i] + accm[2][i]) + (accm[1][i] + accm[3][i]);
+        val[i] = v + mm;
+    }
+    const int row0 = rtg * 16 + 4 * g;
+    if (t < a.T && row0 < a.nrows) {
+        const size_t o = (size_t) t * a.ldo + row0;
+        if (row0 + 3 < a.nrows && (a.ldo & 3) == 0) {
+            bamd_f4 y = { val[0], val[1], val[2], val[3] };
+            if (EPI != BAMD_EPI_STORE) {
+                const bamd_f4 r = *(const bamd_f4 *) (a.res + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = EPI == BAMD_EPI_ADD ? val[i] + r[i] : v_silu(r[i]) * val[i];
+            }
+            *(bamd_f4 *) (a.out + o) = y;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (row0 + i < a.nrows) a.out[o + i] = EPI == BAMD_EPI_ADD ? val[i] + a.res[o + i] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[o + i]) * val[i] : val[i];
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------------------------
 static inline int x_row_blocks(int nrows_pad) { return (nrows_pad + 63) / 64; }
+// Q4_K / Q5_K: the sixteen-wave kernel (default) or the eight-wave one (BAMD_PREFILL_WAVES=8, bamd_launch_prefill_waves: the tests run both)
+static int g_prefill_waves16 = [] { const char * e = getenv("BAMD_PREFILL_WAVES"); return (e && e[0] == '8') ? 0 : 1; }();
+void bamd_launch_prefill_waves(int waves) { g_prefill_waves16 = waves == 8 ? 0 : 1; }
+static unsigned long long * g_prefill_dbg = nullptr;      // -DX_TIMING builds: where the kernels of the next launches leave their phase clocks (bamd_prefill_dbg)
+extern "C" __attribute__((visibility("default"))) void bamd_prefill_dbg(void * dev_buf) { g_prefill_dbg = (unsigned long long *) dev_buf; }
 // bytes of the side table of a K-quant matrix [nrows_pad][K]: builder part first, the consumer part behind it (both 16-byte aligned)
 size_t bamd_prefill_aux_bytes(int type, int nrows_pad, int K) {
     if ((type != BAMD_Q4_K && type != BAMD_Q5_K && type != BAMD_Q6_K) || (K & 255) || (nrows_pad & 7)) return 0;
     const size_t nb = (size_t) (K >> 8), rbk = (size_t) x_row_blocks(nrows_pad);
-    return type == BAMD_Q6_K ? rbk * 4 * nb * 2048 + rbk * nb * 4 * X_CH6_RT : rbk * 4 * nb * 1024 + rbk * nb * 4 * X_CH4_RT;
+    // + two super-blocks of slack behind each table: the sixteen-wave kernel's last two staging calls read past the end of K
+    return type == BAMD_Q6_K ? (rbk * nb + 2) * 8192 + (rbk * nb + 2) * 4 * X_CH6_RT : (rbk * nb + 2) * 4096 + (rbk * nb + 2) * X3_CHS;
 }
-static inline size_t x_ph_bytes(int type, int nrows_pad, int K) { return (size_t) x_row_blocks(nrows_pad) * 4 * (size_t) (K >> 8) * (type == BAMD_Q6_K ? 2048 : 1024); }
+static inline size_t x_ph_bytes(int type, int nrows_pad, int K) { return ((size_t) x_row_blocks(nrows_pad) * (size_t) (K >> 8) + 2) * (type == BAMD_Q6_K ? 8192 : 4096); }
 void bamd_launch_prefill_aux(const void * w_stream, int type, int nrows_pad, int K, void * aux, hipStream_t s) {
     const int nb = K >> 8, nrt = x_row_blocks(nrows_pad) * 4;
     uint8_t * ph = (uint8_t *) aux, * ch = ph + x_ph_bytes(type, nrows_pad, K);
@@ -482,14 +722,21 @@ int bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, 
     if ((epi != BAMD_EPI_STORE) != (res != nullptr)) return 1;
     bamd_mma2_args a; a.w = (const uint8_t *) w_stream; a.ph = (const uint8_t *) aux; a.ch = a.ph + x_ph_bytes(type, nrows_pad, K);
     a.out = out; a.res = res; a.blob16 = (const uint8_t *) blob16; a.K = K; a.T = T; a.nrows = nrows; a.nrows_pad = nrows_pad; a.ldo = ldo;
+    a.dbg = g_prefill_dbg;
     const dim3 grid((T + 63) / 64, x_row_blocks(nrows_pad));
 #define X_LAUNCH(KERNEL, ...) do { \
         if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(512), X_LDS_BYTES, s, a); \
         else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(512), X_LDS_BYTES, s, a); \
         else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(512), X_LDS_BYTES, s, a); } while (0)
+    const int waves16 = g_prefill_waves16;
+#define X3_LAUNCH(KERNEL, ...) do { \
+        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(1024), X3_LDS_BYTES, s, a); \
+        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(1024), X3_LDS_BYTES, s, a); \
+        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(1024), X3_LDS_BYTES, s, a); } while (0)
     if (type == BAMD_Q6_K)      X_LAUNCH(matmul_mfma2_q6k_kernel);
-    else if (type == BAMD_Q5_K) X_LAUNCH(matmul_mfma2_q4k_kernel, , true);
-    else                        X_LAUNCH(matmul_mfma2_q4k_kernel, , false);
+    else if (type == BAMD_Q5_K) { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , true); else X_LAUNCH(matmul_mfma2_q4k_kernel, , true); }
+    else                        { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , false); else X_LAUNCH(matmul_mfma2_q4k_kernel, , false); }
+#undef X3_LAUNCH
 #undef X_LAUNCH
     return 0;
 }

@@ -90,6 +90,22 @@ class HipStage:
     def new_token(self):
         return self.torch.zeros(1, dtype=self.torch.int32, device=self.device)
 
+    def new_hidden_batch(self, n_tokens):
+        return self.torch.zeros(n_tokens, self.n_embd, dtype=self.torch.float32, device=self.device)
+
+    def prefill(self, seq, tokens, n_tokens, pos0, hin, hout, want_logits):
+        """one prompt micro-batch (<= 512 tokens) through this stage: bamd_stage_prefill (the batched kernels: one pass over the stage's weights for
+        the whole micro-batch); a shape without batched kernels is evaluated token by token with the same T > 1 semantics (same bits)"""
+        stream = self.torch.cuda.current_stream().cuda_stream
+        ok = self.ctx[seq].stage_prefill(tokens, n_tokens, pos0, None if hin is None else hin.data_ptr(), None if hout is None else hout.data_ptr(),
+                                         want_logits, stream)
+        if ok:
+            return
+        row = self.n_embd * 4
+        for i in range(n_tokens):
+            self.ctx[seq].stage_step(int(tokens[i]) if tokens is not None else 0, pos0 + i, None if hin is None else hin.data_ptr() + i * row,
+                                     None if hout is None else hout.data_ptr() + i * row, want_logits and i == n_tokens - 1, 1, stream, None)
+
     def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
         stream = self.torch.cuda.current_stream().cuda_stream
         if self.time_steps is not None:
@@ -112,6 +128,58 @@ class HipStage:
         self.model.close()
 
 
+class FakeStage:
+    """Deterministic CPU stand-in for a stage (the world_size-2 gloo tests and `bench.py --backend gloo`): hidden' = (hidden * 5 + pos + 11 * layer) mod 8191
+    per layer; the first stage embeds the token, the last stage picks token = (sum(hidden) * 31 + 7) mod V as its 'arg-max'.  Integer arithmetic in
+    f32, so a pipelined run must equal a sequential single-process evaluation exactly."""
+    E, V = 16, 97
+
+    def __init__(self, layers, is_first, is_last):
+        import torch
+        self.torch = torch
+        self.layers, self.is_first, self.is_last = layers, is_first, is_last
+        self.last_tok = {}
+        self.prefill_calls = []                      # (seq, n_tokens, pos0) of every batched prompt micro-batch (the tests look at it)
+
+    def new_hidden(self): return self.torch.zeros(self.E, dtype=self.torch.float32)
+    def new_token(self): return self.torch.zeros(1, dtype=self.torch.int32)
+    def new_hidden_batch(self, n_tokens): return self.torch.zeros(n_tokens, self.E, dtype=self.torch.float32)
+
+    def _layers(self, h, pos):
+        for l in self.layers:
+            h = self.torch.remainder(h * 5 + pos + 11 * l, 8191)
+        return h
+
+    def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
+        if self.is_first:
+            tok = int(token_dev.item()) if token_dev is not None else token_host
+            h = self.torch.arange(self.E, dtype=self.torch.float32) * 3 + tok
+        else:
+            h = hin.clone()
+        h = self._layers(h, pos)
+        if self.is_last:
+            if want_logits:
+                self.last_tok[seq] = int((int(h.sum().item()) * 31 + 7) % self.V)
+        else:
+            hout.copy_(h)
+
+    def prefill(self, seq, tokens, n_tokens, pos0, hin, hout, want_logits):
+        self.prefill_calls.append((seq, n_tokens, pos0))
+        for i in range(n_tokens):
+            self.step(seq, int(tokens[i]) if self.is_first else 0, None, pos0 + i, None if hin is None else hin[i], None if hout is None else hout[i],
+                      want_logits and i == n_tokens - 1, 1)
+
+    def token_to(self, seq, token_dev): token_dev.fill_(self.last_tok[seq])
+    def sync(self): pass
+
+
+PREFILL_CAP = 512                                    # the reference's n_batch / n_ubatch: prompt positions per micro-batch (llama.cpp:16945-16960)
+
+
+def prompt_microbatches(n_prompt, cap=PREFILL_CAP):
+    return [(i, min(cap, n_prompt - i)) for i in range(0, n_prompt, cap)]
+
+
 def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset=0):
     """Greedy decode of n_seq sequences (same prompt) through `world` stages.  pos_offset: KV position of prompt[0] (a call can
     continue sequences whose first pos_offset positions are already in the stages' KV caches).
@@ -123,6 +191,11 @@ def run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset=0
     So rounds are identical exchange steps on all ranks and no cycle of blocked point-to-point operations can form
     (in-order RCCL streams or rendezvous gloo sends alike).  Positions < len(prompt) consume prompt tokens (known on rank 0),
     later positions the arg-max fed back from the last rank.
+
+    A prompt of more than one token is evaluated in MICRO-BATCHES of <= 512 positions (`_prompt_phase`: the stage's batched kernels, ONE
+    [T, n_embd] f32 message per boundary and micro-batch, micro-batch j + 1 entering stage r while j is in stage r + 1 — the reference's pipelined
+    prompt evaluation, llama.cpp:16945-16960 / GGML_SCHED_MAX_COPIES ggml-backend.c:1030); the rounds above then start at the first generated
+    position.  (A stage object without a `prefill` method keeps the one-token-per-round path for the prompt as well.)
 
     Returns, on rank 0, for every sequence the list of tokens FED after the prompt (n_decode of them); elsewhere empty lists.
     """
@@ -142,14 +215,18 @@ def _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset)
     fed = [[] for _ in range(n_seq)]
     prefill_mode = 1 if n_prompt > 1 else 0
     last_round = (total - 1) * P + (n_seq - 1) + (world - 1) + 1
+    start_pos = 0
+    if n_prompt > 1 and hasattr(stage, "prefill"):
+        _prompt_phase(stage, dist, rank, world, prompt, n_seq, pos_offset, tok, n_decode > 0)
+        start_pos = n_prompt
 
     def slot(j):                                     # local index -> (pos, s) or None
         if j < 0:
             return None
         pos, s = divmod(j, P)
-        return (pos, s) if s < n_seq and pos < total else None
+        return (pos, s) if s < n_seq and start_pos <= pos < total else None
 
-    for k in range(last_round + 1):
+    for k in range(start_pos * P, last_round + 1):
         ops = []
         if world > 1:
             # ---- sends of round k ----
@@ -189,6 +266,36 @@ def _run_pipeline(stage, dist, rank, world, prompt, n_decode, n_seq, pos_offset)
             stage.token_to(s, tok[s])                # last rank (world > 1: held until rank 0's round; world == 1: fed next)
     stage.sync()
     return [[int(t.item()) for t in f] for f in fed]
+
+
+def _prompt_phase(stage, dist, rank, world, prompt, n_seq, pos_offset, tok, want_last):
+    """The prompt of every sequence in micro-batches through the stages.  Item j = (sequence, first position, T); rank r evaluates item j in round
+    j + r; the [T, n_embd] hidden block of item j leaves rank r at the start of round j + r + 1, where rank r + 1 takes it: sent and received in the
+    same round, one batch_isend_irecv group per round and rank (the decode rounds' argument: no cycle of blocked point-to-point operations).  The
+    last stage keeps the arg-max of each sequence's LAST prompt position in tok[s] (want_last), from where the first decode round sends it to rank 0."""
+    first, last = rank == 0, rank == world - 1
+    n_prompt = len(prompt)
+    items = [(s, i0, T) for s in range(n_seq) for (i0, T) in prompt_microbatches(n_prompt)]
+    t_max = max(T for _, _, T in items)
+    hin = None if first else stage.new_hidden_batch(t_max)
+    hout = None if last else stage.new_hidden_batch(t_max)
+    for k in range(len(items) + world - 1):
+        j = k - rank
+        if world > 1:
+            ops = []
+            if not last and 0 <= j - 1 < len(items):
+                ops.append(dist.P2POp(dist.isend, hout[:items[j - 1][2]], rank + 1))
+            if not first and 0 <= j < len(items):
+                ops.append(dist.P2POp(dist.irecv, hin[:items[j][2]], rank - 1))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        if 0 <= j < len(items):
+            s, i0, T = items[j]
+            want = last and want_last and i0 + T == n_prompt
+            stage.prefill(s, prompt[i0:i0 + T] if first else None, T, i0 + pos_offset, None if hin is None else hin[:T], None if hout is None else hout[:T], want)
+            if want:
+                stage.token_to(s, tok[s])
 
 
 def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, steps, dist, torch, model_name="Llama-3-8B Q4_K_M"):

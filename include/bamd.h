@@ -164,6 +164,7 @@ int bamd_bridge_sample_test(void * ctx, const float * logits, const int32_t * la
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
  * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */
 void bamd_set_prefill_batch(int on);   /* 2 = batched, but Q4_K mat-muls on the integer-dot kernel instead of the MFMA kernel */
+void bamd_set_prefill_version(int v);  /* 2 (default): round-5 matrix-core prefill kernels with load-time side tables; 1: the round-2 kernels.  Same bits */
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.

@@ -12,36 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-E, V = 16, 97
-
-
-class FakeStage:
-    """hidden' = (hidden * a + pos + layer-tag) mod P per layer; first stage embeds the token, last stage picks
-    token = (sum(hidden) * 31 + 7) mod V as its 'arg-max'."""
-
-    def __init__(self, layers, is_first, is_last):
-        self.layers, self.is_first, self.is_last = layers, is_first, is_last
-        self.last_tok = {}
-
-    def new_hidden(self): return torch.zeros(E, dtype=torch.float32)
-    def new_token(self): return torch.zeros(1, dtype=torch.int32)
-
-    def step(self, seq, token_host, token_dev, pos, hin, hout, want_logits, prefill_mode):
-        if self.is_first:
-            tok = int(token_dev.item()) if token_dev is not None else token_host
-            h = torch.arange(E, dtype=torch.float32) * 3 + tok
-        else:
-            h = hin.clone()
-        for l in self.layers:
-            h = torch.remainder(h * 5 + pos + 11 * l + seq * 0, 8191)
-        if self.is_last:
-            if want_logits:
-                self.last_tok[seq] = int((int(h.sum().item()) * 31 + 7) % V)
-        else:
-            hout.copy_(h)
-
-    def token_to(self, seq, token_dev): token_dev.fill_(self.last_tok[seq])
-    def sync(self): pass
+from booster_amd.pipeline import FakeStage      # the deterministic CPU stand-in lives in the package (bench.py --backend gloo uses it too)
 
 
 def reference(prompt, n_decode, n_layers):
@@ -73,6 +44,24 @@ def worker(rank, world, port, n_seq, q):
     dist.destroy_process_group()
 
 
+LONG_PROMPT = [(7 * i + 3) % 97 for i in range(1100)]
+
+
+def worker_long(rank, world, port, n_seq, q):
+    """a 1100-token prompt: three micro-batches (512 + 512 + 76) per sequence through the batched prompt phase, then 5 decode steps"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from booster_amd import pipeline
+    ranges = pipeline.split_layers(5, world)
+    st = FakeStage(list(range(*ranges[rank])), rank == 0, rank == world - 1)
+    fed = pipeline.run_pipeline(st, dist, rank, world, LONG_PROMPT, 5, n_seq)
+    calls = list(st.prefill_calls)
+    if rank == 0:
+        q.put((fed, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("n_seq", [1, 2, 3])
 def test_layer_split_world2(n_seq):
     ctx = mp.get_context("spawn")
@@ -88,6 +77,33 @@ def test_layer_split_world2(n_seq):
     assert len(fed) == n_seq and len(fed_two_phase) == n_seq
     for f in fed + fed_two_phase:
         assert f == want
+
+
+@pytest.mark.parametrize("n_seq", [1, 2])
+def test_long_prompt_in_microbatches_world2(n_seq):
+    """the prompt crosses the RCCL pipeline in micro-batches of <= 512 positions (one [T, n_embd] message per boundary each),
+    not one token per round; the generated tokens equal the sequential evaluation"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + n_seq + (os.getpid() % 200)
+    procs = [ctx.Process(target=worker_long, args=(r, 2, port, n_seq, q)) for r in range(2)]
+    for p in procs: p.start()
+    fed, calls = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    want = reference(LONG_PROMPT, 5, 5)
+    assert len(fed) == n_seq
+    for f in fed:
+        assert f == want
+    assert calls == [(s, T, i0) for s in range(n_seq) for i0, T in ((0, 512), (512, 512), (1024, 76))]
+
+
+def test_prompt_microbatches():
+    from booster_amd import pipeline
+    assert pipeline.prompt_microbatches(5) == [(0, 5)]
+    assert pipeline.prompt_microbatches(512) == [(0, 512)]
+    assert pipeline.prompt_microbatches(1100) == [(0, 512), (512, 512), (1024, 76)]
 
 
 def test_split_layers():
