@@ -89,6 +89,28 @@ def cpu_name():
     return "unknown CPU"
 
 
+def physical_cores(limit):
+    """physical cores this process may run on: distinct (package, core) pairs of /proc/cpuinfo among the CPUs of the affinity mask"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
+    seen, cpu, pkg = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and (allowed is None or cpu in allowed):
+                seen.add((pkg, int(v)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(len(seen) or limit, limit))
+
+
 def split_layers(L, n):
     """Booster's gpus: semantic with equal weights (llama.cpp:5954-5958: upper_bound over the cumulative split)."""
     cuts = [int(round(L * (i + 1) / n)) for i in range(n)]
@@ -210,13 +232,22 @@ def main():
         n_past = N_PROMPT
         if warmup > 0:
             ctx.generate_greedy(n_past, warmup); n_past += warmup
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        toks, ev_ms = ctx.generate_greedy(n_past, steps)                   # K hipGraph replays, no host round trips
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # The timed region: EXACTLY K steps between two synchronisations, repeated R = 5 times back to back over the SAME positions (the K steps
+        # rewrite the same KV rows, so every repetition is the metric's n_kv range); `value` is the MEDIAN repetition, config.repeats carries min / median / max
+        # (the driver times 20 steps = 0.03 s: one repetition alone is at the mercy of whatever else the box does in those 30 ms).
+        reps_dt, reps_ev = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks, ev_ms_r = ctx.generate_greedy(n_past, steps)             # K hipGraph replays, no host round trips
+            torch.cuda.synchronize()
+            reps_dt.append(time.perf_counter() - t0); reps_ev.append(ev_ms_r)
+        order = sorted(range(5), key=lambda i: reps_dt[i])
+        dt, ev_ms = reps_dt[order[2]], reps_ev[order[2]]
         n_past += steps
         tok_s = steps / dt
+        repeats = dict(n=5, tokens_per_s=dict(min=round(steps / max(reps_dt), 2), median=round(tok_s, 2), max=round(steps / min(reps_dt), 2)),
+                       note="same K steps over the same positions, back to back; value = the median repetition")
         # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length, per launch kind
         KINDS = ["qkv", "attention", "other", "wo", "gate_up", "ffn_down", "lm_head"]
         KERNEL_OF = {"qkv": "matvec_split_fast_kernel / matvec_split_mixed_kernel (fused QKV, RMSNorm prologue)", "wo": "matvec_split_fast_kernel (wo, +residual)",
@@ -282,7 +313,7 @@ def main():
             value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
             config=dict(workload="%s shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
                                  "128-token prompt, n_ctx %d, n_kv %d..%d" % (model_name, n_ctx, N_PROMPT + warmup, n_past),
-                        parallelism="single GPU", graph_event_ms_per_step=round(ev_ms / steps, 4),
+                        parallelism="single GPU", repeats=repeats, graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),
@@ -306,13 +337,24 @@ def main():
                     ncpu = len(os.sched_getaffinity(0))
                 except AttributeError:
                     ncpu = os.cpu_count() or 1
-                nthr = max(1, min(ncpu, 32))
+                phys = physical_cores(ncpu)
+                # the reference's CPU path is memory-bound: sweep the thread count over {32, 64, all physical cores} (bounded: ~3-5 s each) and report the best
+                cands = sorted(set(max(1, min(ncpu, c)) for c in (32, 64, phys)))
+                ref, sweep = None, {}
                 try:
-                    ref = cpu_baseline_reference(path, nthr)
+                    for c in cands:
+                        r = cpu_baseline_reference(path, c)
+                        if r is None:
+                            break
+                        sweep[str(c)] = r["value"]
+                        if ref is None or r["value"] > ref["value"]:
+                            ref = r
+                    if ref is not None:
+                        ref["thread_sweep_tokens_per_s"] = sweep; ref["physical_cores"] = phys
                 except Exception as e:
                     sys.stderr.write("[bench] reference cpu baseline failed (%r); falling back to the oracle port\n" % (e,))
                     ref = None
-                result["cpu_baseline"] = ref if ref is not None else cpu_baseline(path, nthr)
+                result["cpu_baseline"] = ref if ref is not None else cpu_baseline(path, max(1, min(ncpu, 32)))
             except Exception as e:      # the checker must never take the bench down
                 result["cpu_baseline"] = dict(value=None, unit="tokens/s", cores=0, kind="port", sample="failed: %r" % (e,))
         ctx.close(); m.close()
@@ -392,7 +434,8 @@ def secondary_configs(booster_amd, m8b, torch):
 def bridge_longctx_rate(n_pos=7900):
     """BASELINE config 5 as specified: Mistral-7B shape, all Q6_K, 8 K context, Janus sampling — through include/booster_bridge.h's nine symbols (ctypes
     stands where cgo would).  The decode rate at ~n_pos cached positions is the difference of two requests on the same prompt (n_predict 24 and 88): the
-    prompt evaluation, tokenisation and sampler set-up cancel."""
+    prompt evaluation, tokenisation and sampler set-up cancel.  Round 5: both pods are warmed first, the pair is repeated three times (median, min / max), and
+    the level-1 greedy rate at the same cached length is reported beside it (the first version timed pod 2's first-request allocations)."""
     import ctypes as C
     from booster_amd import gguf, build
     path = os.path.join(os.path.dirname(model_path("m7q6k")), "bamd_bench_m7q6k_vocab.gguf")
@@ -414,33 +457,68 @@ def bridge_longctx_rate(n_pos=7900):
     L.getPromptTokenCount.restype = C.c_int64; L.getPromptTokenCount.argtypes = [C.c_char_p]
     L.init(b"", b"")
     unit = "the quick brown fox jumps over the lazy dog and then "
-    res = {}
-    n_prompt = 0
+    # Two pods (n_predict is a context parameter: cpp/bridge.cpp:723-786), both on this GPU.  Each gets ONE discarded warm-up request with the very prompt
+    # (its first doInference allocates the prefill buffers and the attention scratch; the KV cache is cleared per request by contract, bridge.cpp:459), then
+    # three timed requests, the pods alternating; the decode rate is the MEDIAN of the three differences (long request - short request), min / max beside it.
+    ctxs = {}
     for idx, n_predict in ((1, 24), (2, 88)):
-        ctx = L.initContext(idx, path.encode(), 4, 512, 100, 0, 0, 0, 8192, n_predict, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64, 1, 200, 0.97, 0.99, 0.96, 42, b"")
-        if not ctx:
+        c = L.initContext(idx, path.encode(), 4, 512, 100, 0, 0, 0, 8192, n_predict, 0, 0.0, 0.0, 0.8, 40, 0.9, 1.0, 1.1, 64, 1, 200, 0.97, 0.99, 0.96, 42, b"")
+        if not c:
             raise RuntimeError("initContext failed")
-        if n_prompt == 0:                                                  # size the prompt: tokens per repetition of the unit, from a short request's count
-            L.doInference(idx, ctx, b"probe", b"s", (unit * 8).encode())
-            per = max(L.getPromptTokenCount(b"probe") / 8.0, 1.0)
-            reps = int(n_pos / per)
-        prompt = (unit * reps).encode()
-        job = b"cfg5_%d" % n_predict
+        ctxs[n_predict] = (idx, c)
+    L.doInference(1, ctxs[24][1], b"probe", b"s", (unit * 8).encode())     # size the prompt: tokens per repetition of the unit, from a short request's count
+    per = max(L.getPromptTokenCount(b"probe") / 8.0, 1.0)
+    prompt = (unit * int(n_pos / per)).encode()
+
+    def request(n_predict, tag):
+        idx, c = ctxs[n_predict]
+        job = b"cfg5_%d_%s" % (n_predict, tag)
         t0 = time.perf_counter()
-        n = L.doInference(idx, ctx, job, b"s", prompt)
-        res[n_predict] = (time.perf_counter() - t0, int(n), int(L.getPromptTokenCount(job)))
-        n_prompt = res[n_predict][2]
-    (ta, na, pa), (tb, nb, pb) = res[24], res[88]
-    gen = (nb - pb) - (na - pa)
-    if gen <= 0:
-        raise RuntimeError("the two requests generated %d and %d tokens (an end-of-generation token cut one short)" % (na - pa, nb - pb))
-    ms = (tb - ta) / gen * 1e3
+        n = L.doInference(idx, c, job, b"s", prompt)
+        return time.perf_counter() - t0, int(n), int(L.getPromptTokenCount(job))
+
+    for n_predict in (24, 88):
+        request(n_predict, b"warm")
+    pairs = []
+    for r in range(3):
+        ta, na, pa = request(24, b"r%d" % r)
+        tb, nb, pb = request(88, b"r%d" % r)
+        gen = (nb - pb) - (na - pa)
+        if gen <= 0:
+            raise RuntimeError("the two requests generated %d and %d tokens (an end-of-generation token cut one short)" % (na - pa, nb - pb))
+        pairs.append(dict(ms=(tb - ta) / gen * 1e3, ta=ta, tb=tb, gen=[na - pa, nb - pb], prompt=pb, total=nb))
+    ms_all = sorted(p_["ms"] for p_ in pairs)
+    ms = ms_all[1]
+    pb, nb_tot = pairs[0]["prompt"], pairs[0]["total"]
     E, F, Lr, V = 4096, 14336, 32, 32000
     W = (Lr * (E * (E + 2 * 1024) + E * E + 3 * E * F) + V * E) // 256 * 210
-    bpt = W + 2 * Lr * 1024 * 2 * (pb + (nb - pb) // 2)
-    return dict(workload="Mistral-7B shape, every matrix Q6_K, n_ctx 8192, through the nine bridge symbols with Janus sampling (device prefilter): decode at %d cached positions" % pb,
-                value=round(1e3 / ms, 2), unit="tokens/s", ms_per_token=round(ms, 3), prompt_tokens=pb, generated=[na - pa, nb - pb], bytes_per_token=int(bpt),
-                frac_of_hbm_roofline_tokens=round(1e3 / ms * bpt / (HBM_PEAK_GBS * 1e9), 4), request_seconds=[round(ta, 3), round(tb, 3)])
+    bpt = W + 2 * Lr * 1024 * 2 * (pb + (nb_tot - pb) // 2)
+    out = dict(workload="Mistral-7B shape, every matrix Q6_K, n_ctx 8192, through the nine bridge symbols with Janus sampling (device prefilter): decode at %d cached positions" % pb,
+               value=round(1e3 / ms, 2), unit="tokens/s", ms_per_token=round(ms, 3), prompt_tokens=pb, generated=pairs[0]["gen"], bytes_per_token=int(bpt),
+               frac_of_hbm_roofline_tokens=round(1e3 / ms * bpt / (HBM_PEAK_GBS * 1e9), 4),
+               repeats=dict(n=3, tokens_per_s=dict(min=round(1e3 / ms_all[2], 2), median=round(1e3 / ms_all[1], 2), max=round(1e3 / ms_all[0], 2)),
+                            request_seconds=[[round(p_["ta"], 3), round(p_["tb"], 3)] for p_ in pairs],
+                            note="both pods warmed by one discarded request of the same prompt; value = median of three (88-token request - 24-token request) differences"))
+    # level-1 cross-check on the same GGUF at the same cached length: Context.generate_greedy (device-side greedy loop, no bridge, no Janus) — the difference
+    # to `value` is what the bridge's per-token host work (sampler, detokenisation, status text) costs
+    try:
+        import booster_amd
+        import torch
+        m = booster_amd.Model(path, device=0)
+        ctx = booster_amd.Context(m, 8192)
+        toks = [(7919 * i + 13) % m.n_vocab for i in range(pb)]
+        for i in range(0, pb, 512):
+            ctx.decode(toks[i:i + 512], i)
+        ctx.generate_greedy(pb, 8)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx.generate_greedy(pb + 8, 64)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out["level1_greedy"] = dict(value=round(64 / dt, 2), unit="tokens/s", ms_per_token=round(dt / 64 * 1e3, 3), cached_positions=pb + 8,
+                                    note="Context.generate_greedy (include/bamd.h) at the same cached length: the bridge + Janus overhead is the difference to `value`")
+        ctx.close(); m.close()
+    except Exception as e:
+        out["level1_greedy"] = dict(skipped="failed: %r" % (e,))
+    return out
 
 
 def emit(rank, dist, result, model_name, N, steps, warmup):

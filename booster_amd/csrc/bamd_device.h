@@ -175,6 +175,10 @@ __device__ __forceinline__ double seq_expsum8(const float * vals, int n) {
 // from the FIRST element of largest magnitude (strict > scan), so ties resolve to the lowest lane, lowest element.
 #define BAMD_ACT_BATCH 4
 // LDS layout of the quantised activations of one mat-vec: q8[nb][64] u32 | S[nb][8] i32 | yd[nb] f32 | (16-byte aligned) red[16] f64
+#ifndef BAMD_CEILING
+#define BAMD_CEILING 0               /* timing-only builds (never shipped): 1 = mat-vec prologues without the Q8_K / RMSNorm statistics, 2 = split-K kernels without the
+                                        barrier + sequential chain replay: what the reference's arithmetic costs per launch (profiles/r05_ceiling.txt) */
+#endif
 #define BAMD_ACT_RED_OFF(nb) ((((size_t) (nb) * (256 + 32 + 4)) + 15) & ~(size_t) 15)
 template <bool NORM>
 struct ActPro {
@@ -217,6 +221,21 @@ struct ActPro {
     __device__ __forceinline__ void quantize_batch(float scale, int K, int i0, uint32_t * q8, int * S, float * yd, int bstride = 0, int blimit = 0) {
         const int lane = threadIdx.x & 63;
         const int nwaves = bstride ? bstride : (int) (blockDim.x >> 6), nb = bstride ? blimit : (K >> 8);
+#if BAMD_CEILING & 1
+        // TIMING-ONLY ceiling build (tools/ceiling.sh; never shipped, results are garbage): the activations arrive "already quantised" — no block maxima,
+        // no divisions, no rounding: what a prologue costs that is a plain load + three LDS stores
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = i0 + b * nwaves;
+            if (i < nb) {
+                const uint32_t packed = __float_as_uint(v[b].x) ^ (__float_as_uint(v[b].y) >> 8);
+                q8[i * 64 + (lane & 7) * 8 + (lane >> 3)] = packed;
+                if ((lane & 7) == 0) S[i * 8 + (lane >> 3)] = (int) (packed & 0xff);
+                if (lane == 0) yd[i] = scale;
+            }
+        }
+        return;
+#endif
         uint32_t amaxb[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -296,6 +315,9 @@ struct ActPro {
         const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6, nb = K >> 8;
         const int step = nwaves * BAMD_ACT_BATCH;
         float scale = 1.0f;
+#if BAMD_CEILING & 1
+        if (NORM) { mid(); } else
+#endif
         if (NORM) {
             // sum of squares in double (ggml.c:11874-11877), fixed tree order; f32_rounding_safe() below decides whether the order can matter
             double s = 0.0;

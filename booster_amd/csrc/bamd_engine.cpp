@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -175,12 +176,18 @@ struct bamd_context {
         unsigned long long * tl = nullptr;                                                    // timeline block of the next launch (bamd_wse_timeline)
         std::string why;
     } wse;
+    bool counted = false;            // this context is in g_ctx_live
     int bcap = 0;
-    float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0;   // score rows of the matrix-core prefill attention beyond BAMD_AM_MAXPOS = 512 positions (grow-only; absent = the VALU kernel runs)
+    float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0, attn_bscr_failed = 0;   // score rows of the matrix-core prefill attention beyond BAMD_AM_MAXPOS = 512 positions (grow-only; absent = the VALU kernel runs)
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
 
+// contexts alive per device.  The weight-stream engine (bamd_wse.hip) is ONE persistent launch whose workgroups wait for each other: every workgroup must be
+// resident at once, which holds only while no other context shares the device (two engine launches, each holding part of the CUs, would wait for workgroups that
+// were never scheduled until their spins give up — ADVICE r4).  So the engine is used only by a context that is alone on its device; a second context turns
+// every context of that device back to the launch sequence (wse_usable is part of the graph key: the step graph is recaptured).
+static std::atomic<int> g_ctx_live[64];
 static int dev_alloc(std::vector<void *> & keep, void ** p, size_t bytes) {
     HIPC(hipMalloc(p, bytes + 2048));           // + 2 KiB: the weight-stream engine's last 1 KiB request of a piece may read past the last record
     keep.push_back(*p);
@@ -418,10 +425,12 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
 extern "C" __attribute__((visibility("default"))) bamd_context * bamd_context_new(bamd_model * m, int n_ctx) {
     bamd_context * c = new bamd_context();
     if (context_init(c, m, n_ctx)) { bamd_context_free(c); return nullptr; }
+    c->counted = true; g_ctx_live[m->device & 63].fetch_add(1);
     return c;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_context * c) {
     if (!c) return;
+    if (c->counted && c->m) g_ctx_live[c->m->device & 63].fetch_sub(1);
     if (c->m) hipSetDevice(c->m->device);
     if (c->graph) hipGraphExecDestroy(c->graph);
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
@@ -598,7 +607,7 @@ static void wse_fill_args(bamd_context * c, bamd_wse_args & a) {
 // single-token decode (reference semantics T = 1), sequences the single-launch attention covers, cells following positions: what the engine's
 // attention role implements.  Everything else takes the launch sequence.
 static bool wse_usable(bamd_context * c, int prefill_mode, int pos_hi) {
-    return g_wse && !prefill_mode && attn_fused_for(c, pos_hi) && c->wse.ok;
+    return g_wse && !prefill_mode && attn_fused_for(c, pos_hi) && c->wse.ok && g_ctx_live[c->m->device & 63].load() <= 1;
 }
 // plans the engine the first time it could be used.  Called at the entry points BEFORE any stream capture begins (the planner allocates and copies).
 static void wse_prepare(bamd_context * c) {
@@ -629,9 +638,26 @@ static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStrea
                            with_slots ? c->slots : nullptr, with_slots ? c->cellpos : nullptr);
 }
 
+// The tag of a granule hand-over (bamd_colaunch.hip, bamd_wse.hip) is (host serial : 12, device step : 12, layer : 8); a word must never already hold the tag a
+// consumer is about to wait for.  The serial runs 1 .. 0xffe (0 is what zero-initialised granules carry, 0xfff is reserved) and every time it wraps ALL granule
+// vectors of the context are overwritten with 0xff bytes — tag 0xffffffff, which no launch produces — in stream order ahead of the launch that reuses serial 1
+// (with a bare 12-bit counter a stale granule of 4096 host calls ago carried the awaited tag and a gather passed without waiting).
+static int next_serial(bamd_context * c, hipStream_t s) {
+    if (++c->host_serial > 0xffe) {
+        c->host_serial = 1;
+        const bamd_model * m = c->m;
+        if (c->co_gran) HIPC(hipMemsetAsync(c->co_gran, 0xff, (size_t) m->H * m->hd * 8, s));
+        if (c->wse.gran[0]) {
+            const size_t Ekv = (size_t) m->Hkv * m->hd, gn[5] = { (size_t) m->E, (size_t) m->E + 2 * Ekv, (size_t) m->E, (size_t) m->E, (size_t) m->F };
+            for (int i = 0; i < 5; ++i) if (c->wse.gran[i]) HIPC(hipMemsetAsync(c->wse.gran[i], 0xff, gn[i] * 8, s));
+        }
+    }
+    return 0;
+}
 static int set_state(bamd_context * c, int pos_base, hipStream_t s, bool keep_key) {
     bamd_step_state h; memset(&h, 0, sizeof h);
-    h.pos_base = pos_base; h.n_ctx = c->n_ctx; h.serial = (c->host_serial = (c->host_serial + 1) & 0xfff);
+    if (next_serial(c, s)) return 1;
+    h.pos_base = pos_base; h.n_ctx = c->n_ctx; h.serial = c->host_serial;
     if (keep_key) {
         // keep best_key (the arg-max of the previous lm_head): rewrite only the leading fields
         HIPC(hipMemcpyAsync(c->st, &h, offsetof(bamd_step_state, best_key), hipMemcpyHostToDevice, s));
@@ -902,14 +928,14 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
         t.batch = 1; t.ld_qkv = ldq; t.ld_out = E; t.lds_ld = attn_lds_ld(c, n_past + T - 1); t.batch_pos0p1 = n_past + 1;
         {
             const size_t need = m->hd == 128 ? bamd_attention_batch_mfma_scratch(m->Hkv, gq, T, t.lds_ld) : 0;
-            if (need > c->attn_bscr_bytes) {                                   // (freed with the context; replaced only while nothing of this context is in flight: stream order)
+            if (need > c->attn_bscr_bytes && !(c->attn_bscr_failed && need >= c->attn_bscr_failed)) {   // (freed with the context; replaced only while nothing of this context is in flight: stream order)
                 HIPC(hipStreamSynchronize(s));
                 if (c->attn_bscr) hipFree(c->attn_bscr);
                 c->attn_bscr = nullptr; c->attn_bscr_bytes = 0;
                 // ~ H * T * ld * 4 bytes (0.5 GB at 8 K positions on the 8B shape, 2.4 GB at 18 K on a 70B stage).  If the device cannot spare it the
                 // prompt is not lost: without a scratch block the matrix-core launcher declines and attn_batch_kernel (VALU, no scratch) runs
                 if (hipMalloc((void **) &c->attn_bscr, need) == hipSuccess) c->attn_bscr_bytes = need;
-                else { (void) hipGetLastError(); c->attn_bscr = nullptr; }
+                else { (void) hipGetLastError(); c->attn_bscr = nullptr; c->attn_bscr_failed = need; }   // not retried for this size or larger (every layer of every micro-batch drained the stream and failed again)
             }
             t.batch_scratch = need && c->attn_bscr_bytes >= need ? c->attn_bscr : nullptr;
         }
@@ -1152,7 +1178,8 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
     // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
-    bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx; h.serial = (c->host_serial = (c->host_serial + 1) & 0xfff);
+    if (next_serial(c, s)) return 1;
+    bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx; h.serial = c->host_serial;
     int attn_hi = pos;                                   // what decides single-launch vs three-launch attention
     if (c->cells.active) {
         if (prefill_mode) return fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call");
@@ -1505,6 +1532,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_wse_timeline(bamd_con
     if (!wse_usable(c, 0, pos)) return fail("weight-stream engine not active for this context: " + c->wse.why);
     hipStream_t s = c->stream;
     const size_t words = (size_t) c->wse.plan.n_cu * c->wse.plan.tl_ops * 8;
+    if (c->wse.plan.tl_ops > 254) return fail("bamd_wse_timeline: this stage has more timeline rows than the op records index (8-bit slot: <= 42 layers)");
     if ((size_t) cap_words < words) return fail("bamd_wse_timeline: output buffer too small");
     OwnedDevMem mem; HIPC(hipMalloc(&mem.p, words * 8));
     HIPC(hipMemsetAsync(mem.p, 0, words * 8, s));

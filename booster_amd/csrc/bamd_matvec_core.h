@@ -318,6 +318,12 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
             }
         }
         if (r0 == 0) TL_STAMP(pa.tl, 3);
+#if BAMD_CEILING & 2
+        // TIMING-ONLY ceiling build: no barrier, no chain replay — every wave stores from its own first parked term (garbage results)
+        if (wave < nbatch) { const float4 t = ((const float4 *) (B0 + (size_t) wave * rg_floats))[i0 * 64 + lane]; if ((lane & 7) == 0 && crow < nvalid) out[crow] = t.x + t.y + resv; }
+        batchctr += 1; bbase += M * rg_step;
+        continue;
+#endif
         __syncthreads();
         if (r0 == 0) TL_STAMP(pa.tl, 4);
         if (wave < nbatch) {

@@ -57,8 +57,9 @@ static void byte_maps(uint32_t b2u[256], std::unordered_map<uint32_t, uint8_t> &
 bool BamdVocab::load(const GgufFile & g, std::string & err) {
     // the tokenizer serves the files the engine loads (bamd_engine.cpp: general.architecture "llama" — Llama-2/3, Mistral, deepseek-llm / -coder, SmolLM,
     // Mistral-Nemo (tekken), Viking / Poro ... as GGUF names them); the pre-tokenisers of other architectures' families (qwen2, falcon, starcoder ...) are
-    // restated and pinned as well — llm_load_vocab keys on tokenizer.ggml.pre alone — but a file of another architecture is refused here as it is there
-    { std::string arch; if (g.get_str("general.architecture", arch) && arch != "llama") { err = "general.architecture must be \"llama\" (got \"" + arch + "\")"; return false; } }
+    // restated and pinned as well — llm_load_vocab keys on tokenizer.ggml.pre alone
+    // (the architecture check lives in the model loader, bamd_engine.cpp: the vocabulary is keyed on tokenizer.ggml.model / .pre alone, as llm_load_vocab is —
+    //  vocab-only use on files of other families keeps working)
     std::string model;
     if (!g.get_str("tokenizer.ggml.model", model)) { err = "missing tokenizer.ggml.model"; return false; }
     if (model == "no_vocab") { type = BAMD_VOCAB_NONE; return true; }

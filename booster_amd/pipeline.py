@@ -312,6 +312,17 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
     fed = run_pipeline(stage, dist, rank, N, prompt, warmup + 1, N)
     pos0 = len(prompt) + warmup
     carry = [fed[0][-1] if rank == 0 else 0]
+    # "RCCL saw N ranks", measured: the size of the process group and an all-reduce of ones over it
+    ones = torch.ones(1, dtype=torch.float64, device=stage.device)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    rccl_world, rccl_sum = dist.get_world_size(), float(ones.item())
+    # ---- prompt evaluation through the stages: the prompt of ONE sequence again (same positions, same KV rows), micro-batches of <= 512 positions, one
+    #      [T, n_embd] send/recv per boundary and micro-batch (_prompt_phase) ----
+    dist.barrier(); stage.sync()
+    t0 = time.perf_counter()
+    run_pipeline(stage, dist, rank, N, prompt, 0, 1)
+    stage.sync(); dist.barrier()
+    dt_prompt = time.perf_counter() - t0
     # ---- the metric: one sequence, K steps ----
     dist.barrier(); stage.sync()
     t0 = time.perf_counter()
@@ -336,9 +347,9 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
         empty_ms = a.elapsed_time(b)
     stage_ms = max(sum(x.elapsed_time(y) for x, y in ev) / max(len(ev), 1) - empty_ms, 1e-6)
     wbytes = float(getattr(stage.model, "weight_bytes", 0))         # this rank's slice of the mat-mul weights
-    t = torch.tensor([dt_single, dt_pods], dtype=torch.float64, device=stage.device)
+    t = torch.tensor([dt_single, dt_pods, dt_prompt], dtype=torch.float64, device=stage.device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_single, dt_pods = [float(v) for v in t.tolist()]
+    dt_single, dt_pods, dt_prompt = [float(v) for v in t.tolist()]
     per = torch.zeros(N, 2, dtype=torch.float64, device=stage.device)
     per[rank, 0] = wbytes; per[rank, 1] = stage_ms
     dist.all_reduce(per, op=dist.ReduceOp.SUM)
@@ -352,7 +363,9 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
                 config=dict(workload="%s shapes (synthetic GGUF), greedy batch-1 decode of ONE sequence, layer-split over %d MI355X "
                                      "(Booster's gpus: split), 128-token prompt, n_ctx %d" % (model_name, N, n_ctx),
                             parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state [n_embd] per boundary per token" % N,
-                            rccl_ranks=N, layer_ranges=ranges, sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
+                            rccl_ranks=N, rccl_world=rccl_world, rccl_allreduce_of_ones=rccl_sum, layer_ranges=ranges,
+                            prompt_eval_tokens_per_s=round(len(prompt) / dt_prompt, 1), prompt_microbatches=len(prompt_microbatches(len(prompt))),
+                            sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
                             pods_tokens_per_s=round(N * steps / dt_pods, 2),
                             note="value = one request through all stages (stages idle in turn: the reference's batch-1 behaviour); "
                                  "pods_tokens_per_s = N independent sequences in flight, every stage busy"),

@@ -7,7 +7,7 @@ O=$R/gpurun_out/${1:-prof}
 rm -rf "$O"; mkdir -p "$O/stats" "$O/pmc" "$O/prefill/stats" "$O/prefill/pmc"
 cd /tmp && export TMPDIR=/tmp
 run() { ( cd "$R" && timeout 400 "$@" ) < /dev/null; }
-run python bench.py --steps 128 --warmup 16 --no-secondary > "$O/bench_n1.json" 2> "$O/bench_n1.err"
+run python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"            # the full default run (config.secondary included): this is the line profiles/rNN_bench_n1.json holds
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-secondary > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc" -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > "$O/pmc.out" 2> "$O/pmc.err"
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prefill/stats" -- python tools/prefill_profile.py 512 > "$O/pstats.out" 2> "$O/pstats.err"
