@@ -54,6 +54,7 @@ struct Pod {
     std::atomic<bool> stop{ false };
     std::vector<float> logits;                   // host copy the sampler may modify in place
     bool gpu_sampler = false;                    // Janus penalties + shortlist on the device (bamd_logits_shortlist); env BAMD_JANUS_GPU=0 disables
+    std::chrono::steady_clock::time_point eval_t0; int eval_n = 0; bool eval_open = false;   // an evaluation whose wait happens in the sampler (pod_decode)
     int64_t n_sample_dev = 0, n_sample_host = 0; // tokens sampled from the device shortlist / through the host path
     // llama_timings equivalents (llama.cpp:18527-18551)
     double t_p_eval_ms = 0, t_eval_ms = 0; int64_t n_p_eval = 0, n_eval = 0;
@@ -292,6 +293,12 @@ int sample_janus(Pod & p, float * logits, const std::vector<int> & last_tokens, 
 // (a token that occurs k times in the window is multiplied k times, in sequence, as the reference's loop does), the x0.5 pass and
 // the ratio test run where the logits are, and only the shortlist comes back.  Whenever the order of the result could depend on the
 // reference's full sort the (already penalised) logits are read back and the host shortlist runs on them: same result either way.
+static void pod_eval_done(Pod & p) {
+    if (!p.eval_open) return;
+    p.eval_open = false;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p.eval_t0).count();
+    if (p.eval_n == 1) { p.t_eval_ms += ms; p.n_eval += 1; } else { p.t_p_eval_ms += ms; p.n_p_eval += p.eval_n; }
+}
 int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t promptLen, size_t pos, size_t max) {
     const size_t V = (size_t) p.n_vocab, ctxSize = last_tokens.size();
     Stage & st = p.stages.back();
@@ -320,6 +327,7 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
         std::vector<int32_t> ids((size_t) BAMD_SHORTLIST_CAP); std::vector<float> vals((size_t) BAMD_SHORTLIST_CAP);
         void * stream = st.stream();
         if (bamd_logits_shortlist(st.ctx, pen.data(), (int) pen.size(), ru_context ? 1 : 0, &head, ids.data(), vals.data(), stream)) return -1;
+        pod_eval_done(p);
         host_path = head.nan || !(head.top_logit > 0.0f) || head.ntop != 1 || head.count < 1 || head.count > BAMD_SHORTLIST_CAP;
         if (!host_path) {
             for (int i = 0; i < head.count; i++) cand.push_back(Cand{ ids[(size_t) i], vals[(size_t) i], 0.0f });
@@ -334,6 +342,7 @@ int sample_janus_device(Pod & p, const std::vector<int> & last_tokens, size_t pr
         }
     } else {                                      // more distinct penalised tokens than the device list holds: the host sampler
         const float * lg = p.stages.size() == 1 ? bamd_get_logits(st.ctx) : bamd_stage_get_logits(st.ctx, st.stream());
+        pod_eval_done(p);
         if (!lg) return -1;
         memcpy(p.logits.data(), lg, V * 4);
         p.n_sample_host++;
@@ -452,6 +461,14 @@ int pod_decode(Pod & p, const int * tokens, int n, int n_past, bool need_logits 
             if (hipStreamSynchronize((hipStream_t) lst.stream()) != hipSuccess) return 1;
         }
     }
+    if (p.stages.size() == 1 && p.gpu_sampler) {
+        // bamd_decode did not wait (no read-back: the sampler prefilter follows on the same stream): the evaluation's time ends where sample_janus_device's one
+        // wait returns — the clock keeps running until then (pod_eval_done; the micro-batches of a prompt share one interval), so that timing() / promptEval()
+        // still report wall time per token
+        if (!p.eval_open) { p.eval_t0 = t0; p.eval_n = 0; p.eval_open = true; }
+        p.eval_n += n;
+        return 0;
+    }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (n == 1) { p.t_eval_ms += ms; p.n_eval += 1; } else { p.t_p_eval_ms += ms; p.n_p_eval += n; }    // llama_synchronize, llama.cpp:18527-18551
     return 0;
@@ -551,7 +568,7 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
     if (idx < 0 || idx >= 8 || !ctx || !jobID || !prompt) return 1;
     Pod & p = *(Pod *) ctx;
     const std::string job = jobID, text = prompt;
-    p.t_p_eval_ms = p.t_eval_ms = 0; p.n_p_eval = p.n_eval = 0;             // llama_reset_timings
+    p.t_p_eval_ms = p.t_eval_ms = 0; p.n_p_eval = p.n_eval = 0; p.eval_open = false;   // llama_reset_timings
     p.stop.store(false);
     if (!p.janus_ready) { init_janus(p); upload_sampler_tables(p); }                                       // the reference rebuilds (and leaks) the tables per request
     const uint32_t seed = (uint32_t) time(nullptr);

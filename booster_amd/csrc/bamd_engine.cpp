@@ -141,6 +141,7 @@ struct bamd_context {
     float * logits = nullptr;        // device
     float * logits_host = nullptr;   // pinned
     bool logits_readback = true, logits_host_valid = false;
+    bool status_pending = false;     // a bamd_decode without read-back returned before its stream was waited for: the next synchronising call checks the give-up words
     // sampler prefilter (bamd_logits_shortlist): per-vocabulary tables, penalty list and result (device + pinned mirrors)
     uint8_t * samp_cls = nullptr; float * samp_cut = nullptr;
     bamd_logit_penalty * samp_pen = nullptr, * samp_pen_host = nullptr;
@@ -1017,6 +1018,13 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     c->logits_host_valid = c->logits_readback;
     if (c->logits_readback && hipMemcpyAsync(c->logits_host, c->logits, (size_t) m->V * 4, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("D2H logits"); return 1; }
     if (status_readback(c, s) != hipSuccess) { fail("D2H co-launch status"); return 1; }
+    if (!c->logits_readback) {
+        // nothing of this evaluation is read on the host yet (bamd_set_logits_readback(c, 0): the sampler prefilter runs where the lm_head left the logits): do not wait
+        // here — the caller's next synchronising call (bamd_logits_shortlist, bamd_get_logits) enqueues behind this evaluation, waits ONCE and checks the status words
+        // then.  One host round trip per token instead of two (round 5: 2.31 -> 2.27 ms per token through the bridge at 7850 cached positions)
+        c->status_pending = true;
+        return 0;
+    }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("decode failed: ") + hipGetErrorString(e)); return 1; }
     if (co_gave_up(c)) return 1;
@@ -1049,6 +1057,7 @@ extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(
         if (hipSetDevice(c->m->device) != hipSuccess) return nullptr;
         if (hipMemcpyAsync(c->logits_host, c->logits, (size_t) c->m->V * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return nullptr;
         if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
+        if (c->status_pending) { c->status_pending = false; if (co_gave_up(c)) return nullptr; }
         c->logits_host_valid = true;
     }
     return c->logits_host;
@@ -1098,6 +1107,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_logits_shortlist(bamd
     HIPC(hipMemcpyAsync(c->samp_out_host, c->samp_out, out_bytes, hipMemcpyDeviceToHost, s));
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { fail(std::string("sampler prefilter failed: ") + hipGetErrorString(e)); return 1; }
+    if (c->status_pending) { c->status_pending = false; if (co_gave_up(c)) return 1; }      // the evaluation in front of this call (bamd_decode without read-back) was not waited for
     memcpy(head, c->samp_out_host, sizeof *head);
     const int n = std::min(std::max(head->count, 0), BAMD_SHORTLIST_CAP);
     memcpy(ids, c->samp_out_host + sizeof(bamd_shortlist_head), (size_t) n * 4);
