@@ -190,7 +190,8 @@ struct bamd_context {
 // every context of that device back to the launch sequence (wse_usable is part of the graph key: the step graph is recaptured).
 static std::atomic<int> g_ctx_live[64];
 static int dev_alloc(std::vector<void *> & keep, void ** p, size_t bytes) {
-    HIPC(hipMalloc(p, bytes + 2048));           // + 2 KiB: the weight-stream engine's last 1 KiB request of a piece may read past the last record
+    HIPC(hipMalloc(p, bytes + 4096));           // + 4 KiB: the weight-stream engine's last 1 KiB request of a piece may read past the last record, the sixteen-wave
+                                                // prefill kernel's nibble loads of the two super-blocks behind the end of K past the last record group (bamd_prefill2.hip)
     keep.push_back(*p);
     return 0;
 }
@@ -1381,7 +1382,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_timeline_step(bamd_co
 struct Tmp {
     std::vector<void *> p;
     ~Tmp() { for (void * x : p) hipFree(x); }
-    void * up(const void * h, size_t n) { void * d = nullptr; if (hipMalloc(&d, n + 2048) != hipSuccess) return nullptr; p.push_back(d); if (h && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) return nullptr; return d; }
+    void * up(const void * h, size_t n) { void * d = nullptr; if (hipMalloc(&d, n + 4096) != hipSuccess) return nullptr; p.push_back(d); if (h && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) return nullptr; return d; }
 };
 static int need_device() {
     if (bamd_device_count() <= 0) return fail("no HIP device available: libbooster_amd has no CPU fallback");
@@ -1582,13 +1583,13 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     HIPC(hipMemset(str, 0, wbp));
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
-    if (impl == 2 || impl == 3) {                                   // round-5 kernels (3: the eight-wave Q4_K / Q5_K layout): side table built here, as the engine builds it at the first batched evaluation
-        bamd_launch_prefill_waves(impl == 3 ? 8 : 16);
+    if (impl >= 2 && impl <= 5) {                                   // round-5 kernels (2: the default layout, 3: eight waves of 16 x 32, 4: sixteen waves of 16 x 16, 5: sixteen waves on 32 x 32 tiles): side table built here, as the engine builds it at the first batched evaluation
+        bamd_launch_prefill_waves(impl == 3 ? 8 : impl == 4 ? 16 : impl == 5 ? 32 : 64);
         void * aux = t.up(nullptr, bamd_prefill_aux_bytes(type, nrows_pad, k));
         if (!aux) return fail("device alloc failed");
         bamd_launch_prefill_aux(str, type, nrows_pad, k, aux, nullptr);
         const int rc2 = bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr);
-        bamd_launch_prefill_waves(16);
+        bamd_launch_prefill_waves(64);
         if (rc2) return fail("MFMA path: unsupported type/shape");
     } else if (impl == 1) {
         if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
