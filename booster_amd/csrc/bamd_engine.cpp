@@ -1583,13 +1583,13 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     HIPC(hipMemset(str, 0, wbp));
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
-    if (impl >= 2 && impl <= 5) {                                   // round-5 kernels (2: the default layout, 3: eight waves of 16 x 32, 4: sixteen waves of 16 x 16, 5: sixteen waves on 32 x 32 tiles): side table built here, as the engine builds it at the first batched evaluation
-        bamd_launch_prefill_waves(impl == 3 ? 8 : impl == 4 ? 16 : impl == 5 ? 32 : 64);
+    if (impl == 2 || impl == 3) {                                   // round-5 kernels (3: the eight-wave Q4_K / Q5_K layout): side table built here, as the engine builds it at the first batched evaluation
+        bamd_launch_prefill_waves(impl == 3 ? 8 : 16);
         void * aux = t.up(nullptr, bamd_prefill_aux_bytes(type, nrows_pad, k));
         if (!aux) return fail("device alloc failed");
         bamd_launch_prefill_aux(str, type, nrows_pad, k, aux, nullptr);
         const int rc2 = bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr);
-        bamd_launch_prefill_waves(64);
+        bamd_launch_prefill_waves(16);
         if (rc2) return fail("MFMA path: unsupported type/shape");
     } else if (impl == 1) {
         if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");

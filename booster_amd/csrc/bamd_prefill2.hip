@@ -462,17 +462,19 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
 }
 
 // ==== sixteen waves ===========================================================================================================================
-// The eight-wave kernels above trade vector instructions for LDS traffic and end where the round-2 kernels were.  What the counters say about all of them
-// (profiles/r05_prefill_*): no pipe is saturated and the time follows the TOTAL number of instructions a SIMD issues — scalar, wait and no-op instructions
-// included — at roughly one per five clocks (~4 clocks each plus 16 per MFMA, next to no overlap).  So this kernel is written for instruction count:
-//   * a workgroup is SIXTEEN waves (four per SIMD): four row tiles x four token tiles, ONE 16 x 16 tile per wave (48 accumulator registers, <= 128 VGPRs);
+// The eight-wave kernels above trade vector instructions for LDS traffic and end where the round-2 kernels were (two waves per SIMD: a step is a chain of
+// dependent latencies).  This kernel — the default for Q4_K / Q5_K — puts four waves on every SIMD:
+//   * a workgroup is SIXTEEN waves: four row tiles x four token tiles, ONE 16 x 16 tile per wave (48 accumulator registers, <= 118 VGPRs);
 //     every A fragment is built once and read by four waves, every token record staged once and read by four;
-//   * staging is three full-wave DMA instructions per wave and step, the same straight-line code on every wave: sources are per-wave scalar pointers that
-//     advance by a per-wave stride (records 608 B, consumer headers 3 KiB, builder operands 4 KiB per super-block), destinations per-wave constants; no
-//     clamping at the end of K (the last copies read one super-block past the tables — allocated with that slack — into a block nobody reads again);
+//   * staging is three full-wave DMA instructions per wave and step, the same straight-line code on every wave: sources are fixed per-wave scalar pointers
+//     plus per-lane offsets that advance by a per-wave stride (records 608 B, consumer headers 3 KiB, builder operands 4 KiB per super-block), destinations
+//     per-wave constants; no clamping at the end of K (the last copies read one super-block past the tables — allocated with that slack — into a block
+//     nobody reads again); the copies follow the MFMAs of e = 0..2 instead of opening the step (all sixteen waves' copies at once queue in the vector
+//     memory path: every wave sat 500-1200 clocks in its issue stage);
 //   * the builder's scale operands travel by DMA as well, two steps ahead, into the operand slot of the block that is being read (its previous content
 //     was consumed one step earlier), so a wave's own loads are 8 bytes of nibbles per lane and step through a buffer descriptor (scalar offset);
-//   * d_y sits inside the token record; the epilogue stores 16 bytes per lane.
+//   * d_y sits inside the token record; the chain FMAs of e follow the MFMA of e + 2 (no MFMA -> VALU wait states); the epilogue stores 16 bytes per lane.
+// 112 issued instructions per wave and step (the round-2 kernel: 365 per two tiles).  What that bought and what it did not: DESIGN 4c.
 #define X3_BLK (X_BS_BYTES + X3_CHS + 4096 + 32)           /* records (38 KiB) | headers (3 KiB) | operands (4 KiB) | 32 bytes of zeros: 46 112 B */
 #define X3_BLK0 (2 * X_AF_BYTES)
 #define X3_LDS_BYTES (X3_BLK0 + 2 * X3_BLK)                /* 158 784 B */
@@ -485,10 +487,6 @@ __device__ __forceinline__ void x3_dma(const void * sbase, uint32_t voff, uint32
 }
 #ifndef X_TIMING
 #define X_TIMING 0
-#endif
-#ifndef X3_KO
-#define X3_KO 0                      /* timing-only knock-outs of the sixteen-wave kernel that keep the data VALID (stale): 1 staging copies only in the first two steps, 2 fragment build only
-                                        in the first two steps, 4 no min terms, 8 no workgroup barrier */
 #endif
 #if X_TIMING
 #define X_T(i_) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i_] += now_ - tlast; tlast = now_; } while (0)
@@ -604,24 +602,18 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e + 2 < 8) { Aq[(e + 2) % 3] = X_LDA(e + 2); Bq[(e + 2) % 3] = X_LDB(e + 2); }
-                if (!(X3_KO & 2) || ci < 2) if (e >= 4 && (e & 1) == 0) build_a(e == 4 ? raw[NXT].x : raw[NXT].y, Q5 ? qh[NXT] : 0u, (e >> 1) & 1);
+                if (e >= 4 && (e & 1) == 0) build_a(e == 4 ? raw[NXT].x : raw[NXT].y, Q5 ? qh[NXT] : 0u, (e >> 1) & 1);
                 const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
                 const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[e % 3], Bq[e % 3], z, 0, 0, 0);
-#if X3_KO & 1
-                if (ci < 2) {
-#endif
                 if (e == 0) x3_dma(p01, so0, CUR ? d0_odd : d0_even);
                 if (e == 1) x3_dma(p01, so1, (CUR ? d0_odd : d0_even) + 16384u);
                 if (e == 2) { x3_dma(p2, so2, CUR ? d2_odd : d2_even); so0 += BAMD_B16_REC; so1 += BAMD_B16_REC; so2 += st2; }
-#if X3_KO & 1
-                }
-#endif
                 if (e == 3) load_set(ci + 2, std::integral_constant<int, CUR>());
                 if (e > 1) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[e - 2][i] = fmaf(D[i], sp[e & 1][i], acc[e - 2][i]);
                 }
-                if (!(X3_KO & 2) || ci < 2) if (e >= 4 && (e & 1)) build_b(*(const uint4 *) (phl + NXT * X3_BLK + ((e >> 1) & 1) * 256), afw + NXT * X_AF_BYTES + ((e >> 1) & 1) * 256);
+                if (e >= 4 && (e & 1)) build_b(*(const uint4 *) (phl + NXT * X3_BLK + ((e >> 1) & 1) * 256), afw + NXT * X_AF_BYTES + ((e >> 1) & 1) * 256);
                 sp[e & 1] = si;
                 __builtin_amdgcn_sched_barrier(0);
                 if (e == 3) X_T(1);
@@ -632,7 +624,6 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
 #undef X_LDB
         }
         X_T(2);
-        if (X3_KO & 4) { } else
         if (Q5) {
             union { uint2 u; bamd_h4 h; } av, bv; av.u = *(const uint2 *) (cmn + CUR * X3_BLK); bv.u = *(const uint2 *) (bmn + CUR * X3_BLK);
             const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
@@ -660,7 +651,7 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
         X_T(3);
         lds_dma_wait();
         X_T(4);
-        if (!(X3_KO & 8)) __syncthreads();
+        __syncthreads();
         X_T(5);
     };
     for (int ci = 0; ci < nb; ci += 2) {
@@ -704,418 +695,11 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
     }
 }
 
-// ==== sixteen waves, 32 x 32 tiles on v_mfma_f32_32x32x16_f16 ======================================================================================
-// Valid-data knock-outs of the kernel above (X3_KO) put its time at: operand reads + MFMA + chains 59 %, fragment build 13-16 %, staging 8-10 %, min terms
-// 3-17 % — the core is the LDS operand traffic (2 KB per 16 x 16 x 32 MFMA).  Here a 32 x 32 tile belongs to a wave QUAD and the eight e are split four ways:
-// wave q multiplies e = 2q, 2q + 1 (two K-halves each, chained through the accumulator: exact integers) and the min pair l = q, on
-// v_mfma_f32_32x32x16_f16: 1 KB of operands per 32 768 FLOP instead of 2 KB per 16 384, five MFMAs per wave and step instead of twelve.  The MFMA's M side is
-// the TOKEN operand, so a lane ends up with ONE weight row x 16 tokens: d, dmin are one value each per lane, the sixteen d_y come from a contiguous copy
-// of the block scales.  The reference's hsum tree over e runs across the four waves at the end, through LDS, in its own order.
-//   fragment ring: [e][16-row tile][g][row][16 B], e 4112 B apart (the builders' eight-lane stores fall on eight bank quads), row tiles 1 KiB apart (a
-//     32-row operand read is conflict-free); token records 624 B apart in LDS (39 chunks: the 16-lane read groups of a 32-token operand need an odd number
-//     of 16-byte chunks per token; 608 serves 16-token operands only).
-typedef float bamd_f16x __attribute__((ext_vector_type(16)));
-#define X4_TS 624
-#define X4_ES 4112
-#define X4_AF_BYTES (8 * X4_ES)                            /* 32 896 B */
-#define X4_CH_OFF (64 * X4_TS)                             /* 39 KiB of records, then headers (3 KiB), builder operands (4 KiB), 64 d_y, 32 bytes of zeros */
-#define X4_PH_OFF (X4_CH_OFF + X3_CHS)
-#define X4_YD_OFF (X4_PH_OFF + 4096)
-#define X4_Z_OFF (X4_YD_OFF + 256)
-#define X4_BLK (X4_Z_OFF + 32)                             /* 47 392 B */
-#define X4_BLK0 (2 * X4_AF_BYTES)
-#define X4_LDS_BYTES (X4_BLK0 + 2 * X4_BLK)                /* 160 576 B */
-__device__ __forceinline__ void x4_dma4(const void * sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
-}
-template <int EPI, bool Q5>
-__global__ void __launch_bounds__(1024) matmul_mfma4_q4k_kernel(bamd_mma2_args a) {
-    constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int nb = a.K >> 8;
-    const int rb = blockIdx.y, t0 = blockIdx.x * 64;
-    const size_t b16 = BAMD_BLOB16_BYTES(nb);
-    const uint32_t lds0 = (uint32_t) (size_t) (bamd_lds_vp) smem;
-    // ---- stage plan: instruction k = chunks 64 k .. + 63 of [64 tokens x 39 chunks | 3 KiB of consumer headers | 4 KiB of builder operands]; wave w issues
-    //      k = w, 16 + w, 32 + w (w <= 13; waves 14, 15 repeat the operand copies 42, 43); wave 0 also copies the 64 block scales d_y
-    auto rec_off = [&](int idx) { const int tok = idx / 39, q = idx - tok * 39; const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1; return (uint32_t) ((size_t) tg * b16 + (size_t) (q < 38 ? q : 37) * 16); };
-    const int k2 = wave <= 13 ? 32 + wave : 28 + wave;
-    const bool rec2 = k2 <= 38, hdr2 = k2 >= 39 && k2 <= 41;
-    uint32_t so0 = rec_off(tid), so1 = rec_off(1024 + tid);
-    uint32_t so2 = rec2 ? rec_off(k2 * 64 + lane) : (uint32_t) (((hdr2 ? k2 - 39 : k2 - 42) * 64 + lane) * 16);
-    uint32_t soy; { const int tg = t0 + lane < a.T ? t0 + lane : a.T - 1; soy = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
-    const uint8_t * p01 = a.blob16;
-    const uint8_t * p2 = rec2 ? a.blob16 : hdr2 ? a.ch + (size_t) rb * nb * X3_CHS : a.ph + (size_t) rb * nb * 4096 + 4096;
-    const uint32_t st2 = rec2 ? (uint32_t) BAMD_B16_REC : hdr2 ? (uint32_t) X3_CHS : 4096u;
-    const uint32_t blk_a = lds0 + X4_BLK0, blk_b = blk_a + X4_BLK;
-    const uint32_t d0_even = blk_b + (uint32_t) wave * 1024u, d0_odd = blk_a + (uint32_t) wave * 1024u;
-    const uint32_t d2_even = (k2 <= 41 ? blk_b : blk_a) + (uint32_t) k2 * 1024u, d2_odd = (k2 <= 41 ? blk_a : blk_b) + (uint32_t) k2 * 1024u;
-#define X4_ADV() do { so0 += BAMD_B16_REC; so1 += BAMD_B16_REC; so2 += st2; soy += 4u; } while (0)
-    // ---- builder: as in the 16 x 16 kernel — wave (rt = wave >> 2, tt = wave & 3): record group tt & 1 of 16-row tile rt, pieces g = 2 (tt >> 1) + j
-    const int rt = wave >> 2, tt = wave & 3;
-    const int br = lane >> 3, be = lane & 7, bq = tt & 1, gh = tt >> 1;
-    const bool rt_live = (rb * 4 + rt) * 16 < a.nrows_pad;
-    const int rgq = 2 * (rt_live ? rb * 4 + rt : rb * 4) + bq;
-    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr(a.w + (size_t) rgc * nb * RECB), 0, 0x7fffffff, 0x00020000);
-    const int vraw = lane * 16 + gh * 8, vqh = 1024 + lane * 4;
-    uint2 raw; uint32_t qh = 0u;                                       // ONE set: reloaded (for the super-block after the next) right behind the second piece of a step
-    auto load_set = [&](int ci) {
-        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(wrs, vraw, ci * (int) RECB, 0); raw = make_uint2(v.x, v.y);
-        if (Q5) qh = __builtin_amdgcn_raw_buffer_load_b32(wrs, vqh, ci * (int) RECB, 0);
-    };
-    bamd_h2u c0, c1, c2, c3;
-    const uint32_t qs0 = 4u * (uint32_t) gh;
-    auto build_a = [&](uint32_t wq, uint32_t q, int j) {
-        uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;
-        if (Q5) { lo |= ((q >> (qs0 + 2 * j)) & 0x01010101u) << 4; hi |= ((q >> (qs0 + 2 * j + 1)) & 0x01010101u) << 4; }
-        c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
-        c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
-    };
-    auto build_b = [&](const uint4 & s, unsigned char * dst) {
-        bamd_h2u s0, n0, s1, n1, a0, a1, a2, a3; s0.u = s.x; n0.u = s.y; s1.u = s.z; n1.u = s.w;
-        a0.h = __builtin_elementwise_fma(c0.h, s0.h, n0.h); a1.h = __builtin_elementwise_fma(c1.h, s0.h, n0.h);
-        a2.h = __builtin_elementwise_fma(c2.h, s1.h, n1.h); a3.h = __builtin_elementwise_fma(c3.h, s1.h, n1.h);
-        *(uint4 *) dst = (uint4) { a0.u, a1.u, a2.u, a3.u };
-    };
-    unsigned char * afw = smem + be * X4_ES + rt * 1024 + ((2 * gh) * 16 + 8 * bq + br) * 16;              // this lane's pieces: fragment be, row 8 bq + br of tile rt, g = 2 gh (+ 256: 2 gh + 1)
-    const unsigned char * phl = smem + X4_BLK0 + X4_PH_OFF + rt * 1024 + (2 * gh) * 256 + (8 * bq + br) * 16;
-    // ---- consumer: quad (R = row half, C = token half), part q: e = 2q, 2q + 1 and the min pair l = q.  Lane (n = lane & 31, kg = lane >> 5)
-    const int quad = wave >> 2, R = quad >> 1, C = quad & 1, q = wave & 3;
-    const int n = lane & 31, kg = lane >> 5;
-    const int crt = 2 * R + (n >> 4), m16 = n & 15;                                                       // the weight row of this lane: row m16 of 16-row tile crt
-    const unsigned char * wop = smem + crt * 1024 + (kg * 16 + m16) * 16 + (2 * q) * X4_ES;                // weight operand of (e = 2q, K-half 0); e + 1: + X4_ES; K-half 1: + 512
-    const unsigned char * tokp = smem + X4_BLK0 + (size_t) (32 * C + n) * X4_TS;                           // token 32 C + n's record
-    const unsigned char * top = tokp + kg * 16 + (2 * q) * 64;                                             // token operand of (e = 2q, K-half 0); e + 1: + 64; K-half 1: + 32
-    const unsigned char * chp = smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + m16 * 4;                     // d of the weight row; dmin 64 bytes on
-    const unsigned char * ydp = smem + X4_BLK0 + X4_YD_OFF + (32 * C + 4 * kg) * 4;                        // d_y of tokens 32 C + 8 j + 4 kg + t: + 32 j
-    const unsigned char * wmn = Q5 ? smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + 128 + m16 * 32 + kg * 16
-                                   : (kg == 0 ? smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + 128 + m16 * 32 + q * 8 : smem + X4_BLK0 + X4_Z_OFF);
-    const unsigned char * tmn = tokp + 512 + (Q5 ? kg * 16 : q * 8);
-    bamd_f16x acc0, acc1, accm;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; accm[i] = 0.f; }
-    if (tid < 16) *(uint32_t *) (smem + X4_BLK0 + X4_Z_OFF + (tid >> 3) * X4_BLK + (tid & 7) * 4) = 0u;
-    // prologue = the staging half of a step "-1" of odd parity
-    x3_dma(p01, so0, d0_odd); x3_dma(p01, so1, d0_odd + 16384u); x3_dma(p2, so2, d2_odd);
-    if (wave == 0) x4_dma4(p01, soy, blk_a + X4_YD_OFF);
-    X4_ADV();
-    load_set(0);
-    {
-        const uint8_t * p0 = a.ph + (size_t) rb * nb * 4096 + (size_t) rt * 1024 + (size_t) ((2 * gh) * 256 + (8 * bq + br) * 16);
-        const uint4 s0 = *(const uint4 *) p0, s1 = *(const uint4 *) (p0 + 256);
-        build_a(raw.x, Q5 ? qh : 0u, 0); build_b(s0, afw);
-        build_a(raw.y, Q5 ? qh : 0u, 1); build_b(s1, afw + 256);
-    }
-    load_set(1);
-    lds_dma_wait();
-    __syncthreads();
-    auto step = [&](const int ci, auto cur_tag) {
-        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
-        // d, dmin of the lane's weight row; the sixteen d_y of its tokens
-        const float dw = *(const float *) (chp + CUR * X4_BLK), dmw = *(const float *) (chp + CUR * X4_BLK + 64);
-        bamd_f4 y4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y4[j] = *(const bamd_f4 *) (ydp + CUR * X4_BLK + j * 32);
-#define X4_LW(ee_, kh_) (*(const bamd_h8 *) (wop + CUR * X4_AF_BYTES + (ee_) * X4_ES + (kh_) * 512))
-#define X4_LT(ee_, kh_) (*(const bamd_h8 *) (top + CUR * X4_BLK + (ee_) * 64 + (kh_) * 32))
-        bamd_f16x z;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        // e = 2q: two K-halves chained through the accumulator, then its sixteen chain steps.  One result tile and one operand pair live at a time: the wave has 128
-        // registers (48 accumulators + 16 d_y), and a spilled register is a scratch load with a vmcnt wait in this loop (first version: 2 x slower)
-        bamd_h8 w0 = X4_LW(0, 0), x0 = X4_LT(0, 0);
-        bamd_f16x s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, z, 0, 0, 0);
-        w0 = X4_LW(0, 1); x0 = X4_LT(0, 1);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, s, 0, 0, 0);
-        x3_dma(p01, so0, CUR ? d0_odd : d0_even);
-        build_a(raw.x, Q5 ? qh : 0u, 0);
-        build_b(*(const uint4 *) (phl + NXT * X4_BLK), afw + NXT * X4_AF_BYTES);
-        w0 = X4_LW(1, 0); x0 = X4_LT(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float D = y4[i >> 2][i & 3] * dw; acc0[i] = fmaf(D, s[i], acc0[i]); }
-        __builtin_amdgcn_sched_barrier(0);
-        // e = 2q + 1
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, z, 0, 0, 0);
-        w0 = X4_LW(1, 1); x0 = X4_LT(1, 1);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, s, 0, 0, 0);
-        x3_dma(p01, so1, (CUR ? d0_odd : d0_even) + 16384u);
-        build_a(raw.y, Q5 ? qh : 0u, 1);
-        build_b(*(const uint4 *) (phl + NXT * X4_BLK + 256), afw + NXT * X4_AF_BYTES + 256);
-        load_set(ci + 2);                                              // (both pieces of the next super-block are built: the one register set is free again)
-        // min terms: the exact integer products of pair l = q (Q5_K: of all eight sub-blocks, wave q = 0 only) on one more MFMA (K slots beyond the pair are zeros)
-#ifdef X4_NOMIN
-        const bool has_min = false;
-#else
-        const bool has_min = !Q5 || q == 0;
-#endif
-        if (has_min) {
-            if (Q5) { w0 = *(const bamd_h8 *) (wmn + CUR * X4_BLK); x0 = *(const bamd_h8 *) (tmn + CUR * X4_BLK); }
-            else {
-                union { uint2 u; bamd_h4 h; } a2, b2; a2.u = *(const uint2 *) (wmn + CUR * X4_BLK); b2.u = *(const uint2 *) (tmn + CUR * X4_BLK);
-                w0 = (bamd_h8) { a2.h[0], a2.h[1], a2.h[2], a2.h[3], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-                x0 = (bamd_h8) { b2.h[0], b2.h[1], b2.h[2], b2.h[3], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float D = y4[i >> 2][i & 3] * dw; acc1[i] = fmaf(D, s[i], acc1[i]); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_min) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, z, 0, 0, 0);
-        x3_dma(p2, so2, CUR ? d2_odd : d2_even);
-        if (wave == 0) x4_dma4(p01, soy, (CUR ? blk_a : blk_b) + X4_YD_OFF);
-        X4_ADV();
-        if (has_min) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float Dm = (-y4[i >> 2][i & 3]) * dmw;
-                if (Q5) { const float t = Dm * s[i]; accm[i] = accm[i] + t; } else accm[i] = fmaf(Dm, s[i], accm[i]);
-            }
-        }
-#undef X4_LW
-#undef X4_LT
-        lds_dma_wait();
-        __syncthreads();
-    };
-    for (int ci = 0; ci < nb; ci += 2) {
-        step(ci, std::integral_constant<int, 0>());
-        if (ci + 1 < nb) step(ci + 1, std::integral_constant<int, 1>());
-    }
-#undef X4_ADV
-    // ---- hsum_float_8 over e across the quad, in the reference's order: ((a0 + a4) + (a2 + a6)) + ((a1 + a5) + (a3 + a7)), mm = (m0 + m2) + (m1 + m3); wave q holds
-    //      a_2q, a_2q+1, m_q.  Waves 2, 3 hand theirs to waves 0, 1; wave 1 hands its partial sums to wave 0, which finishes and stores.
-    float * xs = (float *) smem;                                   // (everything in LDS is dead behind the last barrier) slot (quad, s): 48 x 64 floats
-    if (q >= 2) {
-        float * o = xs + (size_t) (quad * 2 + (q - 2)) * 3072 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[i * 64] = acc0[i]; o[(16 + i) * 64] = acc1[i]; o[(32 + i) * 64] = accm[i]; }
-    }
-    __syncthreads();
-    bamd_f16x t0v, t1v, mv;
-    if (q < 2) {
-        const float * o = xs + (size_t) (quad * 2 + q) * 3072 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { t0v[i] = acc0[i] + o[i * 64]; t1v[i] = acc1[i] + o[(16 + i) * 64]; mv[i] = Q5 ? accm[i] : accm[i] + o[(32 + i) * 64]; }
-    }
-    __syncthreads();
-    if (q == 1) {
-        float * o = xs + (size_t) (quad * 2) * 3072 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[i * 64] = t0v[i]; o[(16 + i) * 64] = t1v[i]; o[(32 + i) * 64] = mv[i]; }
-    }
-    __syncthreads();
-    if (q != 0) return;
-    const int row = rb * 64 + 32 * R + n;
-    if (row >= a.nrows) return;
-    const float * o = xs + (size_t) (quad * 2) * 3072 + lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float v = (t0v[i] + o[i * 64]) + (t1v[i] + o[(16 + i) * 64]);
-        const float mm = Q5 ? mv[i] : mv[i] + o[(32 + i) * 64];
-        const float val = v + mm;
-        const int t = t0 + 32 * C + 8 * (i >> 2) + 4 * kg + (i & 3);
-        if (t < a.T) {
-            const size_t oo = (size_t) t * a.ldo + row;
-            a.out[oo] = EPI == BAMD_EPI_ADD ? val + a.res[oo] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[oo]) * val : val;
-        }
-    }
-}
-
-// ==== eight waves, 32 x 32 tiles: a wave PAIR per tile ===================================================================================================
-// The quad kernel above needs 48 accumulators + 16 d_y + a 16-register result tile + operands + the builder's state in the 128 registers a wave has at four
-// waves per SIMD: it spills (13 dwords; a scratch reload is a vector-memory load with a wait in the loop: 2 x slower than the 16 x 16 kernel).  Same tile,
-// same operand traffic, two waves per SIMD: wave q of a pair multiplies e = 4q .. 4q + 3 and the min pairs l = 2q, 2q + 1 (96 accumulators, no spill), the
-// builders take a whole record group each (four pieces per lane, one coalesced 16-byte load), six staging copies per wave and step.
-template <int EPI, bool Q5>
-__global__ void __launch_bounds__(512) matmul_mfma5_q4k_kernel(bamd_mma2_args a) {
-    constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-    const int nb = a.K >> 8;
-    const int rb = blockIdx.y, t0 = blockIdx.x * 64;
-    const size_t b16 = BAMD_BLOB16_BYTES(nb);
-    const uint32_t lds0 = (uint32_t) (size_t) (bamd_lds_vp) smem;
-    // ---- stage plan (block layout of the quad kernel): instruction k = w + 8 r, r = 0..5; k <= 38 records, 39..41 consumer headers, 42..45 builder operands
-    //      (waves 6, 7 repeat 44, 45 in the last round); wave 0 also copies the 64 block scales d_y
-    auto rec_off = [&](int idx) { const int tok = idx / 39, q = idx - tok * 39; const int tg = t0 + tok < a.T ? t0 + tok : a.T - 1; return (uint32_t) ((size_t) tg * b16 + (size_t) (q < 38 ? q : 37) * 16); };
-    uint32_t so[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) so[r] = rec_off(r * 512 + tid);
-    const int k4 = 32 + wave, k5 = wave <= 5 ? 40 + wave : 38 + wave;
-    uint32_t so4 = k4 <= 38 ? rec_off(k4 * 64 + lane) : (uint32_t) (((k4 - 39) * 64 + lane) * 16);
-    uint32_t so5 = (uint32_t) (((k5 <= 41 ? k5 - 39 : k5 - 42) * 64 + lane) * 16);
-    uint32_t soy; { const int tg = t0 + lane < a.T ? t0 + lane : a.T - 1; soy = (uint32_t) ((size_t) tg * b16 + (size_t) nb * BAMD_B16_REC); }
-    const uint8_t * p01 = a.blob16;
-    const uint8_t * chs = a.ch + (size_t) rb * nb * X3_CHS, * phs = a.ph + (size_t) rb * nb * 4096 + 4096;
-    const uint8_t * p4 = k4 <= 38 ? a.blob16 : chs, * p5 = k5 <= 41 ? chs : phs;
-    const uint32_t st4 = k4 <= 38 ? (uint32_t) BAMD_B16_REC : (uint32_t) X3_CHS, st5 = k5 <= 41 ? (uint32_t) X3_CHS : 4096u;
-    const uint32_t blk_a = lds0 + X4_BLK0, blk_b = blk_a + X4_BLK;
-    // destinations by the parity of the step that issues the copies: everything for ci + 1 into the OTHER block, the builder operands of ci + 2 into the block in use
-#define X5_STAGE(PAR) do { const uint32_t bn_ = (PAR) ? blk_a : blk_b, bc_ = (PAR) ? blk_b : blk_a; \
-        x3_dma(p01, so[0], bn_ + (uint32_t) wave * 1024u); x3_dma(p01, so[1], bn_ + (uint32_t) (8 + wave) * 1024u); \
-        x3_dma(p01, so[2], bn_ + (uint32_t) (16 + wave) * 1024u); x3_dma(p01, so[3], bn_ + (uint32_t) (24 + wave) * 1024u); \
-        x3_dma(p4, so4, bn_ + (uint32_t) k4 * 1024u); x3_dma(p5, so5, (k5 <= 41 ? bn_ : bc_) + (uint32_t) k5 * 1024u); \
-        if (wave == 0) x4_dma4(p01, soy, bn_ + X4_YD_OFF); \
-        so[0] += BAMD_B16_REC; so[1] += BAMD_B16_REC; so[2] += BAMD_B16_REC; so[3] += BAMD_B16_REC; so4 += st4; so5 += st5; soy += 4u; } while (0)
-    // ---- builder: wave (rt = wave >> 1, bq = wave & 1) = record group bq of 16-row tile rt; lane (r, e): the 16 bytes of (row 8 bq + r, chunk e) = four pieces
-    const int rt = wave >> 1, bq = wave & 1;
-    const int br = lane >> 3, be = lane & 7;
-    const bool rt_live = (rb * 4 + rt) * 16 < a.nrows_pad;
-    const int rgq = 2 * (rt_live ? rb * 4 + rt : rb * 4) + bq;
-    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr(a.w + (size_t) rgc * nb * RECB), 0, 0x7fffffff, 0x00020000);
-    const int vraw = lane * 16, vqh = 1024 + lane * 4;
-    uint4 raw[2]; uint32_t qh[2] = { 0u, 0u };
-    auto load_set = [&](int ci, auto set_tag) {
-        constexpr int S = decltype(set_tag)::value;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, vraw, ci * (int) RECB, 0); raw[S] = make_uint4(v.x, v.y, v.z, v.w);
-        if (Q5) qh[S] = __builtin_amdgcn_raw_buffer_load_b32(wrs, vqh, ci * (int) RECB, 0);
-    };
-    auto rawg = [&](const uint4 & v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; };
-    auto build = [&](uint32_t wq, uint32_t q, int g, const uint4 & sc, unsigned char * dst) {
-        uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;
-        if (Q5) { lo |= ((q >> (2 * g)) & 0x01010101u) << 4; hi |= ((q >> (2 * g + 1)) & 0x01010101u) << 4; }
-        bamd_h2u c0, c1, c2, c3, s0, n0, s1, n1, a0, a1, a2, a3; s0.u = sc.x; n0.u = sc.y; s1.u = sc.z; n1.u = sc.w;
-        c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
-        c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
-        a0.h = __builtin_elementwise_fma(c0.h, s0.h, n0.h); a1.h = __builtin_elementwise_fma(c1.h, s0.h, n0.h);
-        a2.h = __builtin_elementwise_fma(c2.h, s1.h, n1.h); a3.h = __builtin_elementwise_fma(c3.h, s1.h, n1.h);
-        *(uint4 *) dst = (uint4) { a0.u, a1.u, a2.u, a3.u };
-    };
-    unsigned char * afw = smem + be * X4_ES + rt * 1024 + (8 * bq + br) * 16;                              // piece g at + 256 g
-    const unsigned char * phl = smem + X4_BLK0 + X4_PH_OFF + rt * 1024 + (8 * bq + br) * 16;              // its operands at + 256 g
-    // ---- consumer: pair (R = row half, C = token half) of the 32 x 32 tile, part q: e = 4q .. 4q + 3, min pairs l = 2q, 2q + 1.  Lane (n = lane & 31, kg = lane >> 5)
-    const int duo = wave >> 1, R = duo >> 1, C = duo & 1, q = wave & 1;
-    const int n = lane & 31, kg = lane >> 5;
-    const int crt = 2 * R + (n >> 4), m16 = n & 15;
-    const unsigned char * wop = smem + crt * 1024 + (kg * 16 + m16) * 16 + (4 * q) * X4_ES;
-    const unsigned char * tokp = smem + X4_BLK0 + (size_t) (32 * C + n) * X4_TS;
-    const unsigned char * top = tokp + kg * 16 + (4 * q) * 64;
-    const unsigned char * chp = smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + m16 * 4;
-    const unsigned char * ydp = smem + X4_BLK0 + X4_YD_OFF + (32 * C + 4 * kg) * 4;
-    const unsigned char * wmn = Q5 ? smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + 128 + m16 * 32 + kg * 16
-                                   : (kg == 0 ? smem + X4_BLK0 + X4_CH_OFF + crt * X_CH4_RT + 128 + m16 * 32 + (2 * q) * 8 : smem + X4_BLK0 + X4_Z_OFF);
-    const unsigned char * tmn = tokp + 512 + (Q5 ? kg * 16 : (2 * q) * 8);
-    bamd_f16x acc[4], accm[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; acc[2][i] = 0.f; acc[3][i] = 0.f; accm[0][i] = 0.f; accm[1][i] = 0.f; }
-    if (tid < 16) *(uint32_t *) (smem + X4_BLK0 + X4_Z_OFF + (tid >> 3) * X4_BLK + (tid & 7) * 4) = 0u;
-    X5_STAGE(1);                                                 // records / headers / d_y of super-block 0 into block a, builder operands of super-block 1 into block b
-    load_set(0, std::integral_constant<int, 0>());
-    load_set(1, std::integral_constant<int, 1>());
-    {
-        const uint8_t * p0 = a.ph + (size_t) rb * nb * 4096 + (size_t) rt * 1024 + (size_t) (8 * bq + br) * 16;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) build(rawg(raw[0], g), qh[0], g, *(const uint4 *) (p0 + g * 256), afw + g * 256);
-    }
-    lds_dma_wait();
-    __syncthreads();
-    auto step = [&](const int ci, auto cur_tag) {
-        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
-        X5_STAGE(CUR);
-        load_set(ci + 2, std::integral_constant<int, CUR>());
-        __builtin_amdgcn_sched_barrier(0);
-        const float dw = *(const float *) (chp + CUR * X4_BLK), dmw = *(const float *) (chp + CUR * X4_BLK + 64);
-        float D[16], Dm[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bamd_f4 y = *(const bamd_f4 *) (ydp + CUR * X4_BLK + j * 32);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { D[4 * j + t] = y[t] * dw; Dm[4 * j + t] = (-y[t]) * dmw; }
-        }
-#define X5_LW(ee_, kh_) (*(const bamd_h8 *) (wop + CUR * X4_AF_BYTES + (ee_) * X4_ES + (kh_) * 512))
-#define X5_LT(ee_, kh_) (*(const bamd_h8 *) (top + CUR * X4_BLK + (ee_) * 64 + (kh_) * 32))
-        bamd_f16x z;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        bamd_f16x sp;
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const bamd_h8 w0 = X5_LW(ee, 0), x0 = X5_LT(ee, 0), w1 = X5_LW(ee, 1), x1 = X5_LT(ee, 1);
-            bamd_f16x s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, w0, z, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, w1, s, 0, 0, 0);                            // the second K-half chained through the accumulator: exact integers
-            build(rawg(raw[NXT], ee), qh[NXT], ee, *(const uint4 *) (phl + NXT * X4_BLK + ee * 256), afw + NXT * X4_AF_BYTES + ee * 256);
-            if (ee > 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ee - 1][i] = fmaf(D[i], sp[i], acc[ee - 1][i]);
-            }
-            sp = s;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // min terms (Q4_K: pairs l = 2q, 2q + 1; Q5_K: all eight sub-blocks in one MFMA, wave q = 0 only): K slots beyond the pair are zeros
-        bamd_f16x pm0, pm1;
-        const bool has_min = !Q5 || q == 0;
-        if (has_min) {
-            if (Q5) {
-                const bamd_h8 wv = *(const bamd_h8 *) (wmn + CUR * X4_BLK), tv = *(const bamd_h8 *) (tmn + CUR * X4_BLK);
-                pm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tv, wv, z, 0, 0, 0);
-            } else {
-                union { uint4 u; bamd_h8 h; } a2, b2; a2.u = *(const uint4 *) (wmn + CUR * X4_BLK); b2.u = *(const uint4 *) (tmn + CUR * X4_BLK);     // {l = 2q | l = 2q + 1}
-                const bamd_h8 wv0 = { a2.h[0], a2.h[1], a2.h[2], a2.h[3], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-                const bamd_h8 tv0 = { b2.h[0], b2.h[1], b2.h[2], b2.h[3], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-                const bamd_h8 wv1 = { a2.h[4], a2.h[5], a2.h[6], a2.h[7], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-                const bamd_h8 tv1 = { b2.h[4], b2.h[5], b2.h[6], b2.h[7], (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f, (_Float16) 0.f };
-                pm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tv0, wv0, z, 0, 0, 0);
-                pm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tv1, wv1, z, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[3][i] = fmaf(D[i], sp[i], acc[3][i]);
-        if (has_min) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (Q5) { const float t = Dm[i] * pm0[i]; accm[0][i] = accm[0][i] + t; }
-                else { accm[0][i] = fmaf(Dm[i], pm0[i], accm[0][i]); accm[1][i] = fmaf(Dm[i], pm1[i], accm[1][i]); }
-            }
-        }
-#undef X5_LW
-#undef X5_LT
-        lds_dma_wait();
-        __syncthreads();
-    };
-    for (int ci = 0; ci < nb; ci += 2) {
-        step(ci, std::integral_constant<int, 0>());
-        if (ci + 1 < nb) step(ci + 1, std::integral_constant<int, 1>());
-    }
-#undef X5_STAGE
-    // ---- hsum_float_8 over e across the pair, in the reference's order: t_k = a_k + a_k+4 (k = 0..3), ((t0 + t2) + (t1 + t3)); mm = (m0 + m2) + (m1 + m3); wave 1 hands
-    //      a4..a7, m2, m3 to wave 0 through LDS (everything in LDS is dead behind the last barrier): slot duo = 96 x 64 floats
-    float * xs = (float *) smem + (size_t) duo * 6144 + lane;
-    if (q == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xs[(16 * k + i) * 64] = acc[k][i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { xs[(64 + i) * 64] = accm[0][i]; xs[(80 + i) * 64] = accm[1][i]; }
-    }
-    __syncthreads();
-    if (q != 0) return;
-    const int row = rb * 64 + 32 * R + n;
-    if (row >= a.nrows) return;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float u0 = acc[0][i] + xs[i * 64], u1 = acc[1][i] + xs[(16 + i) * 64], u2 = acc[2][i] + xs[(32 + i) * 64], u3 = acc[3][i] + xs[(48 + i) * 64];
-        const float v = (u0 + u2) + (u1 + u3);
-        const float mm = Q5 ? accm[0][i] : (accm[0][i] + xs[(64 + i) * 64]) + (accm[1][i] + xs[(80 + i) * 64]);
-        const float val = v + mm;
-        const int t = t0 + 32 * C + 8 * (i >> 2) + 4 * kg + (i & 3);
-        if (t < a.T) {
-            const size_t oo = (size_t) t * a.ldo + row;
-            a.out[oo] = EPI == BAMD_EPI_ADD ? val + a.res[oo] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[oo]) * val : val;
-        }
-    }
-}
-
 // ---- host side -----------------------------------------------------------------------------------------------------------------------------
 static inline int x_row_blocks(int nrows_pad) { return (nrows_pad + 63) / 64; }
 // Q4_K / Q5_K: the sixteen-wave kernel (default) or the eight-wave one (BAMD_PREFILL_WAVES=8, bamd_launch_prefill_waves: the tests run both)
-// layout: 8 = eight waves (16 x 32 per wave), 16 = sixteen waves (16 x 16 per wave), 32 = sixteen waves on 32 x 32 tiles (four waves per tile)
-//         64 = eight waves on 32 x 32 tiles (a wave pair per tile)
-static int g_prefill_waves16 = [] { const char * e = getenv("BAMD_PREFILL_WAVES"); return !e ? 64 : e[0] == '8' ? 8 : e[0] == '3' ? 32 : e[0] == '6' ? 64 : 16; }();
-void bamd_launch_prefill_waves(int waves) { g_prefill_waves16 = waves == 8 ? 8 : waves == 16 ? 16 : waves == 32 ? 32 : 64; }
+static int g_prefill_waves16 = [] { const char * e = getenv("BAMD_PREFILL_WAVES"); return (e && e[0] == '8') ? 0 : 1; }();
+void bamd_launch_prefill_waves(int waves) { g_prefill_waves16 = waves == 8 ? 0 : 1; }
 static unsigned long long * g_prefill_dbg = nullptr;      // -DX_TIMING builds: where the kernels of the next launches leave their phase clocks (bamd_prefill_dbg)
 extern "C" __attribute__((visibility("default"))) void bamd_prefill_dbg(void * dev_buf) { g_prefill_dbg = (unsigned long long *) dev_buf; }
 // bytes of the side table of a K-quant matrix [nrows_pad][K]: builder part first, the consumer part behind it (both 16-byte aligned)
@@ -1152,21 +736,9 @@ int bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, 
         if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(1024), X3_LDS_BYTES, s, a); \
         else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(1024), X3_LDS_BYTES, s, a); \
         else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(1024), X3_LDS_BYTES, s, a); } while (0)
-#define X4_LAUNCH(KERNEL, ...) do { \
-        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(1024), X4_LDS_BYTES, s, a); \
-        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(1024), X4_LDS_BYTES, s, a); \
-        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(1024), X4_LDS_BYTES, s, a); } while (0)
-#define X5_LAUNCH(KERNEL, ...) do { \
-        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(512), X4_LDS_BYTES, s, a); \
-        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(512), X4_LDS_BYTES, s, a); \
-        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(512), X4_LDS_BYTES, s, a); } while (0)
     if (type == BAMD_Q6_K)      X_LAUNCH(matmul_mfma2_q6k_kernel);
-    else if (type == BAMD_Q5_K && waves16 == 64) X5_LAUNCH(matmul_mfma5_q4k_kernel, , true);
-    else if (type != BAMD_Q5_K && waves16 == 64) X5_LAUNCH(matmul_mfma5_q4k_kernel, , false);
-    else if (type == BAMD_Q5_K) { if (waves16 == 32) X4_LAUNCH(matmul_mfma4_q4k_kernel, , true); else if (waves16 == 16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , true); else X_LAUNCH(matmul_mfma2_q4k_kernel, , true); }
-    else                        { if (waves16 == 32) X4_LAUNCH(matmul_mfma4_q4k_kernel, , false); else if (waves16 == 16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , false); else X_LAUNCH(matmul_mfma2_q4k_kernel, , false); }
-#undef X4_LAUNCH
-#undef X5_LAUNCH
+    else if (type == BAMD_Q5_K) { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , true); else X_LAUNCH(matmul_mfma2_q4k_kernel, , true); }
+    else                        { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , false); else X_LAUNCH(matmul_mfma2_q4k_kernel, , false); }
 #undef X3_LAUNCH
 #undef X_LAUNCH
     return 0;

@@ -198,12 +198,10 @@ def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
                                                (13, 1024, 64, 16, 2), (13, 2048, 40, 21, 2), (13, 4096, 528, 37, 2), (13, 8192, 48, 33, 2), (13, 768, 24, 65, 2),
                                                (14, 1024, 64, 16, 2), (14, 2048, 40, 21, 2), (14, 4096, 528, 37, 2), (14, 14336, 32, 33, 2), (14, 2816, 24, 17, 2),
                                                (14, 256, 16, 3, 2), (14, 4096, 200, 129, 2),
-                                               # impl 4: the round-5 sixteen-wave layout with one 16 x 16 tile per wave
-                                               (12, 1024, 64, 16, 4), (12, 4096, 528, 37, 4), (12, 11008, 32, 16, 4), (12, 4096, 200, 129, 4), (13, 2048, 40, 21, 4), (13, 768, 24, 65, 4),
                                                # impl 3: the round-5 kernel's eight-wave Q4_K / Q5_K layout
                                                (12, 1024, 64, 16, 3), (12, 4096, 528, 37, 3), (12, 11008, 32, 16, 3), (12, 4096, 200, 129, 3), (13, 2048, 40, 21, 3), (13, 768, 24, 65, 3)])
 def test_mul_mat_batch(bamd, po, t, K, rows, T, impl):
-    """batched prefill mat-mul (impl 0: integer-dot kernel, 1: round-2 MFMA kernel, 2: round-5 MFMA kernel (32 x 32 tiles per wave quad), 3: its eight-wave layout, 4: sixteen waves of 16 x 16) == the reference's mul_mat per activation row, bit for bit;
+    """batched prefill mat-mul (impl 0: integer-dot kernel, 1: round-2 MFMA kernel, 2: round-5 MFMA kernel, 3: its eight-wave layout) == the reference's mul_mat per activation row, bit for bit;
     ragged token tiles, rows % 16 != 0, residual epilogue, K with an odd number of super-blocks (Llama-2's 11008)"""
     rng = np.random.default_rng(77 * t + K + T)
     W = random_kquant_tensor(t, K, rows, rng)
