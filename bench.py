@@ -254,12 +254,16 @@ def main():
                      "gate_up": "matvec_fast_kernel<Q4_K, RMSNorm prologue, silu(gate)*up epilogue> (ffn_gate + ffn_up)", "ffn_down": "matvec_split_fast_kernel (ffn_down, +residual)",
                      "lm_head": "matvec_fast_kernel<Q6_K, arg-max epilogue> (output)", "attention": "attn_fused_kernel",
                      "attention+wo": "attn_wo_kernel (single-launch attention on H CUs, wo + residual on the others)"}
-        LK, MSK, BK = np.zeros(7), np.zeros(7), np.zeros(7)
+        # eight eager steps; per launch kind the MEDIAN step's time (one eager step that catches a clock ramp or a neighbour's burst would otherwise move a kind's
+        # share by 10-15 %: the round-5 profile run read gate/up at 15.5 us once against 13.5-13.7 in every other run)
         ev_over = []
-        reps = 4
+        reps = 8
+        per_rep = []
         for i in range(reps):
             l, ms, b = ctx.profile_step_kinds(n_past - 1)
-            LK += l[:7]; MSK += ms[:7]; BK += b[:7]; ev_over.append(ms[7])
+            per_rep.append((np.array(l[:7], float), np.array(ms[:7], float), np.array(b[:7], float))); ev_over.append(ms[7])
+        LK = per_rep[0][0] * reps; BK = per_rep[0][2] * reps                   # launches and bytes per kind are the same in every step
+        MSK = np.median(np.stack([r[1] for r in per_rep]), axis=0) * reps
         mv = [0, 3, 4, 5, 6]                                             # the mat-vec launches; 1 = attention, 2 = other
         L_ = np.array([LK[mv].sum(), LK[1], LK[2]]); MS_ = np.array([MSK[mv].sum(), MSK[1], MSK[2]]); B_ = np.array([BK[mv].sum(), BK[1], BK[2]])
         ev_empty_ms = float(np.median(ev_over))                          # what an EMPTY event pair reads on the same stream

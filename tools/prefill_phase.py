@@ -20,8 +20,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(16, 8)
 nb = max(int(d[0, 6]), 1)
-names = ["stage+loads", "e0-3", "e4-7", "min", "vmcnt(0)", "barrier"]
-print("clock ticks (s_memtime: 100 MHz constant clock x ? — compare columns) per step, K=%d rows=%d T=%d, nb=%d" % (K, rows, T, nb))
+names = ["d products", "e0-3+staging", "e4-7+build", "min terms", "vmcnt(0)", "barrier"]
+print("shader clocks (s_memtime) per super-block step and wave, by phase (each stamp itself costs a scalar memory round trip: compare columns and waves, not absolutes); K=%d rows=%d T=%d, nb=%d" % (K, rows, T, nb))
 print("wave " + " ".join("%12s" % n for n in names) + "        total")
 for w in range(16):
     print("%4d " % w + " ".join("%12.1f" % (d[w, i] / nb) for i in range(6)) + " %12.1f" % (d[w, :6].sum() / nb))
