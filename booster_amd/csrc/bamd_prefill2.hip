@@ -481,10 +481,8 @@ __global__ void __launch_bounds__(512) matmul_mfma2_q6k_kernel(bamd_mma2_args a)
 #define X3_CH_OFF X_BS_BYTES
 #define X3_PH_OFF (X_BS_BYTES + X3_CHS)
 #define X3_Z_OFF (X3_PH_OFF + 4096)
-// one DMA instruction: m0 <- LDS destination, 1 KiB from (scalar base + per-lane offset)
-__device__ __forceinline__ void x3_dma(const void * sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
-}
+// one DMA instruction: 1 KiB from (scalar base + per-lane offset) to the LDS address lds_dst (m0 is saved and restored around it: the compiler reserves the register)
+__device__ __forceinline__ void x3_dma(const void * sbase, uint32_t voff, uint32_t lds_dst) { lds_dma16_s(sbase, voff, lds_dst); }
 #ifndef X_TIMING
 #define X_TIMING 0
 #endif
