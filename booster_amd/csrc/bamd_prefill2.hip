@@ -5,20 +5,20 @@
 // v_mfma_f32_16x16x32_f16 per SIMD lane e of the reference gives the exact integer sums isum_e of a 16-row x 16-token tile, the f32 chains
 // acc_e = fma(d_x d_y, isum_e, acc_e), the min terms and the final hsum tree follow on the VALU in the reference's order.
 //
-// What changed, and why: in bamd_prefill.hip every wave expands the nibbles of ITS 16 rows into f16 scale x quant
-// fragments and uses each fragment for two MFMAs — 365 issued instructions per wave and super-block of which ~150 are that expansion and
-// the header unpacking in front of it, so the kernel is bound by what one wave must issue (MFMA pipe 19 % busy, VALU 50 %).  Here
-//   * a workgroup is 64 rows x 64 tokens: eight waves = four row tiles x two token pairs (each wave still 16 rows x 32 tokens: 96
-//     accumulator registers, two MFMAs per A operand held in registers);
-//   * the two waves of a row tile build its eight fragments ONCE, half each, one super-block AHEAD, into an LDS ring in MFMA operand
-//     layout (ds_write_b128, read back by both with ds_read_b128: 1 KiB per two MFMAs), from the raw nibble dwords (4 B per lane and
-//     fragment, straight from the wave-stream records: lane (m, g) of fragment e wants dword g of stream lane (m & 7, e)) — the build of
-//     super-block ci + 1 is independent of the MFMAs of ci, so it is interleaved with them, half a fragment per e;
-//   * everything the header unpacking produced per step is PRECOMPUTED AT LOAD TIME into a per-matrix side table ("prefill aux", 104 B per
-//     row and super-block for Q4_K / Q5_K, 72 B for Q6_K: the MI355X has the HBM for it): the builder's per-lane scale operands
-//     {s, -1024 s, s/16, -64 s} as packed f16 pairs (one 16-byte load per lane and step), and the consumers' {d, dmin} as f32 plus the
-//     min-term MFMA operands {2 m_a, 2 m_b, m_a, m_b}, which travel global -> LDS by DMA with the activation records.
-// Per wave and super-block: ~215 issued instructions instead of 365, same 24 MFMAs, same bits.
+// What changed against bamd_prefill.hip, and why: there every wave expands the nibbles of ITS 16 rows into f16 scale x quant
+// fragments and uses each fragment for two MFMAs — 365 issued instructions per wave and super-block, ~150 of them that expansion and the header
+// unpacking in front of it.  Here
+//   * a workgroup is 64 rows x 64 tokens and every fragment is built ONCE per workgroup, one super-block AHEAD, into an LDS ring in MFMA operand layout
+//     (ds_write_b128, read back with ds_read_b128), by builders that work in the wave-stream's own lane order (lane (r, e) of a record group holds the
+//     halves of MFMA lanes (row, g = 0..3) of fragment e: one coalesced request per wave); the build of super-block ci + 1 is independent of the MFMAs of
+//     ci and interleaved with them;
+//   * everything the header unpacking produced per step is PRECOMPUTED AT LOAD TIME into a per-matrix side table ("prefill aux", 104 B per row and
+//     super-block for Q4_K / Q5_K, 72 B for Q6_K: the MI355X has the HBM for it): the builders' per-(row, sub-block pair) scale operands
+//     {s, -1024 s, s'/16, -64 s'} as packed f16 pairs, and the consumers' d, dmin as f32 plus the min-term MFMA operands {2 m_a, 2 m_b, m_a, m_b}, which
+//     travel global -> LDS by DMA with the activation records;
+//   * three layouts: sixteen waves with one 16 x 16 tile each (matmul_mfma3_q4k_kernel, the default for Q4_K / Q5_K), eight waves with 16 x 32 each
+//     (matmul_mfma2_q4k_kernel, BAMD_PREFILL_WAVES=8; matmul_mfma2_q6k_kernel for Q6_K).
+// Same bits as bamd_prefill.hip, a third fewer vector instructions per MFMA — and the same time: DESIGN 4c has the measurements of what bounds it.
 #include "bamd_device.h"
 #include "bamd_mfma_common.h"
 #include <type_traits>
