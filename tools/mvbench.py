@@ -1,6 +1,6 @@
 """Micro-benchmark of mat-vec launch shapes, back to back on one matrix (GPU box only).
 
-    python tools/mvbench.py [8b | modea | ceiling | l2-7b | l32]
+    python tools/mvbench.py [8b | 70b | modea | ceiling | l2-7b | l32]
 
 8b (default): the launch shapes of Llama-3-8B Q4_K_M, both launch modes where both exist, and prologue-only launches; modea: the mode-A
 kernels only (a quick A/B target for kernel edits); ceiling: streaming rate by matrix size, Infinity-Cache-resident (75 MB) up to HBM-bound
@@ -22,6 +22,9 @@ SETS = {
     "ceiling": [("q4k 32768x4096 (75MB, MALL-resident)", 12, 32768, 4096, 0, 0, (1,)), ("q4k 65536x4096 (151MB)", 12, 65536, 4096, 0, 0, (1,)),
                 ("q4k 262144x4096 (604MB)", 12, 262144, 4096, 0, 0, (1,)), ("q6k 32768x4096 (110MB)", 14, 32768, 4096, 0, 0, (1,)),
                 ("q6k 262144x4096 (881MB)", 14, 262144, 4096, 0, 0, (1,))],
+    "70b": [("qkv q4k (one type)", 12, 10240, 8192, 1, 0, (1, 2)), ("wo q4k", 12, 8192, 8192, 0, 1, (1, 2)), ("gate/up q4k", 12, 28672, 8192, 1, 2, (1,)),
+            ("down q4k", 12, 8192, 28672, 0, 1, (1, 2)), ("down q6k", 14, 8192, 28672, 0, 1, (1, 2)), ("prologue-only K28672", 12, 8, 28672, 0, 0, (1,)),
+            ("prologue-only norm K8192", 12, 8, 8192, 1, 0, (1,))],
     "l2-7b": [("qkv", 12, 12288, 4096, 1, 0, (0,)), ("wo", 12, 4096, 4096, 0, 1, (0,)), ("gate/up", 12, 11008, 4096, 1, 2, (0,)), ("down q4k", 12, 4096, 11008, 0, 1, (0,)),
               ("down q6k", 14, 4096, 11008, 0, 1, (0,)), ("lm_head", 14, 32000, 4096, 1, 3, (0,))],
     "l32": [("3B qkv", 12, 5120, 3072, 1, 0, (0,)), ("3B wo", 12, 3072, 3072, 0, 1, (0,)), ("3B gate/up", 12, 8192, 3072, 1, 2, (0,)), ("3B down q4k", 12, 3072, 8192, 0, 1, (0,)),
