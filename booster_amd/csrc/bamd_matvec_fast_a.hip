@@ -89,113 +89,6 @@ __global__ void __launch_bounds__(512) matvec_gateup7_kernel(BAMD_LEAD_PARAMS, b
     else stream_pair_short<TYPE, REC, NBP, true>(wG, wU, b + grid * 4, grid, 0, a.seg[0].out, pa, ap, park, flags, nv);
     TL_STAMP(a.tl, 7);
 }
-// ---- K = 28672 (Llama-3-70B's n_ff: 112 super-blocks per row), 8 x CUs x 4 rows: ffn_down at the 70B widths -----------------------------------
-// One wave per row-group (mode A) leaves four of a CU's eight waves without a row-group, and a wave that walks 112 records alone is paced by its own
-// issue rate, not by the bytes: 22 us for ONE row-group on an idle chip (tools/mvbench.py 70b, "prologue-only K28672"), 29 / 37 us for the Q4_K / Q6_K
-// launch where the bytes need 20 / 30.  Split-K over sixteen waves with the chain behind a barrier (one 112 KB term buffer, two barriers per row-group)
-// measured slower still (35.1 vs 32.7 us per launch in the model).  Here every row-group has a wave PAIR: the lead (waves 0-3) streams super-blocks
-// 0..55 with its chain inline, the helper (waves 4-7) computes the TERMS of super-blocks 56..111 and parks them compactly ({fs, pm} per lane, {d, dmin}
-// per row: 576 bytes per record, 4 x 56 of them = 126 KB beside the 32 KB of activations), and the lead replays them in order behind its own steps:
-// each lane's f32 chain is the reference's sequential chain over super-blocks 0..111 (ggml-quants.c:6937-6941, :6970, :8219).  The PLAIN prologue is
-// shared: fourteen blocks per wave, all fourteen requests out at entry (four activation batches in registers), one barrier.
-#define BAMD_D70_NB 112
-#define BAMD_D70_CUT 56
-#define BAMD_D70_PARK_BYTES ((size_t) 4 * (BAMD_D70_NB - BAMD_D70_CUT) * 576)
-template <int TYPE, int EPI, bool HELPER>
-__device__ __forceinline__ void stream_half_row(const uint8_t * __restrict__ w, int rg, float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
-                                                ActPro<false> & a0, ActPro<false> & a1, ActPro<false> & a2, ActPro<false> & a3, float * park, int * flag, int nvalid) {
-    typedef typename RecOf<TYPE>::type REC;
-    constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;
-    constexpr int NB = BAMD_D70_NB, CUT = BAMD_D70_CUT, NREC = HELPER ? NB - CUT : CUT, SB0 = HELPER ? CUT : 0, D = 8;
-    static_assert(NREC % D == 0 && (NB - CUT) % 8 == 0, "whole ring chunks");
-    const int lane = threadIdx.x & 63, wave = wave_id(), r8 = lane >> 3;
-    const bamd_rsrc rs = weight_rsrc(w);
-    const int base = rg * (NB * RECB) + SB0 * RECB;          // < 2 GiB: 1024 row-groups x 112 x 1680
-    REC ring[D];
-#pragma unroll
-    for (int s = 0; s < D / 2; ++s) load_rec(ring[s], rs, base + s * RECB, lane);
-    TL_STAMP(pa.tl, 1);
-    const int row = rg * 8 + r8;
-    float resv = 0.f;
-    if (!HELPER && EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
-    a0.template quantize_batch<4>(1.0f, pa.K, wave, pa.q8, pa.S, pa.yd, 8, NB);
-#pragma unroll
-    for (int s = D / 2; s < D; ++s) load_rec(ring[s], rs, base + s * RECB, lane);
-    a1.template quantize_batch<4>(1.0f, pa.K, wave + 32, pa.q8, pa.S, pa.yd, 8, NB);
-    a2.template quantize_batch<4>(1.0f, pa.K, wave + 64, pa.q8, pa.S, pa.yd, 8, NB);
-    a3.template quantize_batch<2>(1.0f, pa.K, wave + 96, pa.q8, pa.S, pa.yd, 8, NB);
-    __syncthreads();
-    TL_STAMP(pa.tl, 2);
-    const uint32_t * q8 = pa.q8; const int * S = pa.S; const float * yd = pa.yd;
-    RowAcc A = { 0.f, 0.f };
-    for (int c = 0; c < NREC / D; ++c) {
-        // refills stay unconditional (counted waits): behind the last chunk the wave re-requests its last record (never consumed)
-        const bool more = c + 1 < NREC / D;
-        const int nxt = more ? base + (c + 1) * (D * RECB) : base + (NREC - 1) * RECB;
-        const int step = more ? RECB : 0;
-#pragma unroll
-        for (int s = 0; s < D; ++s) {
-            pin_rec(ring[s]);
-            const Terms T = block_terms(ring[s], SB0 + c * D + s, lane, q8, S, yd);
-            if (HELPER) {
-                float * rec = park + (size_t) (c * D + s) * 144;
-                *(float2 *) (rec + lane * 2) = make_float2(T.fs, T.pm);
-                if ((lane & 7) == 0) *(float2 *) (rec + 128 + r8 * 2) = make_float2(T.d, T.dmin);
-            } else chain_step<TYPE>(A, T.d, T.fs, T.dmin, T.pm);
-            load_rec(ring[s], rs, nxt + s * step, lane);
-            if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c == 0) TL_STAMP(pa.tl, 3);
-    }
-    TL_STAMP(pa.tl, 4);
-    if (HELPER) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-    }
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = 0; i < NB - CUT; i += 8) {
-        float2 fp[8], dd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const float * rec = park + (size_t) (i + u) * 144; fp[u] = *(const float2 *) (rec + lane * 2); dd[u] = *(const float2 *) (rec + 128 + r8 * 2); }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, dd[u].x, fp[u].x, dd[u].y, fp[u].y);
-    }
-    const float val = finish_row<TYPE>(A);
-    if ((lane & 7) == 0 && row < nvalid) out[row] = EPI == BAMD_EPI_ADD ? val + resv : val;
-    TL_STAMP(pa.tl, 5);
-}
-template <int TYPE, int EPI>
-__global__ void __launch_bounds__(512) matvec_down70_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
-    BAMD_LEAD_TAKE(a);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TL_STAMP(a.tl, 0);
-    const ProArgs pa = carve_lds(a, smem);
-    const int wave = wave_id(), grid = (int) gridDim.x, b = (int) blockIdx.x;
-    ActPro<false> a0, a1, a2, a3;                           // blocks wave, wave + 8, ..., wave + 104: the first memory instructions of the kernel
-    a0.template issue<4>(pa.x, pa.nw, pa.K, wave, 8, BAMD_D70_NB);      a1.template issue<4>(pa.x, pa.nw, pa.K, wave + 32, 8, BAMD_D70_NB);
-    a2.template issue<4>(pa.x, pa.nw, pa.K, wave + 64, 8, BAMD_D70_NB); a3.template issue<2>(pa.x, pa.nw, pa.K, wave + 96, 8, BAMD_D70_NB);
-    float * park0 = (float *) (smem + BAMD_ACT_RED_OFF(BAMD_D70_NB) + 16 * sizeof(double) + 16 * sizeof(unsigned long long));
-    int * flags = (int *) ((unsigned char *) park0 + BAMD_D70_PARK_BYTES);
-    if (threadIdx.x < 4) flags[threadIdx.x] = 0;             // ordered before their first use by the prologue's workgroup barrier
-    const int j = wave & 3;
-    const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
-    float * park = park0 + (size_t) j * (BAMD_D70_NB - BAMD_D70_CUT) * 144;
-    if (wave < 4) stream_half_row<TYPE, EPI, false>((const uint8_t *) a.seg[0].w, b + grid * j, a.seg[0].out, a.res, pa, a0, a1, a2, a3, park, flags + j, nv);
-    else          stream_half_row<TYPE, EPI, true>((const uint8_t *) a.seg[0].w, b + grid * j, a.seg[0].out, a.res, pa, a0, a1, a2, a3, park, flags + j, nv);
-    TL_STAMP(a.tl, 7);
-}
-static const bool g_down70 = [] { const char * e = getenv("BAMD_DOWN70"); return !(e && e[0] == '0'); }();
-template <int EPI>
-static bool launch_down70(const bamd_mv_args & a, int t, int grid, hipStream_t s) {
-    const size_t lds = act_lds_bytes(a.K) + BAMD_D70_PARK_BYTES + 16;
-#define BAMD_D70(T_) if (t == T_) { hipLaunchKernelGGL((matvec_down70_kernel<T_, EPI>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
-    BAMD_D70(BAMD_Q4_K) BAMD_D70(BAMD_Q5_K) BAMD_D70(BAMD_Q6_K)
-#undef BAMD_D70
-    return false;
-}
-
 static const bool g_gateup7 = [] { const char * e = getenv("BAMD_GATEUP7"); return !(e && e[0] == '0'); }();
 
 // mode B (split-K), one segment of one type, NBW = K / 2048 records per wave and row-group, M row-groups per batch
@@ -220,10 +113,6 @@ static bool launch_fast_a_types(const bamd_mv_args & a, int t0, int t1, int grid
 }
 bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
-    if (g_down70 && nb == BAMD_D70_NB && pro == BAMD_PRO_PLAIN && a.nseg == 1 && (a.seg[0].nrows >> 3) == 4 * grid && (a.mode & 15) <= 1) {
-        if (epi == BAMD_EPI_ADD)   return launch_down70<BAMD_EPI_ADD>(a, a.seg[0].type, grid, s);
-        if (epi == BAMD_EPI_STORE) return launch_down70<BAMD_EPI_STORE>(a, a.seg[0].type, grid, s);
-    }
     if ((nb & 7) != 0 || nb < 8 || nb > 8 * BAMD_ACT_BATCH) return false;      // SMALLK prologue: K <= 8192
     const int slots = grid * 8;
     int t0 = a.seg[0].type, t1 = 0;

@@ -213,25 +213,6 @@ def test_mul_mat_vec_large_k(bamd, po, t, K, rows):
 
 
 @pytest.mark.parametrize("t", [12, 13, 14])
-@pytest.mark.parametrize("with_res", [True, False])
-def test_mul_mat_vec_70b_ffn_down(bamd, po, t, with_res):
-    """Llama-3-70B's ffn_down launch (8192 rows, K = 28672) on a 256-CU device: four row-groups per workgroup, a wave pair per row-group — the lead streams
-    super-blocks 0..55 with its chain inline, the helper parks the terms of 56..111, the lead replays them (matvec_down70_kernel) == the generic kernel
-    == the oracle"""
-    K, rows = 28672, 8192
-    rng = np.random.default_rng(97 * t + 5)
-    W = random_kquant_tensor(t, K, rows, rng)
-    x = (rng.standard_normal(K) * 2).astype(np.float32)
-    res = rng.standard_normal(rows).astype(np.float32) if with_res else None
-    fast = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=0)
-    generic = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=17)
-    want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0]
-    if with_res:
-        want = want + res
-    assert np.array_equal(bits(fast), bits(generic)) and np.array_equal(bits(fast), bits(want)), "type %d" % t
-
-
-@pytest.mark.parametrize("t", [12, 13, 14])
 @pytest.mark.parametrize("K,rows,norm", [(11008, 520, False), (13824, 264, False), (5120, 640, True), (5120, 1032, False), (4352, 72, True), (12032, 40, False), (3072, 3072, False), (3072, 1032, True), (2304, 24, False), (3840, 520, True)])
 def test_mul_mat_vec_uneven_split(bamd, po, t, K, rows, norm):
     """split-K when K / 256 is not a multiple of 8 (Llama-2's 11008 = 43, 13824 = 54, 5120 = 20 super-blocks, Llama-3.2-3B's 3072 = 12; 9, 15, 17
