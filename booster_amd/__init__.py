@@ -65,12 +65,6 @@ def lib():
         L.bamd_op_get_row.argtypes = [ci, vp, ci, ci, ci, vp]
         L.bamd_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.bamd_op_rope_row.argtypes = [ci, ci, cf, cf, vp, vp]
-        L.bamd_op_wse_matvec.argtypes = [ci, vp, vp, ci, ci, vp, vp, cf, vp, vp, ci, ci, ci, ci, vp, vp]
-        L.bamd_wse_plan_describe.argtypes = [ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, ci]
-        L.bamd_wse_timeline.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci), C.POINTER(ci)]
-        L.bamd_set_wse.argtypes = [ci]; L.bamd_set_wse.restype = None
-        L.bamd_wse_active.argtypes = [vp]
-        L.bamd_wse_why.argtypes = [vp]; L.bamd_wse_why.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -96,12 +90,6 @@ def set_prefill_version(v):
 
 def device_count():
     return lib().bamd_device_count()
-
-
-def set_wse(on):
-    """1: single-token steps run their layers on the weight-stream engine (one persistent launch, bamd_wse.h) where the model's shape has a
-    program; 0: the launch sequence.  Takes effect for contexts created afterwards (captured graphs keep the path they were captured with)."""
-    lib().bamd_set_wse(int(on))
 
 
 class Model:
@@ -202,18 +190,6 @@ class Context:
         _chk(lib().bamd_timeline_step(self.h, pos, replays, _p(out), cap, C.byref(n)))
         return out[:n.value]
 
-    def wse_active(self):
-        """(True, "") when this context's steps run on the weight-stream engine, else (False, why not)"""
-        return bool(lib().bamd_wse_active(self.h)), lib().bamd_wse_why(self.h).decode()
-
-    def wse_timeline(self, pos, replays=3):
-        """stamps of one engine launch: u64 [n_cu][ops][8], 100 MHz wall clock (events: csrc/bamd_wse.h BAMD_WSE_TL_*)"""
-        cap = 512 * (6 * self.model.n_layer + 2) * 8
-        out = np.zeros(cap, np.uint64)
-        n_cu = C.c_int(0); ops = C.c_int(0)
-        _chk(lib().bamd_wse_timeline(self.h, pos, replays, _p(out), cap, C.byref(n_cu), C.byref(ops)))
-        return out[:n_cu.value * ops.value * 8].reshape(n_cu.value, ops.value, 8)
-
     def stage_step(self, token, pos, hidden_in_ptr, hidden_out_ptr, want_logits, prefill_mode, stream_ptr, token_dev_ptr=None):
         _chk(lib().bamd_stage_step(self.h, int(token), token_dev_ptr, int(pos), hidden_in_ptr, hidden_out_ptr, int(want_logits),
                                    int(prefill_mode), stream_ptr))
@@ -288,47 +264,6 @@ def op_ffn_gate_up(ttype, wg_raw, wu_raw, nrows, k, x, norm_w=None, eps=0.0):
     y = np.zeros(nrows, np.float32)
     _chk(lib().bamd_op_ffn_gate_up(ttype, _p(wg_raw), _p(wu_raw), nrows, k, _p(x), _p(nw), eps, _p(y)))
     return y
-
-
-WSE_EPI_STORE, WSE_EPI_ADD, WSE_EPI_GATE, WSE_EPI_UP, WSE_EPI_ARGMAX = 0, 1, 2, 3, 4
-
-
-def op_wse_matvec(ttype, w_raw, nrows, k, x, norm_w=None, eps=0.0, residual=None, w_up_raw=None, nc=10, thin=0, n_cu=0, timeline=False, nch=1):
-    """y = W . Q8_K(x) through the weight-stream engine kernel (csrc/bamd_wse.hip) as a one-piece program; with w_up_raw: silu(Wg a) * (Wu a).
-    Returns (y, info) or (y, info, stamps); info = [n_cu, ring slots, term records, ops per CU, LDS bytes, err0..3]"""
-    w_raw = np.ascontiguousarray(w_raw, np.uint8); x = np.ascontiguousarray(x, np.float32)
-    wu = None if w_up_raw is None else np.ascontiguousarray(w_up_raw, np.uint8)
-    nw = None if norm_w is None else np.ascontiguousarray(norm_w, np.float32)
-    res = None if residual is None else np.ascontiguousarray(residual, np.float32)
-    y = np.zeros(nrows, np.float32); info = np.zeros(16, np.int32)
-    tl = np.zeros((512, 2, 8), np.uint64) if timeline else None
-    epi = WSE_EPI_ADD if residual is not None else WSE_EPI_STORE
-    _chk(lib().bamd_op_wse_matvec(ttype, _p(w_raw), _p(wu), nrows, k, _p(x), _p(nw), eps, _p(res), _p(y), epi, nc, int(thin) | (256 if nch == 2 else 0), n_cu, _p(tl), _p(info)))
-    if timeline:
-        n = int(info[0]); pieces = 2 if wu is not None else 1
-        return y, info, tl.reshape(-1)[:n * pieces * 8].reshape(n, pieces, 8)
-    return y, info
-
-
-def wse_selftest():
-    """LDS-DMA facts of this device: [words ok of 256 at LDS 100 KiB, word at 8 KiB, word at 9 KiB, last words of both, LDS base]"""
-    out = np.zeros(8, np.uint32)
-    lib().bamd_wse_selftest.argtypes = [C.c_void_p]
-    _chk(lib().bamd_wse_selftest(_p(out)))
-    return out
-
-
-def wse_plan_describe(n_cu, E, H, Hkv, hd, F, L, V, types7, head_type=0, n_ctx=512, nc=10):
-    """the engine's per-CU programs for a model shape (host only, no device): (head dict, rows int64 [n][16]) — see bamd_wse_plan_describe"""
-    t7 = np.ascontiguousarray(types7, np.int32)
-    head = np.zeros(8, np.int64)
-    cap = n_cu * (8 * L + 4)
-    rows = np.zeros((cap, 16), np.int64)
-    n = lib().bamd_wse_plan_describe(n_cu, E, H, Hkv, hd, F, L, V, _p(t7), head_type, n_ctx, nc, _p(head), _p(rows), cap)
-    if n < 0:
-        raise BamdError(lib().bamd_last_error().decode())
-    keys = ("rc", "n_cu", "ops_per_cu", "ns", "tr", "nc", "lds_bytes", "rows")
-    return dict(zip(keys, (int(v) for v in head))), rows[:n]
 
 
 def op_get_row(ttype, w_raw, nrows, k, row):

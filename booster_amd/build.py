@@ -9,14 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libbooster_amd.so")
-SOURCES = ["bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_attention_mfma.hip", "bamd_colaunch.hip", "bamd_wse.hip", "bamd_wse_plan.cpp", "bamd_prefill.hip", "bamd_prefill2.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
-HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_wse.h", "bamd_device.h", "bamd_matvec_core.h", "bamd_attn_fused.h", "bamd_mfma_common.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
+SOURCES = ["bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_attention_mfma.hip", "bamd_colaunch.hip", "bamd_prefill.hip", "bamd_prefill2.hip", "bamd_sampler.hip", "bamd_engine.cpp", "bamd_gguf.cpp", "bamd_vocab.cpp", "bamd_bridge.cpp"]
+HEADERS = ["bamd_formats.h", "bamd_kernels.h", "bamd_device.h", "bamd_matvec_core.h", "bamd_attn_fused.h", "bamd_mfma_common.h", "bamd_gguf.h", "bamd_vocab.h", "bamd_unicode_tables.h", "../../include/bamd.h", "../../include/booster_bridge.h"]
 # -ffp-contract=off: the numerics contract (bit-parity with the reference CPU path) forbids implicit FMA fusion.
 # -fno-slp-vectorize (decode kernels only, NO_SLP): SLP packs neighbouring f32 multiplies into v_pk_mul_f32, whose operands need
 # even-aligned register pairs: the copies it adds sit right behind the loads (a full s_waitcnt before the weight ring could be
 # requested) and packed f32 is no faster there.  The prefill kernels keep SLP: their f32 chains run on float4 accumulators, where
 # v_pk_fma_f32 halves the instruction count (same IEEE fma per element).
-NO_SLP = ("bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_colaunch.hip", "bamd_wse.hip")
+NO_SLP = ("bamd_matvec.hip", "bamd_matvec_fast_a.hip", "bamd_matvec_fast_b.hip", "bamd_attention.hip", "bamd_colaunch.hip")
 # gfx950 kernarg preload for the decode mat-vec kernels: their leading scalar parameters (BAMD_LEAD_PARAMS: activation / weight pointers, K, eps)
 # arrive in SGPRs at wave launch, so the first requests do not wait for an s_load of the argument block (+0.3 % decode, measured)
 KERNARG_PRELOAD = {"bamd_matvec_fast_a.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"], "bamd_matvec_fast_b.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}

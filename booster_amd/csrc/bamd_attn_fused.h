@@ -15,9 +15,9 @@
 // flag (MI355X_MICROARCH.md, R2): the wo workgroups of the same launch re-read their granules until every tag is this launch's tag, with no drain,
 // barrier or flag hop on this side.  done_flags then points at the granule array [H * hd].
 // ENV: where the body runs.  AttnEnvWG = a whole 512-thread workgroup (attn_fused_kernel, attn_wo_kernel): thread / wave ids from the hardware,
-// __syncthreads, this token's q / k / v read from the f32 vectors of the argument block.  The weight-stream engine (bamd_wse.hip) runs the same body
-// on eight of its consumer waves: ids relative to the first of them, a counting barrier among those waves, q / k / v from an LDS stage it filled
-// from the validated granules of the QKV launch role.
+// __syncthreads, this token's q / k / v read from the f32 vectors of the argument block.  (Round 4's weight-stream engine ran the same body on eight of its
+// consumer waves through another ENV; the engine was removed in round 6 — profiles/r04_engine_vs_launches.txt — the parameter stays for a role that
+// takes its inputs from somewhere else.)
 struct AttnEnvWG {
     int tid, wave, nthr;
     __device__ __forceinline__ AttnEnvWG() : tid((int) threadIdx.x), wave(wave_id()), nthr((int) blockDim.x) { }

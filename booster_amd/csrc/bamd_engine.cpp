@@ -10,7 +10,6 @@
 #include "bamd_formats.h"
 #include "bamd_gguf.h"
 #include "bamd_kernels.h"
-#include "bamd_wse.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -38,13 +37,6 @@ extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_version(
 static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
-// the weight-stream engine (bamd_wse.h): the layers of a decode step as ONE persistent launch.  BAMD_WSE=0 / 1 overrides the default;
-// BAMD_WSE_NC = consumer waves per CU (8..14), BAMD_WSE_THIN=1 keeps one fill outstanding while a CU gathers
-static int g_wse = [] { const char * e = getenv("BAMD_WSE"); return e ? atoi(e) : 0; }();
-static int g_wse_nc = [] { const char * e = getenv("BAMD_WSE_NC"); const int v = e ? atoi(e) : 10; return v < 8 ? 8 : v > 14 ? 14 : v; }();
-static int g_wse_thin = [] { const char * e = getenv("BAMD_WSE_THIN"); return e ? atoi(e) : 0; }();
-static int g_wse_nch = [] { const char * e = getenv("BAMD_WSE_NCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 2 ? 2 : v; }();
-#define BAMD_WSE_LDS_LIMIT (160 * 1024 - 2560)      /* dynamic LDS the engine may plan with: 160 KiB less the static arrays of attn_fused_body (2144 B) */
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
 
@@ -167,31 +159,15 @@ struct bamd_context {
     // batched prefill buffers, [bcap] tokens each (allocated at the first multi-token decode)
     // phase-stamp blocks (bamd_timeline_step, BAMD_TIMING builds): one block of BAMD_TL_SLOT_WORDS u64 per launch
     unsigned long long * tl_base = nullptr; int tl_slot = 0, tl_cap = 0;
-    // weight-stream engine state (lazily planned at the first single-token step; bamd_wse.h)
-    struct Wse {
-        bool tried = false, ok = false;
-        bamd_wse_plan plan = {}; bamd_wse_op * d_ops = nullptr;
-        unsigned long long * gran[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // X, QKV, ATT, X2, HID granule vectors
-        unsigned short ** d_kc = nullptr, ** d_vc = nullptr;
-        uint32_t * err = nullptr;                                                             // [16]: give-ups, first code, workgroup, wave
-        unsigned long long * tl = nullptr;                                                    // timeline block of the next launch (bamd_wse_timeline)
-        std::string why;
-    } wse;
-    bool counted = false;            // this context is in g_ctx_live
     int bcap = 0;
     float * attn_bscr = nullptr; size_t attn_bscr_bytes = 0, attn_bscr_failed = 0;   // score rows of the matrix-core prefill attention beyond BAMD_AM_MAXPOS = 512 positions (grow-only; absent = the VALU kernel runs)
     float * bx = nullptr, * bx2 = nullptr, * bqkv = nullptr, * batt = nullptr, * bh = nullptr; unsigned char * bblob = nullptr, * bblob16 = nullptr;
     std::vector<void *> allocs;
 };
 
-// contexts alive per device.  The weight-stream engine (bamd_wse.hip) is ONE persistent launch whose workgroups wait for each other: every workgroup must be
-// resident at once, which holds only while no other context shares the device (two engine launches, each holding part of the CUs, would wait for workgroups that
-// were never scheduled until their spins give up — ADVICE r4).  So the engine is used only by a context that is alone on its device; a second context turns
-// every context of that device back to the launch sequence (wse_usable is part of the graph key: the step graph is recaptured).
-static std::atomic<int> g_ctx_live[64];
 static int dev_alloc(std::vector<void *> & keep, void ** p, size_t bytes) {
-    HIPC(hipMalloc(p, bytes + 4096));           // + 4 KiB: the weight-stream engine's last 1 KiB request of a piece may read past the last record, the sixteen-wave
-                                                // prefill kernel's nibble loads of the two super-blocks behind the end of K past the last record group (bamd_prefill2.hip)
+    HIPC(hipMalloc(p, bytes + 4096));           // + 4 KiB: the sixteen-wave prefill kernel's nibble loads of the two super-blocks behind the end of K run past
+                                                // the last record group (bamd_prefill2.hip)
     keep.push_back(*p);
     return 0;
 }
@@ -415,7 +391,6 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
     HIPC(hipMemsetAsync(c->co_gran, 0, (size_t) m->H * m->hd * 8 + 64, c->stream));
     c->co_err = (uint32_t *) (c->co_gran + (size_t) m->H * m->hd);
     HIPC(hipMemsetAsync(c->logits, 0, (size_t) m->V * 4, c->stream));
-    c->wse.err = c->co_err + 4;                                       // the engine's give-up words share the status block
     HIPC(hipHostMalloc((void **) &c->logits_host, (size_t) m->V * 4 + 64));     // + the give-up words of the co-launch / engine kernels, read back with the logits
     memset(c->logits_host + m->V, 0, 64);
     c->forced_cap = 4096; c->out_cap = n_ctx + 8;
@@ -427,17 +402,14 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
 extern "C" __attribute__((visibility("default"))) bamd_context * bamd_context_new(bamd_model * m, int n_ctx) {
     bamd_context * c = new bamd_context();
     if (context_init(c, m, n_ctx)) { bamd_context_free(c); return nullptr; }
-    c->counted = true; g_ctx_live[m->device & 63].fetch_add(1);
     return c;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_context * c) {
     if (!c) return;
-    if (c->counted && c->m) g_ctx_live[c->m->device & 63].fetch_sub(1);
     if (c->m) hipSetDevice(c->m->device);
     if (c->graph) hipGraphExecDestroy(c->graph);
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
-    bamd_wse_plan_free(&c->wse.plan);
     if (c->logits_host) hipHostFree(c->logits_host);
     if (c->attn_bscr) hipFree(c->attn_bscr);
     if (c->samp_pen_host) hipHostFree(c->samp_pen_host);
@@ -477,12 +449,8 @@ static void seg_of(bamd_mv_seg & sg, const DevMat & d, float * out) { sg.w = d.s
 static bool attn_fused_for(const bamd_context * c, int pos_hi) { return g_attn_fused && pos_hi < 448 && !c->cells.active; }   // shifted cells: three-launch path (attn_qk_kernel<.., SH>)
 // LDS row length of the single-launch / batched attention kernels for sequences up to position pos_hi: a multiple of 64, independent of n_ctx
 static int attn_lds_ld(const bamd_context * c, int pos_hi) { return std::min((pos_hi + 1 + 63) / 64 * 64, c->n_ctx_pad); }
-static int wse_enqueue_layers(bamd_context * c, hipStream_t s, StepTimer * tm);
-static bool wse_usable(bamd_context * c, int prefill_mode, int pos_hi);
-static void wse_prepare(bamd_context * c);
 static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, StepTimer * tm, int pos_hi) {
     bamd_model * m = c->m;
-    if (wse_usable(c, prefill_mode, pos_hi)) return wse_enqueue_layers(c, s, tm);      // all layers of the stage as ONE persistent launch (bamd_wse.h)
     const int gq = m->H / m->Hkv;
     static const int qk_tiles = [] { const char * e = getenv("BAMD_QK_TILES"); return e ? atoi(e) : 64; }();   // score-kernel workgroups per KV head: 64 = two per CU at Hkv = 8 (16 waves per CU: 2.066 -> 2.038 ms/token at 8000 positions; 128: 2.13)
     const int tiles = std::min(std::max(c->n_ctx / 64, 1), qk_tiles);
@@ -553,94 +521,13 @@ static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
     bamd_launch_matvec(a, BAMD_PRO_NORM, BAMD_EPI_ARGMAX, m->n_cu, s);
     if (tm) tm->end(s);
 }
-// ---- weight-stream engine: plan once per context, then one launch per step (bamd_wse.h) --------------------------------------------------------
-static void wse_mat(bamd_wse_mat & w, const DevMat & d) { w.stream = (uint64_t) d.stream; w.type = d.type; w.nrows_pad = d.nrows_pad; w.nrows = d.nrows; w.K = d.K; }
-static int wse_init(bamd_context * c) {
-    bamd_model * m = c->m;
-    bamd_context::Wse & w = c->wse;
-    w.tried = true;
-    const int nl = (int) m->layers.size();
-    if (nl < 1) { w.why = "no layers on this stage"; return 1; }
-    std::vector<bamd_wse_layer> L((size_t) nl);
-    for (int i = 0; i < nl; ++i) {
-        const DevLayer & y = m->layers[(size_t) i];
-        wse_mat(L[i].wq, y.wq); wse_mat(L[i].wk, y.wk); wse_mat(L[i].wv, y.wv); wse_mat(L[i].wo, y.wo); wse_mat(L[i].wg, y.wg); wse_mat(L[i].wu, y.wu); wse_mat(L[i].wd, y.wd);
-        L[i].attn_norm = (uint64_t) y.attn_norm; L[i].ffn_norm = (uint64_t) y.ffn_norm;
-    }
-    const int ld = std::min(512, c->n_ctx_pad);
-    if (m->hd % 64 || m->hd > 256) { w.why = "head_dim not 64 / 128 / 192 / 256"; return 1; }
-    const size_t attn_lds = (size_t) ld * 8 + (size_t) 3 * m->hd * 4;
-    if (bamd_wse_plan_build(&w.plan, L.data(), 0, nl, m->n_cu, m->E, m->H, m->Hkv, m->hd, m->F, nullptr, 0, m->V, attn_lds, g_wse_nc, BAMD_WSE_LDS_LIMIT)) { w.why = w.plan.why; return 1; }
-    {
-        size_t static_lds = 0;
-        if (bamd_wse_setup(m->hd, &static_lds)) { w.why = "the device refused the engine kernel's LDS size"; bamd_wse_plan_free(&w.plan); return 1; }
-        if (w.plan.lds_bytes + static_lds > 160 * 1024) { w.why = "the engine's LDS plan plus the kernel's static LDS exceed 160 KiB"; bamd_wse_plan_free(&w.plan); return 1; }
-    }
-    const size_t ob = (size_t) w.plan.n_cu * w.plan.ops_per_cu * sizeof(bamd_wse_op);
-    if (dev_alloc(c->allocs, (void **) &w.d_ops, ob)) return 1;
-    HIPC(hipMemcpy(w.d_ops, w.plan.ops, ob, hipMemcpyHostToDevice));
-    const size_t Ekv = (size_t) m->Hkv * m->hd, gn[5] = { (size_t) m->E, (size_t) m->E + 2 * Ekv, (size_t) m->E, (size_t) m->E, (size_t) m->F };
-    for (int i = 0; i < 5; ++i) { if (dev_alloc(c->allocs, (void **) &w.gran[i], gn[i] * 8)) return 1; HIPC(hipMemset(w.gran[i], 0, gn[i] * 8)); }
-    if (dev_alloc(c->allocs, (void **) &w.d_kc, (size_t) nl * 8) || dev_alloc(c->allocs, (void **) &w.d_vc, (size_t) nl * 8)) return 1;
-    HIPC(hipMemcpy(w.d_kc, c->kc.data(), (size_t) nl * 8, hipMemcpyHostToDevice));
-    HIPC(hipMemcpy(w.d_vc, c->vc.data(), (size_t) nl * 8, hipMemcpyHostToDevice));
-    w.ok = true;
-    return 0;
-}
-static void wse_fill_args(bamd_context * c, bamd_wse_args & a) {
-    bamd_model * m = c->m; bamd_context::Wse & w = c->wse;
-    memset(&a, 0, sizeof a);
-    a.ops = w.d_ops; a.ops_per_cu = w.plan.ops_per_cu; a.ns = w.plan.ns; a.tr = w.plan.tr; a.nc = w.plan.nc; a.nch = g_wse_nch;
-    a.off_act[0] = w.plan.off_act[0]; a.off_act[1] = w.plan.off_act[1]; a.off_terms = w.plan.off_terms; a.off_misc = w.plan.off_misc; a.off_attn = w.plan.off_attn;
-    const uint32_t Ekv = (uint32_t) (m->Hkv * m->hd);
-    a.vec[BAMD_WSE_V_XIN] = { c->x, (uint32_t) m->E, 0 };
-    a.vec[BAMD_WSE_V_X] = { w.gran[0], (uint32_t) m->E, 1 };
-    a.vec[BAMD_WSE_V_QKV] = { w.gran[1], (uint32_t) m->E + 2 * Ekv, 1 };
-    a.vec[BAMD_WSE_V_ATT] = { w.gran[2], (uint32_t) m->E, 1 };
-    a.vec[BAMD_WSE_V_X2] = { w.gran[3], (uint32_t) m->E, 1 };
-    a.vec[BAMD_WSE_V_HID] = { w.gran[4], (uint32_t) m->F, 1 };
-    a.vec[BAMD_WSE_V_XOUT] = { c->x, (uint32_t) m->E, 0 };            // the first layer's reads of XIN are long over when the last layer stores
-    a.vec[BAMD_WSE_V_LOGITS] = { c->logits, (uint32_t) m->V, 0 };
-    a.st = c->st; a.err = w.err; a.tl = w.tl; a.tl_ops = w.plan.tl_ops; a.best_key = &c->st->best_key; a.eps = m->eps;
-    a.at.st = c->st; a.at.rope = c->rope; a.at.hd = m->hd; a.at.Hkv = m->Hkv; a.at.n_ctx = c->n_ctx_pad; a.at.kq_scale = 1.0f / sqrtf((float) m->hd);
-    a.at.lds_ld = std::min(512, c->n_ctx_pad);
-    a.kc = w.d_kc; a.vc = w.d_vc; a.gq = m->H / m->Hkv; a.H = m->H; a.thin = g_wse_thin;
-}
-// single-token decode (reference semantics T = 1), sequences the single-launch attention covers, cells following positions: what the engine's
-// attention role implements.  Everything else takes the launch sequence.
-static bool wse_usable(bamd_context * c, int prefill_mode, int pos_hi) {
-    return g_wse && !prefill_mode && attn_fused_for(c, pos_hi) && c->wse.ok && g_ctx_live[c->m->device & 63].load() <= 1;
-}
-// plans the engine the first time it could be used.  Called at the entry points BEFORE any stream capture begins (the planner allocates and copies).
-static void wse_prepare(bamd_context * c) {
-    if (!g_wse || c->wse.tried) return;
-    if (wse_init(c)) {
-        c->wse.ok = false;
-        if (c->wse.why.empty()) c->wse.why = g_err;
-        if (getenv("BAMD_WSE_VERBOSE")) fprintf(stderr, "bamd: weight-stream engine not used: %s\n", c->wse.why.c_str());
-    }
-}
-static int wse_enqueue_layers(bamd_context * c, hipStream_t s, StepTimer * tm) {
-    bamd_model * m = c->m;
-    bamd_wse_args a; wse_fill_args(c, a);
-    double bytes = 0;
-    for (const DevLayer & y : m->layers) bytes += (double) (y.wq.bytes + y.wk.bytes + y.wv.bytes + y.wo.bytes + y.wg.bytes + y.wu.bytes + y.wd.bytes);
-    if (tm) tm->begin(s, 0, bytes, 4);                                // the whole stage in one launch: booked under the dominant kind (gate/up)
-    if (bamd_launch_wse(a, m->n_cu, c->wse.plan.lds_bytes, s)) { if (tm) tm->cancel(); return fail("weight-stream engine: launch refused"); }
-    if (tm) tm->end(s);
-    return 0;
-}
-extern "C" __attribute__((visibility("default"))) void bamd_set_wse(int on) { g_wse = on; }
-extern "C" __attribute__((visibility("default"))) int bamd_wse_active(bamd_context * c) { return c->wse.ok ? 1 : 0; }
-extern "C" __attribute__((visibility("default"))) const char * bamd_wse_why(bamd_context * c) { return c->wse.why.c_str(); }
-
 static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStream_t s, bool with_slots = false) {
     bamd_model * m = c->m;
     bamd_launch_step_begin(c->st, c->forced, n_forced, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, do_embed, s,
                            with_slots ? c->slots : nullptr, with_slots ? c->cellpos : nullptr);
 }
 
-// The tag of a granule hand-over (bamd_colaunch.hip, bamd_wse.hip) is (host serial : 12, device step : 12, layer : 8); a word must never already hold the tag a
+// The tag of a granule hand-over (bamd_colaunch.hip) is (host serial : 12, device step : 12, layer : 8); a word must never already hold the tag a
 // consumer is about to wait for.  The serial runs 1 .. 0xffe (0 is what zero-initialised granules carry, 0xfff is reserved) and every time it wraps ALL granule
 // vectors of the context are overwritten with 0xff bytes — tag 0xffffffff, which no launch produces — in stream order ahead of the launch that reuses serial 1
 // (with a bare 12-bit counter a stale granule of 4096 host calls ago carried the awaited tag and a gather passed without waiting).
@@ -649,10 +536,6 @@ static int next_serial(bamd_context * c, hipStream_t s) {
         c->host_serial = 1;
         const bamd_model * m = c->m;
         if (c->co_gran) HIPC(hipMemsetAsync(c->co_gran, 0xff, (size_t) m->H * m->hd * 8, s));
-        if (c->wse.gran[0]) {
-            const size_t Ekv = (size_t) m->Hkv * m->hd, gn[5] = { (size_t) m->E, (size_t) m->E + 2 * Ekv, (size_t) m->E, (size_t) m->E, (size_t) m->F };
-            for (int i = 0; i < 5; ++i) if (c->wse.gran[i]) HIPC(hipMemsetAsync(c->wse.gran[i], 0xff, gn[i] * 8, s));
-        }
     }
     return 0;
 }
@@ -964,17 +847,16 @@ static int enqueue_prefill_batch(bamd_context * c, int T, int n_past, hipStream_
 }
 
 // a wo workgroup of a co-launch (bamd_colaunch.hip) that never saw the attention role's flags gave up instead of hanging: the results are void
-// the give-up words of the kernels that wait inside a launch (attention || wo co-launch: word 0; weight-stream engine: words 4..7), copied behind
+// the give-up words of the kernels that wait inside a launch (attention || wo co-launch: word 0), copied behind
 // the host logits by status_readback and checked once the stream has been synchronised.  A give-up invalidates that step only: the words are
 // cleared after reporting, so the context stays usable.
 static hipError_t status_readback(bamd_context * c, hipStream_t s) { return hipMemcpyAsync(c->logits_host + c->m->V, c->co_err, 32, hipMemcpyDeviceToHost, s); }
 static int co_gave_up(bamd_context * c) {
     uint32_t w[8]; memcpy(w, c->logits_host + c->m->V, 32);
-    if (!w[0] && !w[4]) return 0;
+    if (!w[0]) return 0;
     hipMemsetAsync(c->co_err, 0, 32, c->stream);
     hipStreamSynchronize(c->stream);
     memset(c->logits_host + c->m->V, 0, 32);
-    if (w[4]) { char b[200]; snprintf(b, sizeof b, "weight-stream engine: %u waits gave up (first: code 0x%x, workgroup %u, wave %u); results invalid", w[4], w[5], w[6], w[7]); return fail(b); }
     return fail("co-launched attention + wo: a workgroup gave up waiting for the attention role (results invalid)");
 }
 extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context * c, const int32_t * tokens, int n_tokens, int n_past) {
@@ -990,7 +872,6 @@ extern "C" __attribute__((visibility("default"))) int bamd_decode(bamd_context *
     }
     if (n_tokens > c->forced_cap) { fail("n_tokens out of range (token by token evaluation takes at most 4096 per call)"); return 1; }
     if (hipSetDevice(m->device) != hipSuccess) { fail("hipSetDevice"); return 1; }
-    wse_prepare(c);
     hipStream_t s = c->stream;
     if (c->cells.active && n_tokens > 1) { fail("after a context shift (bamd_kv_seq_add) tokens are evaluated one per call"); return 1; }
     if (!c->cells.active) c->n_cached = std::max(c->n_cached, n_past + n_tokens);
@@ -1137,7 +1018,6 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     if (!m->with_embd || !m->with_output) return fail("bamd_generate_greedy needs a stage that owns embedding and output");
     if (n_steps < 1 || n_past < 1 || n_past + n_steps > c->n_ctx || n_steps + 1 > c->out_cap) return fail("bad n_past / n_steps");
     HIPC(hipSetDevice(m->device));
-    wse_prepare(c);
     hipStream_t s = c->stream;
     int attn_hi = n_past + n_steps;
     if (c->cells.active) {
@@ -1159,7 +1039,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
         HIPC(hipMemcpyAsync(c->slots, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, s));
         HIPC(hipStreamSynchronize(s));                                    // (hs is a host temporary)
     } else c->n_cached = std::max(c->n_cached, n_past + n_steps);
-    const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0)) | (wse_usable(c, 0, attn_hi) ? 4 : 0);     // 2: the shifted-cell kernels and the slot table (other arguments: recapture)
+    const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0));     // 2: the shifted-cell kernels and the slot table (other arguments: recapture)
     if (c->graph && c->graph_fused != fused) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     if (!c->graph && build_graph(c, attn_hi)) return 1;
     c->graph_fused = fused;
@@ -1185,7 +1065,6 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
                                void * hidden_out_dev, int want_logits, int prefill_mode, void * hip_stream) {
     bamd_model * m = c->m;
     HIPC(hipSetDevice(m->device));
-    wse_prepare(c);
     hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
     // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
@@ -1224,7 +1103,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
         return 0;
     }
     bamd_context::StageGraph & sg = c->sgraph[want_logits ? 1 : 0][prefill_mode ? 1 : 0];
-    const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0)) | (wse_usable(c, 0, attn_hi) ? 4 : 0);     // 2: the shifted-cell kernels (other arguments: recapture)
+    const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0));     // 2: the shifted-cell kernels (other arguments: recapture)
     if (sg.exec && (sg.token_src != (const void *) forced || sg.hin != hidden_in_dev || sg.hout != hidden_out_dev || sg.fused != fused)) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
     if (!sg.exec) {
         hipGraph_t g = nullptr;
@@ -1285,7 +1164,6 @@ static int profile_step_kinds(bamd_context * c, int pos, int * launches, double 
     bamd_model * m = c->m;
     if (!m->with_embd || !m->with_output) return fail("profile needs a full single-stage model");
     HIPC(hipSetDevice(m->device));
-    wse_prepare(c);
     hipStream_t s = c->stream;
     int32_t tok = 1;
     HIPC(hipMemcpyAsync(c->forced, &tok, 4, hipMemcpyHostToDevice, s));
@@ -1340,7 +1218,6 @@ extern "C" __attribute__((visibility("default"))) int bamd_timeline_step(bamd_co
     if (!bamd_timing_enabled()) return fail("bamd_timeline_step: library built without -DBAMD_TIMING (use booster_amd/lib/libbooster_amd_timing.so)");
     if (!m->with_embd || !m->with_output) return fail("timeline needs a full single-stage model");
     HIPC(hipSetDevice(m->device));
-    wse_prepare(c);
     hipStream_t s = c->stream;
     const int cap = (int) m->layers.size() * 5 + 1;
     if (cap > cap_launches) return fail("bamd_timeline_step: output buffer too small");
@@ -1430,138 +1307,6 @@ static int op_matvec(int type, const void * wA, const void * wB, int nrows, int 
     HIPC(hipGetLastError());
     HIPC(hipDeviceSynchronize());
     HIPC(hipMemcpy(y, dy, (size_t) nrows * 4, hipMemcpyDeviceToHost));
-    return 0;
-}
-// the same mat-vec through the weight-stream engine kernel: a one-piece program (or gate + up), plain f32 in and out.  epi: BAMD_WSE_EPI_*;
-// nc: consumer waves; tl (optional): [n_cu][pieces][8] wall-clock stamps of the launch; info (optional): {n_cu, ns, tr, ops_per_cu, lds_bytes, err0..3}
-extern "C" __attribute__((visibility("default"))) int bamd_op_wse_matvec(int type, const void * wA, const void * wB, int nrows, int k, const float * x, const float * norm_w, float eps,
-                                                                         const float * residual, float * y, int epi, int nc, int thin, int n_cu, unsigned long long * tl, int32_t * info) {
-    if (need_device()) return 1;
-    if (!bamd_is_kquant(type) || k <= 0 || k % 256 || nrows <= 0) return fail("bad type/shape");
-    if (n_cu <= 0) n_cu = n_cu0();
-    const int nrows_pad = (nrows + 7) / 8 * 8;
-    Tmp t; const size_t wb = bamd_row_bytes(type, k) * (size_t) nrows, wbp = bamd_stream_bytes(type, k, nrows_pad);
-    void * rawA = t.up(wA, wb), * strA = t.up(nullptr, wbp), * rawB = nullptr, * strB = nullptr;
-    if (wB) { rawB = t.up(wB, wb); strB = t.up(nullptr, wbp); }
-    if (strA) HIPC(hipMemset(strA, 0, wbp));
-    if (strB) HIPC(hipMemset(strB, 0, wbp));
-    float * dx = (float *) t.up(x, (size_t) k * 4); float * dw = norm_w ? (float *) t.up(norm_w, (size_t) k * 4) : nullptr;
-    float * dres = residual ? (float *) t.up(residual, (size_t) nrows * 4) : nullptr; float * dy = (float *) t.up(nullptr, (size_t) nrows * 4);
-    bamd_step_state hst; memset(&hst, 0, sizeof hst); hst.serial = 1; hst.step = 1; hst.n_ctx = 32;
-    bamd_step_state * st = (bamd_step_state *) t.up(&hst, sizeof hst);
-    uint32_t * err = (uint32_t *) t.up(nullptr, 64);
-    if (!rawA || !strA || !dx || !dy || !st || !err || (wB && (!rawB || !strB)) || (norm_w && !dw) || (residual && !dres)) return fail("device alloc/copy failed");
-    HIPC(hipMemset(err, 0, 64));
-    HIPC(hipMemset(dy, 0xff, (size_t) nrows * 4));                     // poison: a row the engine never stores shows
-    bamd_launch_repack(rawA, strA, type, nrows, k, nullptr);
-    if (wB) bamd_launch_repack(rawB, strB, type, nrows, k, nullptr);
-    bamd_wse_mat mA = { (uint64_t) strA, type, nrows_pad, nrows, k }, mB = { (uint64_t) strB, type, nrows_pad, nrows, k };
-    bamd_wse_plan plan;
-    if (bamd_wse_plan_single(&plan, &mA, wB ? &mB : nullptr, (uint64_t) dw, epi, n_cu, nc, BAMD_WSE_LDS_LIMIT)) return fail(std::string("weight-stream engine plan: ") + plan.why);
-    struct PlanGuard { bamd_wse_plan * p; ~PlanGuard() { bamd_wse_plan_free(p); } } guard { &plan };
-    const size_t ob = (size_t) plan.n_cu * plan.ops_per_cu * sizeof(bamd_wse_op);
-    bamd_wse_op * dops = (bamd_wse_op *) t.up(plan.ops, ob);
-    unsigned long long * dtl = tl ? (unsigned long long *) t.up(nullptr, (size_t) n_cu * plan.tl_ops * 64) : nullptr;
-    if (!dops || (tl && !dtl)) return fail("device alloc/copy failed");
-    if (dtl) HIPC(hipMemset(dtl, 0, (size_t) n_cu * plan.tl_ops * 64));
-    bamd_wse_args a; memset(&a, 0, sizeof a);
-    a.ops = dops; a.ops_per_cu = plan.ops_per_cu; a.ns = plan.ns; a.tr = plan.tr; a.nc = plan.nc; a.nch = thin >> 8 ? 2 : 1; thin &= 255;
-    a.off_act[0] = plan.off_act[0]; a.off_act[1] = plan.off_act[1]; a.off_terms = plan.off_terms; a.off_misc = plan.off_misc; a.off_attn = plan.off_attn;
-    a.vec[BAMD_WSE_V_XIN] = { dx, (uint32_t) k, 0 }; a.vec[BAMD_WSE_V_X2] = { dres, (uint32_t) nrows, 0 };
-    a.vec[BAMD_WSE_V_XOUT] = { dy, (uint32_t) nrows, 0 }; a.vec[BAMD_WSE_V_LOGITS] = { dy, (uint32_t) nrows, 0 };
-    a.st = st; a.err = err; a.tl = dtl; a.tl_ops = plan.tl_ops; a.best_key = &st->best_key; a.eps = eps; a.thin = thin;
-    if (bamd_wse_setup(0)) return fail("weight-stream engine: the device refused the kernel's LDS size");
-    if (bamd_launch_wse(a, n_cu, plan.lds_bytes, nullptr)) return fail("weight-stream engine: launch refused");
-    HIPC(hipGetLastError());
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(y, dy, (size_t) nrows * 4, hipMemcpyDeviceToHost));
-    uint32_t herr[4]; HIPC(hipMemcpy(herr, err, 16, hipMemcpyDeviceToHost));
-    if (tl) HIPC(hipMemcpy(tl, dtl, (size_t) n_cu * plan.tl_ops * 64, hipMemcpyDeviceToHost));
-    if (info) { info[0] = n_cu; info[1] = plan.ns; info[2] = plan.tr; info[3] = plan.ops_per_cu; info[4] = (int32_t) plan.lds_bytes; for (int i = 0; i < 4; ++i) info[5 + i] = (int32_t) herr[i]; }
-    if (herr[0]) { char b[160]; snprintf(b, sizeof b, "weight-stream engine: %u waits gave up (first: code 0x%x, workgroup %u, wave %u)", herr[0], herr[1], herr[2], herr[3]); return fail(b); }
-    return 0;
-}
-// LDS-DMA facts of this device (bamd_wse.hip: wse_selftest_kernel): out[0..5]
-extern "C" __attribute__((visibility("default"))) int bamd_wse_selftest(uint32_t * out) {
-    if (need_device()) return 1;
-    Tmp t;
-    std::vector<uint32_t> pat(4096); for (size_t i = 0; i < pat.size(); ++i) pat[i] = (uint32_t) i;
-    uint8_t * src = (uint8_t *) t.up(pat.data(), pat.size() * 4); uint32_t * dout = (uint32_t *) t.up(nullptr, 64);
-    if (!src || !dout) return fail("device alloc/copy failed");
-    HIPC(hipMemset(dout, 0, 64));
-    if (bamd_wse_selftest_launch(src, dout, nullptr)) return fail("selftest launch refused");
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(out, dout, 32, hipMemcpyDeviceToHost));
-    return 0;
-}
-// The engine's plan for a model of the given shape, without a device: fake stream addresses (matrix i of layer l at a synthetic base), one row of 16
-// int64 per (CU, op): {cu, kind, type, src, nb, ntask, row0, nvalid, gs0, rps, grec0, act, actbuf, epi, in_vec << 8 | in_tag, out_vec << 8 | out_tag}.
-// head: out[0..7] = {rc, n_cu, ops_per_cu, ns, tr, nc, lds_bytes, rows}.  Returns rows written (<= cap_rows), -1 when the plan fails (bamd_last_error).
-extern "C" __attribute__((visibility("default"))) int bamd_wse_plan_describe(int n_cu, int E, int H, int Hkv, int hd, int F, int L, int V, const int * types7, int head_type, int n_ctx, int nc,
-                                                                             int64_t * head, int64_t * rows, int cap_rows) {
-    std::vector<bamd_wse_layer> Ls((size_t) L);
-    uint64_t base = 1ull << 20;
-    auto mk = [&](bamd_wse_mat & w, int type, int nrows, int K) {
-        w.type = type; w.nrows = nrows; w.nrows_pad = (nrows + 7) / 8 * 8; w.K = K; w.stream = base;
-        base += (bamd_stream_bytes(type, K, w.nrows_pad) + 4095) / 4096 * 4096 + 4096;
-    };
-    const int Ekv = Hkv * hd;
-    for (int l = 0; l < L; ++l) {
-        bamd_wse_layer & y = Ls[(size_t) l];
-        mk(y.wq, types7[0], E, E); mk(y.wk, types7[1], Ekv, E); mk(y.wv, types7[2], Ekv, E); mk(y.wo, types7[3], E, E);
-        mk(y.wg, types7[4], F, E); mk(y.wu, types7[5], F, E); mk(y.wd, types7[6], E, F);
-        y.attn_norm = 16; y.ffn_norm = 16;
-    }
-    bamd_wse_mat hm; if (head_type) mk(hm, head_type, V, E);
-    bamd_wse_plan plan;
-    const int ld = std::min(512, (n_ctx + 63) / 64 * 64);
-    const int rc = bamd_wse_plan_build(&plan, Ls.data(), 0, L, n_cu, E, H, Hkv, hd, F, head_type ? &hm : nullptr, 16, V, (size_t) ld * 8 + (size_t) 3 * hd * 4, nc, BAMD_WSE_LDS_LIMIT);
-    if (rc) { fail(std::string("weight-stream engine plan: ") + plan.why); return -1; }
-    int n = 0;
-    for (int c = 0; c < plan.n_cu; ++c)
-        for (int i = 0; i < plan.ops_per_cu; ++i) {
-            const bamd_wse_op & o = plan.ops[(size_t) c * plan.ops_per_cu + i];
-            if (o.kind == BAMD_WSE_END) break;
-            if (n < cap_rows) {
-                int64_t * r = rows + (size_t) n * 16;
-                r[0] = c; r[1] = o.kind; r[2] = o.type; r[3] = (int64_t) o.src; r[4] = o.nb; r[5] = o.ntask; r[6] = o.row0; r[7] = o.nvalid; r[8] = o.gs0; r[9] = o.rps; r[10] = o.grec0;
-                r[11] = o.act; r[12] = o.actbuf; r[13] = o.epi; r[14] = (int64_t) o.in_vec << 8 | o.in_tag; r[15] = (int64_t) o.out_vec << 8 | o.out_tag;
-            }
-            ++n;
-        }
-    head[0] = 0; head[1] = plan.n_cu; head[2] = plan.ops_per_cu; head[3] = plan.ns; head[4] = plan.tr; head[5] = plan.nc; head[6] = (int64_t) plan.lds_bytes; head[7] = n;
-    bamd_wse_plan_free(&plan);
-    return n < cap_rows ? n : cap_rows;
-}
-// Stamps of ONE engine launch of this context's stage at position pos (replayed `replays` times eagerly, the last one read): out [n_cu][tl_ops][8] u64 of
-// the 100 MHz wall clock (events: bamd_wse.h), rows = the ops of a CU's program in order (per layer: qkv, attention, wo, gate, up, down).
-extern "C" __attribute__((visibility("default"))) int bamd_wse_timeline(bamd_context * c, int pos, int replays, unsigned long long * out, int cap_words, int * n_cu, int * tl_ops) {
-    bamd_model * m = c->m;
-    if (!m->with_embd || !m->with_output) return fail("timeline needs a full single-stage model");
-    HIPC(hipSetDevice(m->device));
-    wse_prepare(c);
-    if (!wse_usable(c, 0, pos)) return fail("weight-stream engine not active for this context: " + c->wse.why);
-    hipStream_t s = c->stream;
-    const size_t words = (size_t) c->wse.plan.n_cu * c->wse.plan.tl_ops * 8;
-    if (c->wse.plan.tl_ops > 254) return fail("bamd_wse_timeline: this stage has more timeline rows than the op records index (8-bit slot: <= 42 layers)");
-    if ((size_t) cap_words < words) return fail("bamd_wse_timeline: output buffer too small");
-    OwnedDevMem mem; HIPC(hipMalloc(&mem.p, words * 8));
-    HIPC(hipMemsetAsync(mem.p, 0, words * 8, s));
-    int32_t tok = 1;
-    HIPC(hipMemcpyAsync(c->forced, &tok, 4, hipMemcpyHostToDevice, s));
-    c->wse.tl = (unsigned long long *) mem.p;
-    int rc = 0;
-    for (int r = 0; r < replays && !rc; ++r) {
-        rc = set_state(c, pos, s, false);
-        if (!rc) { enqueue_begin(c, 1, 1, s); rc = enqueue_layers(c, 0, s, nullptr, pos); enqueue_lm_head(c, s, nullptr); }
-    }
-    c->wse.tl = nullptr;
-    if (rc) return rc;
-    HIPC(status_readback(c, s));
-    HIPC(hipStreamSynchronize(s));
-    if (co_gave_up(c)) return 1;
-    HIPC(hipMemcpy(out, mem.p, words * 8, hipMemcpyDeviceToHost));
-    *n_cu = c->wse.plan.n_cu; *tl_ops = c->wse.plan.tl_ops;
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int type, const void * w_raw, int nrows, int k, const float * x, const float * norm_w, float eps,

@@ -15,6 +15,6 @@ for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if any(t in k for t in ("matvec", "attn", "mfma", "quantize", "matmul", "wse")):
+    if any(t in k for t in ("matvec", "attn", "mfma", "quantize", "matmul")):
         print(k[:70], {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=%d" % len(next(iter(d.values()))))
 PY

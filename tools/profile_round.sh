@@ -13,9 +13,6 @@ run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc" -- python bench.p
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prefill/stats" -- python tools/prefill_profile.py 512 > "$O/pstats.out" 2> "$O/pstats.err"
 run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$O/prefill/pmc" -- python tools/prefill_profile.py 512 > "$O/ppmc.out" 2> "$O/ppmc.err"
 run python tools/prefill_bench.py 512 > "$O/prefill_bench.txt" 2>&1
-# the weight-stream engine (BAMD_WSE=1): kernel statistics of the same bench command (round 4: the A/B of profiles/r04_engine_vs_launches.txt)
-mkdir -p "$O/wse_stats"
-BAMD_WSE=1 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/wse_stats" -- python bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-secondary > "$O/bench_wse_under_rocprof.json" 2> "$O/wse_stats.err"
 if [ -f "$R/booster_amd/lib/libbooster_amd_timing.so" ]; then
     ( cd "$R" && BAMD_LIB=booster_amd/lib/libbooster_amd_timing.so timeout 300 python tools/timeline.py 200 "$O/timeline.json" ) < /dev/null > "$O/timeline.txt" 2>&1
 fi
