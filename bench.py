@@ -43,6 +43,7 @@ MODELS = {"8b": ("Llama-3-8B Q4_K_M", CFG_8B, "bamd_llama3_8b_q4_k_m_synth.gguf"
           "m7q6k": ("Mistral-7B Q6_K", CFG_M7, "bamd_mistral7b_q6_k_synth.gguf")}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 N_PROMPT, N_CTX = 128, 512
+from booster_amd.pipeline import SCALING_NOTE  # noqa: E402  (host-side text only)
 KV_BYTES_PER_POS = 2 * 32 * 8 * 128 * 2
 
 
@@ -314,10 +315,10 @@ def main():
         kv_bytes_per_pos = 2 * CFG["L"] * CFG["Hkv"] * (CFG["E"] // CFG["H"]) * 2
         bytes_per_token = m.weight_bytes + kv_bytes_per_pos * n_kv_avg
         result = dict(
-            value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="weak",
+            value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="strong",      # the same word on every line: one sequence, total work fixed as N grows (config.scaling_note)
             config=dict(workload="%s shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
                                  "128-token prompt, n_ctx %d, n_kv %d..%d" % (model_name, n_ctx, N_PROMPT + warmup, n_past),
-                        parallelism="single GPU", repeats=repeats, graph_event_ms_per_step=round(ev_ms / steps, 4),
+                        parallelism="single GPU", scaling_note=SCALING_NOTE, repeats=repeats, graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),

@@ -38,7 +38,7 @@ struct JanusParams { int32_t janus = 1, depth = 200; float scale = 0.96f, hi = 0
 // micro-batch k + 1 while stage s + 1 still reads micro-batch k from the other buffer — the prompt pipelines across the stages the way the
 // reference's scheduler does with its input copies (GGML_SCHED_MAX_COPIES, cpp/ggml/src/ggml-backend.c:1030, :1751-1844)
 struct Stage {
-    bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0; void * hidden_in[2] = { nullptr, nullptr }; hipEvent_t done[2] = { nullptr, nullptr };
+    bamd_model * model = nullptr; bamd_context * ctx = nullptr; int device = 0, vdevice = 0, layer_first = 0, layer_last = 0; void * hidden_in[2] = { nullptr, nullptr }; hipEvent_t done[2] = { nullptr, nullptr };
     void * stream() const { return bamd_context_stream(ctx); }
 };
 
@@ -526,6 +526,7 @@ static void * init_context_impl(int idx, char * modelName, int batch_size, int g
     pod->jp.janus = janus; pod->jp.depth = depth; pod->jp.scale = scale; pod->jp.hi = hi; pod->jp.lo = lo;
     for (size_t s = 0; s < plan.size(); ++s) {
         Stage st; st.device = ndev_plan != ndev ? plan[s].first % ndev : plan[s].first;
+        st.vdevice = plan[s].first; st.layer_first = plan[s].second.first; st.layer_last = plan[s].second.second;
         if (st.device >= ndev) { fprintf(stderr, "initContext: gpu%d requested but only %d HIP device(s) present\n", st.device + 1, ndev); return nullptr; }
         const bool first = s == 0, last = s + 1 == plan.size();
         st.model = bamd_model_load(path.c_str(), st.device, plan[s].second.first, plan[s].second.second, first, last);
@@ -702,6 +703,12 @@ BAMD_API int bamd_bridge_tokenize(void * ctx, const char * text, int add_special
     const std::vector<int> t = p.vocab.tokenize(text, add_special != 0, parse_special != 0);
     for (int i = 0; i < (int) t.size() && i < cap; ++i) out[i] = t[(size_t) i];
     return (int) t.size();
+}
+// test hook: the stages a pod was split into — {device of the plan (virtual or real), layer_first, layer_last} per stage (what plan_stages + BOOSTER_GPUS + BAMD_VIRTUAL_DEVICES produced)
+BAMD_API int bamd_bridge_stage_layout(void * ctx, int32_t * out, int cap_stages) {
+    Pod & p = *(Pod *) ctx;
+    for (size_t s = 0; s < p.stages.size() && (int) s < cap_stages; ++s) { out[3 * s] = p.stages[s].vdevice; out[3 * s + 1] = p.stages[s].layer_first; out[3 * s + 2] = p.stages[s].layer_last; }
+    return (int) p.stages.size();
 }
 BAMD_API const char * bamd_bridge_token_to_piece(void * ctx, int id, int * len) {
     Pod & p = *(Pod *) ctx; const std::string & s = p.vocab.token_to_piece(id); if (len) *len = (int) s.size(); return s.c_str();

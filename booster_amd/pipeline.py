@@ -173,6 +173,11 @@ class FakeStage:
     def sync(self): pass
 
 
+# bench.py's "scaling" field is "strong" on every line (one sequence, the total work fixed as N grows); what the 1 -> 8 curve of a batch-1 layer split can look like:
+SCALING_NOTE = ("batch-1 layer split: the N stages work one after another on ONE sequence, so value is flat (minus one hop per boundary) from 1 to 8 GPUs by "
+                "construction - Booster's gpus: split buys capacity, not batch-1 speed; a flat curve is the expected result, not a failed strong-scaling run "
+                "(pods_tokens_per_s is the rate with every stage busy)")
+
 PREFILL_CAP = 512                                    # the reference's n_batch / n_ubatch: prompt positions per micro-batch (llama.cpp:16945-16960)
 
 
@@ -360,6 +365,7 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
     value = steps / dt_single
     stage.close()
     return dict(value=round(value, 2), ms_per_step=round(dt_single / steps * 1e3, 4), scaling="strong",
+                cpu_baseline=dict(value=None, unit="tokens/s", cores=0, kind="reference", skipped="timed on rank 0 at N = 1 only (bench contract); see the N = 1 line"),
                 config=dict(workload="%s shapes (synthetic GGUF), greedy batch-1 decode of ONE sequence, layer-split over %d MI355X "
                                      "(Booster's gpus: split), 128-token prompt, n_ctx %d" % (model_name, N, n_ctx),
                             parallelism="layer-split pp%d, one RCCL send/recv of the f32 hidden state [n_embd] per boundary per token" % N,
@@ -368,21 +374,27 @@ def run_layer_split_bench(path, cfg, N, rank, local, prompt, n_ctx, warmup, step
                             sum_of_stage_ms=round(sum(d["ms_per_token"] for d in stages), 4),
                             pods_tokens_per_s=round(N * steps / dt_pods, 2),
                             note="value = one request through all stages (stages idle in turn: the reference's batch-1 behaviour); "
-                                 "pods_tokens_per_s = N independent sequences in flight, every stage busy"),
+                                 "pods_tokens_per_s = N independent sequences in flight, every stage busy",
+                            scaling_note=SCALING_NOTE),
                 roofline=dict(bound="hbm", achieved=slow["achieved_GBps"], peak=8000.0, unit="GB/s", frac=round(slow["achieved_GBps"] / 8000.0, 4), traffic=None,
                               kernel="slowest stage: weight bytes of its layer slice / its stage time per token (HIP events on the stage stream)",
                               stages=stages))
 
 
-def run_plumbing_check(N, rank, prompt, warmup, steps, dist, stage_cls, n_layer=5):
+def run_plumbing_check(N, rank, prompt, warmup, steps, dist, stage_cls, n_layer=None):
     """bench.py --backend gloo: everything of the N > 1 leg EXCEPT the GPU stage — launch, rendezvous, layer ranges, the round schedule with its
-    two-phase use (warm-up, then K timed steps from the carried token), max-over-ranks timing, rank 0's JSON — on a deterministic CPU stand-in
-    for the stage (tests/test_pipeline_gloo.py: FakeStage).  `value` is the stand-in's rate and means nothing; `config.fed_tokens` lets the
-    test compare the pipelined tokens with a sequential evaluation."""
+    two-phase use (warm-up, then K timed steps from the carried token), the group-size check, max-over-ranks timing, rank 0's JSON — on a deterministic
+    CPU stand-in for the stage (FakeStage).  `value` is the stand-in's rate and means nothing; `config.fed_tokens` lets the test compare the pipelined
+    tokens with a sequential evaluation.  N <= 2: five layers split evenly (the round-3 test's shape); beyond: 10 layers per rank split by
+    split_layers_balanced, i.e. the 80-layer / 8-stage schedule of BASELINE config 4 at N = 8."""
     import torch
-    ranges = split_layers(n_layer, N)
+    if n_layer is None:
+        n_layer = 5 if N <= 2 else 10 * N
+    ranges = split_layers(n_layer, N) if N <= 2 else split_layers_balanced(n_layer, N, head_cost=1.3)
     stage = stage_cls(list(range(*ranges[rank])), rank == 0, rank == N - 1)
     dist.barrier()
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)                  # "the group saw N ranks", measured (the nccl leg reports the same two fields as rccl_*)
     fed = run_pipeline(stage, dist, rank, N, prompt, warmup + 1, 1)
     pos0 = len(prompt) + warmup
     carry = [fed[0][-1] if rank == 0 else 0]
@@ -394,7 +406,10 @@ def run_plumbing_check(N, rank, prompt, warmup, steps, dist, stage_cls, n_layer=
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    why = "plumbing check on CPU (gloo, stand-in stage): nothing is measured"
     return dict(value=round(steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="strong",
                 config=dict(workload="PLUMBING CHECK on CPU (gloo): the layer-split schedule over %d ranks with a deterministic stand-in stage — not a measurement" % N,
-                            parallelism="layer-split pp%d" % N, gloo_ranks=N, layer_ranges=ranges, fed_tokens=(fed[0] + fed2[0]) if rank == 0 else []),
-                roofline=None)
+                            parallelism="layer-split pp%d" % N, gloo_ranks=N, group_world=dist.get_world_size(), group_allreduce_of_ones=float(ones.item()),
+                            n_layer=n_layer, layer_ranges=ranges, fed_tokens=(fed[0] + fed2[0]) if rank == 0 else []),
+                roofline=dict(bound="hbm", achieved=None, peak=8000.0, unit="GB/s", frac=None, traffic=None, skipped=why),
+                cpu_baseline=dict(value=None, unit="tokens/s", cores=0, kind="reference", skipped=why))

@@ -160,6 +160,10 @@ void bamd_janus_test_free(void * janus);
 int bamd_bridge_sample_test(void * ctx, const float * logits, const int32_t * last, int n_last, int prompt_len, int pos, int max, uint32_t seed,
                             int device, float * logits_after, int64_t * counts);
 
+/* Test hook: the stages initContext split a pod into (Booster's gpus: rule, BOOSTER_GPUS, BAMD_VIRTUAL_DEVICES): out[3 s .. 3 s + 2] = {device of the plan,
+ * first layer, last layer + 1} for up to cap_stages stages; returns the number of stages. */
+int bamd_bridge_stage_layout(void * ctx, int32_t * out, int cap_stages);
+
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
  * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */

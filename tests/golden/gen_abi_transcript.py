@@ -17,6 +17,9 @@ sys.path.insert(0, ROOT)
 from booster_amd import gguf  # noqa: E402
 
 MODEL = dict(E=512, H=4, Hkv=1, L=3, F=768, seed=21)
+# round 6: the same session on a SIXTEEN-layer model (abi_transcript_l16.json), deep enough for Booster's split over eight devices
+# (BOOSTER_GPUS with eight weights: seven hand-offs per evaluation) — tests/test_gpu_bridge.py::test_reference_abi_transcript_eight_stages
+MODEL_L16 = dict(E=512, H=4, Hkv=1, L=16, F=768, seed=23)
 N_VOCAB = 30100      # the reference's initJanus indexes its Llama-2 id table without bounds: the vocabulary must cover it (tests/golden/gen_janus_kats.py)
 
 
@@ -46,7 +49,7 @@ def script():
     ]
 
 
-def main():
+def main(MODEL=MODEL, out_name="abi_transcript.json"):
     vocab = gguf.synthetic_janus_vocab(N_VOCAB)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "bridge.gguf")
@@ -57,10 +60,11 @@ def main():
         r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "bridge_ref"), path, sp], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
     out = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(out) == len(lines), (len(out), len(lines))
-    json.dump(dict(model=MODEL, n_vocab=N_VOCAB, script=lines, results=out), open(os.path.join(HERE, "abi_transcript.json"), "w"), indent=0)
+    json.dump(dict(model=MODEL, n_vocab=N_VOCAB, script=lines, results=out), open(os.path.join(HERE, out_name), "w"), indent=0)
     for l, o in zip(lines, out):
         print(l[:40].ljust(42), {k: (bytes.fromhex(v)[:60] if k == "hex" else v) for k, v in o.items() if k not in ("op", "job")})
 
 
 if __name__ == "__main__":
     main()
+    main(MODEL_L16, "abi_transcript_l16.json")

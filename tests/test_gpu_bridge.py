@@ -33,11 +33,21 @@ def lib(bamd):
     return bind(bamd)
 
 
-def make_model(tmp_path, name):
+def make_model(tmp_path, name, L=3):
     vocab = gguf.synthetic_spm_vocab()
     p = str(tmp_path / name)
-    gguf.write_synthetic_llama(p, E=512, H=4, Hkv=1, L=3, F=768, V=len(vocab["tokens"]), seed=21, vocab=vocab)
+    gguf.write_synthetic_llama(p, E=512, H=4, Hkv=1, L=L, F=768, V=len(vocab["tokens"]), seed=21, vocab=vocab)
     return p, vocab
+
+
+EIGHT_GPUS_L16 = "3,2,2,2,2,2,2,2"          # sixteen layers + the output layer over eight devices: 3 | 2 | 2 | 2 | 2 | 2 | 2 | 1 + output
+
+
+def stage_layout(lib, ctx):
+    out = np.zeros(3 * 8, np.int32)
+    lib.bamd_bridge_stage_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    n = lib.bamd_bridge_stage_layout(ctx, out.ctypes.data_as(C.c_void_p), 8)
+    return [tuple(int(v) for v in out[3 * s:3 * s + 3]) for s in range(n)]
 
 
 def ctx_args(idx, path, gpus, n_ctx, predict, hi=1.0, lo=1.0):
@@ -189,6 +199,46 @@ def test_long_prompt_pipelines_through_three_stages(lib, bamd, tmp_path, monkeyp
     assert texts[0] == texts[1]
 
 
+def test_long_prompt_pipelines_through_eight_stages(lib, bamd, tmp_path, monkeypatch):
+    """the EIGHT-stage schedule of BASELINE config 4 inside one process — BOOSTER_GPUS with eight weights over eight devices (virtual ones on a
+    one-GPU box: eight stage streams, seven event-ordered hand-off copies per evaluation, double-buffered prompt micro-batches) — on a sixteen-layer model: a prompt
+    of six micro-batches and the generated text equal the single-stage pod's"""
+    path, vocab = make_model(tmp_path, "bridge_l16.gguf", L=16)
+    prompt = (b"the cat sat on the hat and the hen ate the ham " * 120)[:2900]
+    texts = []
+    for pod, gpus in ((0, None), (1, EIGHT_GPUS_L16)):
+        if gpus:
+            monkeypatch.setenv("BOOSTER_GPUS", gpus)
+            if bamd.device_count() < 8:
+                monkeypatch.setenv("BAMD_VIRTUAL_DEVICES", "8")
+        ctx = lib.initContext(*ctx_args(pod, path, (100, 0, 0, 0), 4096, 12))
+        assert ctx
+        lay = stage_layout(lib, ctx)
+        if gpus:
+            assert lay == [(0, 0, 3)] + [(d, 1 + 2 * d, 3 + 2 * d) for d in range(1, 7)] + [(7, 15, 16)], lay
+        else:
+            assert lay == [(0, 0, 16)]
+        job = ("long8-%d" % pod).encode()
+        n = lib.doInference(pod, ctx, job, b"", prompt)
+        assert n > 2048 + 1, "the prompt must span at least five micro-batches (%d evaluations)" % n
+        texts.append((n, lib.status(job)))
+    assert texts[0] == texts[1]
+
+
+@pytest.mark.parametrize("split", ["one stage", "eight stages"])
+def test_reference_abi_transcript_sixteen_layers(lib, bamd, tmp_path, split, monkeypatch):
+    """the same scripted session of the nine symbols recorded from the GENUINE reference bridge on a SIXTEEN-layer model (tests/golden/abi_transcript_l16.json),
+    replayed on one stage and through Booster's split over eight devices (BOOSTER_GPUS=3,2,2,2,2,2,2,2: seven hand-offs per evaluation): every return value,
+    status() text and token count the reference's, unchanged by the split"""
+    if split == "eight stages":
+        monkeypatch.setenv("BOOSTER_GPUS", EIGHT_GPUS_L16)
+        if bamd.device_count() < 8:
+            monkeypatch.setenv("BAMD_VIRTUAL_DEVICES", "8")
+    ctxs = replay_transcript(lib, bamd, tmp_path, "l16" + split[:3], "abi_transcript_l16.json")
+    for c in ctxs.values():
+        assert len(stage_layout(lib, c)) == (8 if split == "eight stages" else 1)
+
+
 @pytest.mark.parametrize("split", ["one stage", "three stages"])
 def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
     """the nine cgo symbols replayed against the transcript recorded from the GENUINE reference bridge
@@ -206,10 +256,10 @@ def test_reference_abi_transcript(lib, bamd, tmp_path, split, monkeypatch):
     replay_transcript(lib, bamd, tmp_path, split[:3])
 
 
-def replay_transcript(lib, bamd, tmp_path, tag):
+def replay_transcript(lib, bamd, tmp_path, tag, fixture="abi_transcript.json"):
     import json
     import os
-    t = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "abi_transcript.json")))
+    t = json.load(open(os.path.join(os.path.dirname(__file__), "golden", fixture)))
     vocab = gguf.synthetic_janus_vocab(t["n_vocab"])
     path = str(tmp_path / "abi.gguf")
     gguf.write_synthetic_llama(path, V=len(vocab["tokens"]), vocab=vocab, **t["model"])
@@ -241,3 +291,4 @@ def replay_transcript(lib, bamd, tmp_path, tag):
             assert (lib.promptEval(("abi-%s-" % tag + p[1]).encode()) >= 0) == bool(want["nonneg"])
         elif op == "genms":
             assert (lib.timing(("abi-%s-" % tag + p[1]).encode()) >= 0) == bool(want["nonneg"])
+    return ctxs

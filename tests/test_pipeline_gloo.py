@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (gloo): the layer-split schedule of booster_amd.pipeline — message order, token feedback, several
+"""CPU, world_size 2 / 4 / 8 (gloo): the layer-split schedule of booster_amd.pipeline — message order, token feedback, several
 sequences in flight — with a CPU stand-in for the GPU stage.  The stand-in is deterministic integer arithmetic, so the
 pipelined result must equal a sequential single-process evaluation."""
 import os
@@ -97,6 +97,62 @@ def test_long_prompt_in_microbatches_world2(n_seq):
     for f in fed:
         assert f == want
     assert calls == [(s, T, i0) for s in range(n_seq) for i0, T in ((0, 512), (512, 512), (1024, 76))]
+
+
+def worker_deep(rank, world, port, n_seq, n_layers, prompt, n_decode, q):
+    """BASELINE config 4's schedule: `n_layers` layers over `world` stages split by split_layers_balanced (the stage that also runs the
+    output layer gets fewer), n_seq sequences in flight"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from booster_amd import pipeline
+    ranges = pipeline.split_layers_balanced(n_layers, world, head_cost=1.3)
+    st = FakeStage(list(range(*ranges[rank])), rank == 0, rank == world - 1)
+    fed = pipeline.run_pipeline(st, dist, rank, world, prompt, n_decode, n_seq)
+    calls = list(st.prefill_calls)
+    if rank == 0:
+        q.put((fed, calls, ranges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_deep(world, n_seq, n_layers, prompt, n_decode, port_base):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = port_base + 10 * world + n_seq + (os.getpid() % 200)
+    procs = [ctx.Process(target=worker_deep, args=(r, world, port, n_seq, n_layers, prompt, n_decode, q)) for r in range(world)]
+    for p in procs: p.start()
+    fed, calls, ranges = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    return fed, calls, ranges
+
+
+@pytest.mark.parametrize("world,n_seq", [(4, 1), (4, 4), (8, 1), (8, 3), (8, 8)])
+def test_eighty_layers_over_four_and_eight_stages(world, n_seq):
+    """the schedule BASELINE config 4 runs — 80 layers over 8 stages (7 boundaries; also 4), 1..8 sequences in flight (fewer than,
+    equal to and — at world 4 — as many as the stages) — gives the tokens of the sequential evaluation.  No schedule beyond world 2 had run anywhere before."""
+    prompt = [3, 1, 4, 1, 5, 9, 2, 6]
+    fed, calls, ranges = run_deep(world, n_seq, 80, prompt, 6, 29700)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 80 and len(ranges) == world
+    if world == 8:
+        assert ranges[-1] == (71, 80) and ranges[0] == (0, 10)           # 10 layers per stage, 9 + the output layer on the last (head cost 1.3 layers)
+    want = reference(prompt, 6, 80)
+    assert len(fed) == n_seq
+    for f in fed:
+        assert f == want
+    assert calls == [(s, 8, 0) for s in range(n_seq)]                   # the 8-token prompt crossed every boundary as ONE [8, n_embd] block per sequence
+
+
+def test_long_prompt_in_microbatches_world8():
+    """a 1100-token prompt = three micro-batches (512 + 512 + 76) per sequence pipelined through EIGHT stages (micro-batch j + 1 enters stage r while j is in r + 1),
+    two sequences, then decode rounds: tokens == sequential"""
+    fed, calls, _ = run_deep(8, 2, 80, LONG_PROMPT, 4, 29800)
+    want = reference(LONG_PROMPT, 4, 80)
+    assert len(fed) == 2
+    for f in fed:
+        assert f == want
+    assert calls == [(s, T, i0) for s in range(2) for i0, T in ((0, 512), (512, 512), (1024, 76))]
 
 
 def test_prompt_microbatches():
