@@ -22,7 +22,7 @@ events around every launch of eager steps; `roofline.per_kind` lists every launc
 `roofline.all_matvec_launches` the average over all weight-streaming launches (the figure round 1 reported); `traffic` is NOT measured in this run: it is the per-launch HBM read bytes of the committed
 rocprofv3 PMC pass (profiles/), quoted for comparison.  `cpu_baseline` times the GENUINE reference CPU path
 (oracle/_ref/ref_bench, built in the build container and shipped prebuilt) on this box's host cores on the same GGUF:
-a 16-token prefill and 32 single-token decode steps, rank 0, N = 1 only.
+a 16-token prefill and 64 single-token decode steps per point of a thread / placement sweep, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -119,25 +119,59 @@ def split_layers(L, n):
     return list(zip(first, cuts))
 
 
-def cpu_baseline_reference(path, nthreads):
+def socket0_cpus():
+    """logical CPUs of physical package 0 that this process may use, one per core first (SMT siblings last): where a pinned run of the reference is placed"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        return []
+    first, rest, seen, cpu, pkg = [], [], set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and pkg == 0 and cpu in allowed:
+                (rest if int(v) in seen else first).append(cpu); seen.add(int(v))
+    except (OSError, ValueError):
+        pass
+    return first + rest
+
+
+def cpu_baseline_reference(path, nthreads, pinned=False, n_decode=64):
     """The GENUINE reference CPU path (oracle/_ref/ref_bench: ggml + llama.cpp of gotzmann/booster compiled in place by
     oracle/Makefile with Booster's `make cpu` flags, -march=x86-64-v3) on the same GGUF, all 32 layers: a 16-token prefill and
-    12 single-token llama_decode steps; the metric is the reference's own t_eval definition.  None if the binary is not there."""
+    n_decode single-token llama_decode steps; the metric is the reference's own t_eval definition (llama.cpp:18527-18551).
+    pinned: OMP_PROC_BIND=close OMP_PLACES=cores, under numactl --cpunodebind=0 --membind=0 where numactl exists, else with the
+    affinity mask cut to the cores of package 0 (when they suffice).  None if the binary is not there."""
     import re
+    import shutil
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     if not os.path.exists(exe):
         return None
-    n_prompt, n_decode = 16, 32
+    n_prompt = 16
     env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
-    out = subprocess.run([exe, path, str(nthreads), str(n_prompt), str(n_decode), "512"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                         timeout=600, env=env, check=True).stdout.decode()
+    cmd, pre, how = [exe, path, str(nthreads), str(n_prompt), str(n_decode), "512"], None, "unpinned"
+    if pinned:
+        env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+        how = "OMP_PROC_BIND=close OMP_PLACES=cores"
+        s0 = socket0_cpus()
+        if shutil.which("numactl") and len(s0) >= nthreads:
+            cmd = ["numactl", "--cpunodebind=0", "--membind=0"] + cmd; how += ", numactl --cpunodebind=0 --membind=0"
+        elif len(s0) >= nthreads:
+            pre = lambda: os.sched_setaffinity(0, set(s0))
+            how += ", affinity = the %d CPUs of package 0" % len(s0)
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env, check=True, preexec_fn=pre).stdout.decode()
     m = re.search(r"tokens_per_s=([0-9.]+) ms_per_token=([0-9.]+) prompt_tokens_per_s=([0-9.]+)", out)
-    return dict(value=round(float(m.group(1)), 4), unit="tokens/s", cores=nthreads, kind="reference",
+    return dict(value=round(float(m.group(1)), 4), unit="tokens/s", cores=nthreads, kind="reference", placement=how,
                 sample="genuine reference CPU path (gotzmann/booster's ggml + llama.cpp built by oracle/Makefile, `make cpu` flags with -march=x86-64-v3) "
-                       "on %d threads of this box's host (%s, %d logical CPUs) on the same GGUF, all layers: %d-token prefill (%.1f tok/s) + %d greedy "
+                       "on %d threads (%s) of this box's host (%s, %d logical CPUs) on the same GGUF, all layers: %d-token prefill (%.1f tok/s) + %d greedy "
                        "single-token llama_decode steps, %.1f ms per token.  Build-container figures for config 1 (128 + 128 tokens, threads = 1 and 8): BASELINE.md section 3"
-                       % (nthreads, cpu_name(), os.cpu_count() or 0, n_prompt, float(m.group(3)), n_decode, float(m.group(2))))
+                       % (nthreads, how, cpu_name(), os.cpu_count() or 0, n_prompt, float(m.group(3)), n_decode, float(m.group(2))))
 
 
 def cpu_baseline(path, nthreads):
@@ -343,19 +377,27 @@ def main():
                 except AttributeError:
                     ncpu = os.cpu_count() or 1
                 phys = physical_cores(ncpu)
-                # the reference's CPU path is memory-bound: sweep the thread count over {32, 64, all physical cores} (bounded: ~3-5 s each) and report the best
-                cands = sorted(set(max(1, min(ncpu, c)) for c in (32, 64, phys)))
-                ref, sweep = None, {}
+                # the reference's best on this box: its OpenMP decode is memory- and barrier-bound and gets SLOWER beyond one socket's worth of
+                # threads, so the sweep covers {8, 16, 24, 32, 48} (and every physical core when that is fewer), each unpinned and pinned to cores of one package;
+                # 64 decode steps per point (~3-8 s each, bounded by `budget`); the best point is the baseline, the whole sweep rides along
+                cands = sorted(set(max(1, min(ncpu, c)) for c in (8, 16, 24, 32, 48) if c <= max(phys, 8)))
+                ref, sweep, t_sweep, budget = None, {}, time.time(), 150.0
                 try:
-                    for c in cands:
-                        r = cpu_baseline_reference(path, c)
-                        if r is None:
-                            break
-                        sweep[str(c)] = r["value"]
-                        if ref is None or r["value"] > ref["value"]:
-                            ref = r
+                    for c in sorted(cands, key=lambda c: abs(c - 32)):           # the likely optimum first: a box that runs out of budget still has it
+                        for pinned in (False, True):
+                            if time.time() - t_sweep > budget:
+                                sweep["%d%s" % (c, "p" if pinned else "")] = "skipped (sweep budget)"
+                                continue
+                            r = cpu_baseline_reference(path, c, pinned)
+                            if r is None:
+                                break
+                            sweep["%d%s" % (c, "p" if pinned else "")] = r["value"]
+                            if ref is None or r["value"] > ref["value"]:
+                                ref = r
                     if ref is not None:
-                        ref["thread_sweep_tokens_per_s"] = sweep; ref["physical_cores"] = phys
+                        ref["thread_sweep_tokens_per_s"] = dict(points=sweep, key="<threads>[p = pinned: OMP_PROC_BIND=close OMP_PLACES=cores on package 0]",
+                                                                seconds=round(time.time() - t_sweep, 1))
+                        ref["physical_cores"] = phys
                 except Exception as e:
                     sys.stderr.write("[bench] reference cpu baseline failed (%r); falling back to the oracle port\n" % (e,))
                     ref = None

@@ -570,6 +570,10 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
     Pod & p = *(Pod *) ctx;
     const std::string job = jobID, text = prompt;
     p.t_p_eval_ms = p.t_eval_ms = 0; p.n_p_eval = p.n_eval = 0; p.eval_open = false;   // llama_reset_timings
+    // an evaluation that no sampler call followed (stopInference during the prompt, the n_ctx - 4 exit, an error return) was never waited for: wait on every
+    // way out, close its timing interval and report a give-up of that evaluation
+    struct OpenEval { Pod & p; bool failed = false; void close() { if (p.eval_open) { if (bamd_synchronize(p.stages[0].ctx)) { fprintf(stderr, "doInference: %s\n", bamd_last_error()); failed = true; } pod_eval_done(p); } }
+                      ~OpenEval() { close(); } } open_eval{ p };
     p.stop.store(false);
     if (!p.janus_ready) { init_janus(p); upload_sampler_tables(p); }                                       // the reference rebuilds (and leaks) the tables per request
     const uint32_t seed = (uint32_t) time(nullptr);
@@ -631,6 +635,8 @@ static int64_t do_inference_impl(int idx, void * ctx, char * jobID, char * promp
         }
         if (p.vocab.is_eog(embd.back())) break;
     }
+    open_eval.close();
+    if (open_eval.failed) return 1;
     std::lock_guard<std::mutex> lk(g_mu);
     Job & j = g_jobs[job];
     j.prompt_eval = p.n_p_eval ? (int64_t) (p.t_p_eval_ms / (double) p.n_p_eval) : 0;

@@ -931,6 +931,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_prefill(bamd_co
     if (ensure_batch_buffers(c)) return 1;
     if (enqueue_prefill_batch(c, n_tokens, n_past, s, hidden_in_dev, hidden_out_dev)) return 1;
     if (m->with_output && want_logits) enqueue_lm_head(c, s, nullptr);
+    {   // a launch the runtime rejected (LDS size, grid) leaves no other trace (bamd_decode checks the same way)
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(le));
+    }
     return 0;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_batch(int on) { g_prefill_batch = on ? 1 : 0; g_prefill_mfma = on == 2 ? 0 : 1; }
@@ -943,6 +947,15 @@ extern "C" __attribute__((visibility("default"))) const float * bamd_get_logits(
         c->logits_host_valid = true;
     }
     return c->logits_host;
+}
+// waits for everything enqueued on the context's stream and reports what a bamd_decode without read-back left pending (the co-launch give-up words): the
+// synchronisation point of a caller that evaluated without sampling afterwards (a request that stops during its prompt, or at n_ctx - 4)
+extern "C" __attribute__((visibility("default"))) int bamd_synchronize(bamd_context * c) {
+    HIPC(hipSetDevice(c->m->device));
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(std::string("bamd_synchronize: ") + hipGetErrorString(e));
+    if (c->status_pending) { c->status_pending = false; if (co_gave_up(c)) return 1; }
+    return 0;
 }
 extern "C" __attribute__((visibility("default"))) void bamd_set_logits_readback(bamd_context * c, int on) { c->logits_readback = on != 0; }
 extern "C" __attribute__((visibility("default"))) void * bamd_context_stream(bamd_context * c) { return (void *) c->stream; }

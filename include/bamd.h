@@ -119,6 +119,9 @@ int bamd_logits_shortlist(bamd_context * c, const bamd_logit_penalty * pen, int 
 void * bamd_context_stream(bamd_context * c);
 /* 0: bamd_decode leaves the logits on the device; bamd_get_logits then copies them on demand (default 1: copied by every decode) */
 void bamd_set_logits_readback(bamd_context * c, int on);
+/* waits for the context's stream and reports what a bamd_decode without read-back left unchecked (llama_synchronize, llama.cpp:18527-18551): for a caller
+ * that evaluates and then does NOT sample (a request stopped during its prompt).  Returns 0 or 1. */
+int bamd_synchronize(bamd_context * c);
 /* test hook: overwrite the device logits (n_vocab floats) */
 int bamd_set_logits_test(bamd_context * c, const float * logits);
 

@@ -299,3 +299,48 @@ def test_stage_prefill_equals_single_stage(bamd, tmp_path):
         c.close()
     for s in stages + [full]:
         s.close()
+
+
+class _NoPrefill:
+    """a HipStage without the batched prompt phase: run_pipeline's hasattr fallback (one token per round)"""
+    def __init__(self, st):
+        self._st = st
+
+    def __getattr__(self, name):
+        if name == "prefill":
+            raise AttributeError(name)
+        return getattr(self._st, name)
+
+
+def test_pipeline_prompt_phase_on_real_kernels(bamd, tmp_path):
+    """booster_amd.pipeline's batched prompt phase on the REAL stage (HipStage.prefill -> bamd_stage_prefill) against the one-token-per-round path and
+    the plain level-1 evaluation: a 513-token prompt = a 512-position micro-batch + a ONE-token tail (bamd_stage_prefill declines T = 1: the per-token fallback
+    inside HipStage.prefill), a 1100-token prompt = three micro-batches, and the same with the batched kernels switched off (every micro-batch takes the fallback)"""
+    import os
+    import torch
+    from booster_amd import pipeline
+    if os.environ.get("BAMD_ATTN_FUSED") == "0" or os.environ.get("BAMD_PREFILL_BATCH") == "0":
+        pytest.skip("the batched prefill kernels are switched off by the environment")
+    p = str(tmp_path / "syn_pp.gguf")
+    gguf.write_synthetic_llama(p, E=1024, H=8, Hkv=2, L=3, F=2048, V=512, seed=13)
+    n_ctx = 1280
+    for n_prompt in (513, 1100):
+        prompt = [(37 * i + 11) % 512 for i in range(n_prompt)]
+        m = bamd.Model(p); ctx = bamd.Context(m, n_ctx)
+        for i in range(0, n_prompt, 512):
+            lg = ctx.decode(prompt[i:i + 512], i)
+        want, n_past = [], n_prompt
+        for _ in range(5):
+            t = int(np.argmax(lg)); want.append(t)
+            lg = ctx.decode([t], n_past); n_past += 1
+        ctx.close(); m.close()
+        for mode in ("batched", "no prefill method", "batched kernels off"):
+            st = pipeline.HipStage(bamd, torch, p, 0, (0, 3), True, True, n_ctx, 1)
+            if mode == "batched kernels off":
+                bamd.set_prefill_batch(False)
+            try:
+                fed = pipeline.run_pipeline(_NoPrefill(st) if mode == "no prefill method" else st, None, 0, 1, prompt, 5, 1)
+            finally:
+                bamd.set_prefill_batch(True)
+                st.close()
+            assert fed[0] == want, "%d-token prompt, %s" % (n_prompt, mode)
