@@ -378,13 +378,13 @@ def main():
                     ncpu = os.cpu_count() or 1
                 phys = physical_cores(ncpu)
                 # the reference's best on this box: its OpenMP decode is memory- and barrier-bound and gets SLOWER beyond one socket's worth of
-                # threads, so the sweep covers {8, 16, 24, 32, 48} (and every physical core when that is fewer), each unpinned and pinned to cores of one package;
+                # threads, so the sweep covers {8, 16, 24, 32, 48} each unpinned and pinned to cores of one package, plus 12 and 20 unpinned around the optimum measured in round 6;
                 # 64 decode steps per point (~3-8 s each, bounded by `budget`); the best point is the baseline, the whole sweep rides along
-                cands = sorted(set(max(1, min(ncpu, c)) for c in (8, 16, 24, 32, 48) if c <= max(phys, 8)))
+                cands = sorted(set(max(1, min(ncpu, c)) for c in (8, 12, 16, 20, 24, 32, 48) if c <= max(phys, 8)))
                 ref, sweep, t_sweep, budget = None, {}, time.time(), 150.0
                 try:
-                    for c in sorted(cands, key=lambda c: abs(c - 32)):           # the likely optimum first: a box that runs out of budget still has it
-                        for pinned in (False, True):
+                    for c in sorted(cands, key=lambda c: abs(c - 18)):           # the likely optimum first (round 6, 2 x EPYC 9575F: 16 threads unpinned 34.9 tok/s, 32: 19.6): a box that runs out of budget still has it
+                        for pinned in ((False,) if c in (12, 20) else (False, True)):
                             if time.time() - t_sweep > budget:
                                 sweep["%d%s" % (c, "p" if pinned else "")] = "skipped (sweep budget)"
                                 continue
