@@ -352,7 +352,8 @@ def main():
             value=round(tok_s, 2), ms_per_step=round(dt / steps * 1e3, 4), scaling="strong",      # the same word on every line: one sequence, total work fixed as N grows (config.scaling_note)
             config=dict(workload="%s shapes (synthetic GGUF, random K-quant blocks), greedy batch-1 decode on 1xMI355X, "
                                  "128-token prompt, n_ctx %d, n_kv %d..%d" % (model_name, n_ctx, N_PROMPT + warmup, n_past),
-                        parallelism="single GPU", scaling_note=SCALING_NOTE, repeats=repeats, graph_event_ms_per_step=round(ev_ms / steps, 4),
+                        parallelism="single GPU", scaling_note=SCALING_NOTE, repeats=repeats,
+                        aql_runs=ctx.aql_runs(), replay=("AQL packets, fence scope NONE, own HSA queue (csrc/bamd_aql.h)" if ctx.aql_runs() > 0 else "one hipGraph per step on a HIP stream"), graph_event_ms_per_step=round(ev_ms / steps, 4),
                         bytes_per_token=int(bytes_per_token), frac_of_hbm_roofline_tokens=round(tok_s * bytes_per_token / (HBM_PEAK_GBS * 1e9), 4),
                         time_split_ms_per_token=dict(matvec=round(MS_[0] / reps - L_[0] / reps * ev_overhead_ms, 4), attention=round(MS_[1] / reps - L_[1] / reps * ev_overhead_ms, 4),
                                                      other=round(max(MS_[2] / reps - L_[2] / reps * ev_overhead_ms, 0.0), 4)),

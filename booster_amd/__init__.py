@@ -65,6 +65,8 @@ def lib():
         L.bamd_op_get_row.argtypes = [ci, vp, ci, ci, ci, vp]
         L.bamd_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.bamd_op_rope_row.argtypes = [ci, ci, cf, cf, vp, vp]
+        L.bamd_set_aql.argtypes = [ci]; L.bamd_set_aql.restype = None
+        L.bamd_aql_runs.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -86,6 +88,12 @@ def set_prefill_batch(on):
 def set_prefill_version(v):
     """2 (default): the round-5 matrix-core prefill kernels (bamd_prefill2.hip, load-time side tables); 1: the round-2 kernels (bamd_prefill.hip).  Same bits."""
     lib().bamd_set_prefill_version(int(v))
+
+
+def set_aql(on):
+    """True (default): Context.generate_greedy replays the step as AQL packets with fence scope NONE on the library's own HSA queue (csrc/bamd_aql.h) where it
+    can; False: one hipGraph per step on the context's HIP stream.  Same kernels, same bits.  Takes effect at the next generate_greedy call."""
+    lib().bamd_set_aql(int(bool(on)))
 
 
 def device_count():
@@ -147,6 +155,10 @@ class Context:
         ms = C.c_float(0)
         _chk(lib().bamd_generate_greedy(self.h, n_past, n_steps, _p(out), C.byref(ms)))
         return out, float(ms.value)
+
+    def aql_runs(self):
+        """generate_greedy calls of this context that ran on the own AQL queue so far"""
+        return int(lib().bamd_aql_runs(self.h))
 
     def last_logits(self):
         return np.ctypeslib.as_array(lib().bamd_get_logits(self.h), shape=(self.model.n_vocab,)).copy()

@@ -24,8 +24,8 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 #define BAMD_QK_PREFETCH(t0_) do { \
         _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) { \
             int i_ = ((t0_) + j * (int) gridDim.y) * 64 + (int) (threadIdx.x >> 6) * 8 + (int) ((threadIdx.x & 63) >> 3); i_ = i_ < (SH ? n_kv : pos) ? i_ : 0; \
-            const unsigned short * kr_ = a.kc + (size_t) i_ * Ekv + hk * hd + (int) (threadIdx.x & 7) * L; \
-            _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = *(const uint4 *) (kr_ + g * 8); \
+            const unsigned short * kr_ = a.kc + (size_t) i_ * Ekv + hk * hd + (int) (threadIdx.x & 7) * 8; \
+            _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = *(const uint4 *) (kr_ + g * BAMD_KGRP); \
         } } while (0)
     BAMD_QK_PREFETCH((int) blockIdx.y);
     const float * rope = a.rope + (size_t) pos * hd;
@@ -55,11 +55,11 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     kreg[g] = make_uint4(0, 0, 0, 0);
-                    if (g < LG) { const uint4 own = *(const uint4 *) (k16t + e * L + g * 8); kreg[g] = i == cell ? own : kpre[j][g < LG ? g : 0]; }
+                    if (g < LG) { const uint4 own = *(const uint4 *) (k16t + g * BAMD_KGRP + e * 8); kreg[g] = i == cell ? own : kpre[j][g < LG ? g : 0]; }
                 }
 #pragma unroll
                 for (int g = 0; g < GQ; ++g) {
-                    const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * L) : kq_chain<false>(kreg, L, qt + g * hd + e * L, nullptr);
+                    const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * 8) : kq_chain<false>(kreg, L, qt + g * hd + e * 8, nullptr);
                     sc[j][g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
                 }
             }
@@ -416,13 +416,13 @@ __global__ void __launch_bounds__(512) attn_batch_kernel(bamd_attn_args a, int g
         const bool valid = i < n_kv && i <= pos;
         // unconditional requests (a masked position reads row `pos`, which this micro-batch stored), every chain runs, the mask is a select:
         // a conditional load is a branch with a full wait at its join
-        const unsigned short * krow = a.kc + (size_t) (valid ? i : pos) * Ekv + hk * hd + e * L;
+        const unsigned short * krow = a.kc + (size_t) (valid ? i : pos) * Ekv + hk * hd + e * 8;
         uint4 kl[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) kl[g] = g * 8 < L ? *(const uint4 *) (krow + g * 8) : make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) kl[g] = g * 8 < L ? *(const uint4 *) (krow + g * BAMD_KGRP) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int hh = 0; hh < GQH; ++hh) {
-            float v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * L));
+            float v = hsum8_vecdot(kq_chain<true>(kl, L, nullptr, &q16t[hh][0] + e * 8));
             v = valid ? v : -INFINITY;                             // masked (KQ_mask, llama.cpp:14152-14200)
             if (e == 0 && i < n_kv) sc[(size_t) hh * ld + i] = v;
         }
@@ -551,15 +551,15 @@ __global__ void __launch_bounds__(1024) k_shift_kernel(unsigned short * kc, int 
 }
 void bamd_launch_k_shift(unsigned short * kc, int n_cells, int Hkv, int hd, const int32_t * tab_of_cell, const float * tab, hipStream_t s) {
     int nt = Hkv * hd / 2; if (nt > 1024) nt = 1024; nt = (nt + 63) & ~63;
-    hipLaunchKernelGGL(k_shift_kernel, dim3(n_cells), dim3(nt), 0, s, kc, Hkv, hd, tab_of_cell, tab);
+    BAMD_LAUNCH(k_shift_kernel, dim3(n_cells), dim3(nt), 0, s, kc, Hkv, hd, tab_of_cell, tab);
 }
 
 static void launch_attn_fused(const bamd_attn_args & a, int gq, dim3 grid, size_t lds, hipStream_t s) {
     switch (a.hd >> 6) {                                       // head_dim 64 / 128 / 192 / 256 (checked by the callers)
-        case 1: hipLaunchKernelGGL((attn_fused_kernel<1>), grid, dim3(512), lds, s, a, gq); break;
-        case 2: hipLaunchKernelGGL((attn_fused_kernel<2>), grid, dim3(512), lds, s, a, gq); break;
-        case 3: hipLaunchKernelGGL((attn_fused_kernel<3>), grid, dim3(512), lds, s, a, gq); break;
-        default: hipLaunchKernelGGL((attn_fused_kernel<4>), grid, dim3(512), lds, s, a, gq); break;
+        case 1: BAMD_LAUNCH((attn_fused_kernel<1>), grid, dim3(512), lds, s, a, gq); break;
+        case 2: BAMD_LAUNCH((attn_fused_kernel<2>), grid, dim3(512), lds, s, a, gq); break;
+        case 3: BAMD_LAUNCH((attn_fused_kernel<3>), grid, dim3(512), lds, s, a, gq); break;
+        default: BAMD_LAUNCH((attn_fused_kernel<4>), grid, dim3(512), lds, s, a, gq); break;
     }
 }
 
@@ -568,7 +568,7 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     const int ld = a.lds_ld ? a.lds_ld : a.n_ctx;
     if (a.hd > 256 || (a.hd & 63) || (ld & 63) || (size_t) ld * 8 > BAMD_ATTN_LDS_MAX || !a.batch) return 1;
     if (gq < 1 || gq > 8) return 1;
-    hipLaunchKernelGGL(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
+    BAMD_LAUNCH(kv_store_batch_kernel, dim3(a.Hkv, T), dim3(256), 0, s, a);
     if (bamd_launch_attention_batch_mfma(a, gq, T, s) == 0) return 0;        // head_dim 128 (beyond 512 positions with a.batch_scratch): the matrix-core kernel (bamd_attention_mfma.hip)
     // as many query heads of a KV head per workgroup as have their score rows fit the LDS (ld floats each: the probabilities replace
     // the scores in place); a single head per workgroup runs on attn_fused_kernel (separate rows: 2 x ld floats)
@@ -576,9 +576,9 @@ int bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStre
     while (gqh > 1 && (size_t) gqh * ld * 4 > BAMD_ATTN_LDS_MAX) gqh >>= 1;
     const size_t lds_g = (size_t) gqh * ld * 4;
     const dim3 grid(a.Hkv * gq / (gqh > 1 ? gqh : 1), T);
-    if (gqh == 8)      hipLaunchKernelGGL((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
-    else if (gqh == 4) hipLaunchKernelGGL((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
-    else if (gqh == 2) hipLaunchKernelGGL((attn_batch_kernel<2>), grid, dim3(512), lds_g, s, a, gq);
+    if (gqh == 8)      BAMD_LAUNCH((attn_batch_kernel<8>), grid, dim3(512), lds_g, s, a, gq);
+    else if (gqh == 4) BAMD_LAUNCH((attn_batch_kernel<4>), grid, dim3(512), lds_g, s, a, gq);
+    else if (gqh == 2) BAMD_LAUNCH((attn_batch_kernel<2>), grid, dim3(512), lds_g, s, a, gq);
     else launch_attn_fused(a, gq, dim3(a.Hkv * gq, T), (size_t) ld * 8, s);
     return 0;
 }
@@ -595,7 +595,7 @@ template <int G> static bool spv_launch(const bamd_attn_args & a, hipStream_t s)
     constexpr int Z = (G & 1) ? 1 : 2, NH = G / Z;
     if (!spv_ok<G>(a)) return false;
     const size_t lds = (size_t) NH * a.n_ctx * 4 + BAMD_SPV_SLACK, vcb = (size_t) a.Hkv * a.hd * a.n_ctx * 2;
-    hipLaunchKernelGGL((attn_spv_kernel<(NH == 1 || NH == 2 || NH == 4) ? NH : 1>), dim3(a.Hkv, a.hd / 8, Z), dim3(1024), lds, s, a, G, (uint32_t) vcb);
+    BAMD_LAUNCH((attn_spv_kernel<(NH == 1 || NH == 2 || NH == 4) ? NH : 1>), dim3(a.Hkv, a.hd / 8, Z), dim3(1024), lds, s, a, G, (uint32_t) vcb);
     return true;
 }
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
@@ -614,20 +614,20 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     switch (gq) {
 #define CASE(G) case G: \
         if (a.cellpos) switch (a.hd >> 6) { \
-            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1, true>), g1, dim3(512), 0, s, a); break; \
-            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2, true>), g1, dim3(512), 0, s, a); break; \
-            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3, true>), g1, dim3(512), 0, s, a); break; \
-            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, true>), g1, dim3(512), 0, s, a); break; \
+            case 1: BAMD_LAUNCH((attn_qk_kernel<G, 1, true>), g1, dim3(512), 0, s, a); break; \
+            case 2: BAMD_LAUNCH((attn_qk_kernel<G, 2, true>), g1, dim3(512), 0, s, a); break; \
+            case 3: BAMD_LAUNCH((attn_qk_kernel<G, 3, true>), g1, dim3(512), 0, s, a); break; \
+            default: BAMD_LAUNCH((attn_qk_kernel<G, 4, true>), g1, dim3(512), 0, s, a); break; \
         } else switch (a.hd >> 6) { \
-            case 1: hipLaunchKernelGGL((attn_qk_kernel<G, 1, false>), g1, dim3(512), 0, s, a); break; \
-            case 2: hipLaunchKernelGGL((attn_qk_kernel<G, 2, false>), g1, dim3(512), 0, s, a); break; \
-            case 3: hipLaunchKernelGGL((attn_qk_kernel<G, 3, false>), g1, dim3(512), 0, s, a); break; \
-            default: hipLaunchKernelGGL((attn_qk_kernel<G, 4, false>), g1, dim3(512), 0, s, a); break; \
+            case 1: BAMD_LAUNCH((attn_qk_kernel<G, 1, false>), g1, dim3(512), 0, s, a); break; \
+            case 2: BAMD_LAUNCH((attn_qk_kernel<G, 2, false>), g1, dim3(512), 0, s, a); break; \
+            case 3: BAMD_LAUNCH((attn_qk_kernel<G, 3, false>), g1, dim3(512), 0, s, a); break; \
+            default: BAMD_LAUNCH((attn_qk_kernel<G, 4, false>), g1, dim3(512), 0, s, a); break; \
         } \
         if (spv_launch<G>(a, s)) break; \
-        hipLaunchKernelGGL(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
-        if ((G & 1) == 0) hipLaunchKernelGGL(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2)), 0, s, a, gq); /* even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128) */ \
-        else hipLaunchKernelGGL(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \
+        BAMD_LAUNCH(attn_softmax_kernel, dim3(a.Hkv * G), dim3(1024), 0, s, a); \
+        if ((G & 1) == 0) BAMD_LAUNCH(attn_pv_kernel, dim3(a.Hkv, a.hd / 8, 2), dim3(64 * (G / 2)), 0, s, a, gq); /* even ratios: two workgroups per KV head (all 256 CUs at Hkv x hd/8 = 128) */ \
+        else BAMD_LAUNCH(attn_pv_kernel, g3, dim3(64 * G), 0, s, a, gq); \
         break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE

@@ -71,16 +71,16 @@ __global__ void __launch_bounds__(64 * BAMD_AM_NW) __attribute__((amdgpu_waves_p
     const int pmax = P0 + tlast;                                               // highest position any column of this tile attends
     int npos = (pmax + 1 + 63) & ~63; npos = npos < n_ctx ? npos : n_ctx;       // positions past a column's own are masked: exact no-ops (attn_batch_kernel)
     const int mrow = lane & 15, kq = lane >> 4;                                // MFMA operand roles of this lane: A[m = mrow][k = kq], B[k = kq][n = mrow]
-    // a ring of BAMD_AM_KD tiles of K rows per wave in flight (64 bytes per lane and tile: the 8-byte piece e * 16 + 4 kq .. + 3 of every e), requested
+    // a ring of BAMD_AM_KD tiles of K rows per wave in flight (64 bytes per lane and tile: the 8-byte piece of chain steps 4 kq .. 4 kq + 3 of every lane e, kperm order), requested
     // unconditionally (a tile past the end: the last one again) so that the waits stay counted
-    const unsigned short * kbase = a.kc + (size_t) hk * hd + 4 * kq;
+    const unsigned short * kbase = a.kc + (size_t) hk * hd + (kq >> 1) * BAMD_KGRP + (kq & 1) * 4;      // chain steps l = 4 kq .. 4 kq + 3 of every lane e (kperm)
     const int ntile = npos >> 4;
     uint2 ring[BAMD_AM_KD][8];
     auto kload = [&](uint2 (&dst)[8], int pt) {
         const int row = (pt < ntile ? pt : ntile - 1) * 16 + mrow;
         const unsigned short * kp = kbase + (size_t) row * Ekv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = *(const uint2 *) (kp + e * L);
+        for (int e = 0; e < 8; ++e) dst[e] = *(const uint2 *) (kp + e * 8);
     };
     // ---- RoPE of the 16 query vectors -> f16, chain-major (rope_heads' arithmetic, ggml.c:14130-14143).  16 x 64 pairs: 1024 / NT per thread, all
     //      requested (8-byte loads) before anything else, the K ring right behind them ----
@@ -107,11 +107,11 @@ __global__ void __launch_bounds__(64 * BAMD_AM_NW) __attribute__((amdgpu_waves_p
     if (dbg_exit == 1) return;
     // ================= pass 1: scores (and the running maximum of every column) =================
     {
-        // B fragments, once: column mrow, elements 32 s + 8 j + e for s = kq — stored at e * 16 + 4 kq + j: four consecutive halves per e
+        // B fragments, once: column mrow, elements 32 s + 8 j + e for s = kq — stored at (kq >> 1) * 64 + e * 8 + (kq & 1) * 4 + j (kperm): four consecutive halves per e
         float B[8][4];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint2 w = *(const uint2 *) (q16 + mrow * hd + e * L + 4 * kq);
+            const uint2 w = *(const uint2 *) (q16 + mrow * hd + (kq >> 1) * BAMD_KGRP + e * 8 + (kq & 1) * 4);
             B[e][0] = h2f_lo(w.x); B[e][1] = h2f_hi(w.x); B[e][2] = h2f_lo(w.y); B[e][3] = h2f_hi(w.y);
         }
         const int pcol = P0 + ((t0 + mrow / GQ) < T ? (t0 + mrow / GQ) : T - 1);   // the position of this lane's column (D layout: column = lane & 15 as well)

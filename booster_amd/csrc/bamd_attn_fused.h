@@ -24,9 +24,9 @@ struct AttnEnvWG {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ float2 qk2(const bamd_attn_args & a, int role, int h, int hk, int hd, int rp) const {
         const float * rsrc = role == 1 ? a.k + (size_t) hk * hd : a.q + (size_t) h * hd;
-        return *(const float2 *) (rsrc + 2 * rp);
+        return BAMD_IK_QKV ? ik_ld2f(rsrc + 2 * rp) : *(const float2 *) (rsrc + 2 * rp);                        // q | k | v: the QKV launch's output (inter-kernel data, bamd_device.h)
     }
-    __device__ __forceinline__ float vel(const bamd_attn_args & a, int hk, int hd, int i) const { return a.v[hk * hd + i]; }
+    __device__ __forceinline__ float vel(const bamd_attn_args & a, int hk, int hd, int i) const { return ik_ld_if<BAMD_IK_QKV != 0>(a.v + hk * hd + i); }
 };
 template <int LG, bool COLAUNCH, typename ENV = AttnEnvWG>
 __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const int h, const int tokb_in, unsigned char * attn_dyn, uint32_t * done_flags, uint32_t tag, const ENV env = ENV()) {
@@ -41,9 +41,9 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     // batched prefill (a.batch): tokb_in = token of the micro-batch (the kernel's blockIdx.y); its K/V rows and those of the earlier tokens of the batch
     // were stored by kv_store_batch_kernel, and masked positions are exact no-ops, so each token uses its own padded length
     const int tokb = a.batch ? tokb_in : 0;
-    const int pos = st->pos + tokb;
-    int n_kv = st->n_kv;
-    if (a.batch) { n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < st->n_ctx ? n_kv : st->n_ctx; }
+    const int pos = ik_ld_if<BAMD_IK_ST != 0>(&st->pos) + tokb;                  // the step state is inter-kernel data: never through the scalar cache
+    int n_kv = ik_ld_if<BAMD_IK_ST != 0>(&st->n_kv);
+    if (a.batch) { const int nc = ik_ld(&st->n_ctx); n_kv = (pos + 1 + 31) / 32 * 32; n_kv = n_kv < nc ? n_kv : nc; }
     a.q += (size_t) tokb * a.ld_qkv; a.k += (size_t) tokb * a.ld_qkv; a.v += (size_t) tokb * a.ld_qkv; a.out += (size_t) tokb * a.ld_out;
     constexpr int hd = LG * 64, L = LG * 8, hp = hd / 2;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
@@ -65,19 +65,21 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     // 2. this lane's K chunks of the first 4 x 64 positions and its V^T chunks of the first 4 blocks (rows d = r_pos + 64 dd), all
     //    unconditional: a tile past the end of the cache is clamped to the last one, positions >= pos hold zeros or stale finite
     //    values whose scores are masked below and whose probabilities are exactly 0
+    // the KV cache is inter-kernel data too (earlier steps' launches wrote the rows): sc1 buffer loads, 32-bit byte offsets into this layer's K / V^T
+    const bamd_ik_rsrc rk = ik_rsrc(a.kc), rv = ik_rsrc(a.vc);
     uint4 kreg[4][LG];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = t * 64 + r_pos < n_ctx ? t * 64 + r_pos : n_ctx - 64 + r_pos;
 #pragma unroll
-        for (int g = 0; g < LG; ++g) kreg[t][g] = *(const uint4 *) (a.kc + (size_t) i * Ekv + hk * hd + e * L + g * 8);
+        for (int g = 0; g < LG; ++g) kreg[t][g] = ik_ld128_if<BAMD_IK_KLD != 0>(rk, (uint32_t) (i * Ekv + hk * hd + g * BAMD_KGRP + e * 8) * 2u);
     }
     uint4 vreg[4][LG < 2 ? LG : 2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int tb = t * 64 < n_ctx ? t * 64 : n_ctx - 64;
 #pragma unroll
-        for (int dd = 0; dd < (LG < 2 ? LG : 2); ++dd) vreg[t][dd] = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + tb + e * 8);
+        for (int dd = 0; dd < (LG < 2 ? LG : 2); ++dd) vreg[t][dd] = ik_ld128_if<BAMD_IK_VLD != 0>(rv, (uint32_t) ((hk * hd + r_pos + 64 * dd) * n_ctx + tb + e * 8) * 2u);
     }
     {   // RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143 — rope_heads' arithmetic) into the chain-major LDS copies
         const float t0 = xin.x * cs.x, t1 = xin.y * cs.y, t2 = xin.x * cs.y, t3 = xin.y * cs.x;
@@ -89,14 +91,14 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     env.sync();
     // KV store by the first query head of each KV head — llm_build_kv_store, llama.cpp:7830-7875
     if (h == hk * gq && !a.batch && tid < hd) {
-        a.kc[(size_t) pos * Ekv + hk * hd + tid] = k16t[tid];
-        a.vc[(size_t) (hk * hd + tid) * n_ctx + vperm(pos)] = f2h(vst);
+        ik_st_if<BAMD_IK_KVST != 0>(a.kc + (size_t) pos * Ekv + hk * hd + tid, k16t[tid]);
+        ik_st_if<BAMD_IK_KVST != 0>(a.vc + (size_t) (hk * hd + tid) * n_ctx + vperm(pos), f2h(vst));
     }
     TL_STAMP(a.tl, 1);
     // ---- scores: every chain runs unconditionally (independent chains interleave), the mask is a select at the end ----
     uint4 kself[4];                                                // this token's K row is not visible in the cache yet
 #pragma unroll
-    for (int g = 0; g < 4; ++g) kself[g] = g < LG ? *(const uint4 *) (k16t + e * L + g * 8) : make_uint4(0, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) kself[g] = g < LG ? *(const uint4 *) (k16t + g * BAMD_KGRP + e * 8) : make_uint4(0, 0, 0, 0);
 #define BAMD_SCORE_TILE(t0_, KL_) do { \
         const int i = (t0_) + r_pos; \
         uint4 kk[4]; \
@@ -104,7 +106,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
             const uint4 kc_ = g < LG ? KL_[g < LG ? g : 0] : make_uint4(0, 0, 0, 0); \
             kk[g].x = i == pos ? kself[g].x : kc_.x; kk[g].y = i == pos ? kself[g].y : kc_.y; kk[g].z = i == pos ? kself[g].z : kc_.z; kk[g].w = i == pos ? kself[g].w : kc_.w; \
         } \
-        float v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(kk, L, nullptr, q16t + e * L)) : hsum8_tinyblas(kq_chain<false>(kk, L, qt + e * L, nullptr)); \
+        float v = a.prefill_mode ? hsum8_vecdot(kq_chain<true>(kk, L, nullptr, q16t + e * 8)) : hsum8_tinyblas(kq_chain<false>(kk, L, qt + e * 8, nullptr)); \
         v = (i < n_kv && i <= pos) ? v : -INFINITY;               /* masked (KQ_mask, llama.cpp:14152-14200) */ \
         if (e == 0 && i < n_kv) sc[i] = v; \
     } while (0)
@@ -114,7 +116,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
         const int i2 = t0 + r_pos;
         uint4 kl[LG];
 #pragma unroll
-        for (int g = 0; g < LG; ++g) kl[g] = *(const uint4 *) (a.kc + (size_t) i2 * Ekv + hk * hd + e * L + g * 8);    // n_kv <= n_ctx: in bounds
+        for (int g = 0; g < LG; ++g) kl[g] = ik_ld128_if<BAMD_IK_KLD != 0>(rk, (uint32_t) (i2 * Ekv + hk * hd + g * BAMD_KGRP + e * 8) * 2u);    // n_kv <= n_ctx: in bounds
         BAMD_SCORE_TILE(t0, kl);
     }
 #undef BAMD_SCORE_TILE
@@ -181,7 +183,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
             for (int dd = 0; dd < (LG < 2 ? LG : 2); ++dd) BAMD_PV_BLOCK(t * 64, dd, vreg[t][dd]);
 #pragma unroll
             for (int dd = 2; dd < LG; ++dd) {                      // hd > 128
-                const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + t * 64 + e * 8);
+                const uint4 vv = ik_ld128_if<BAMD_IK_VLD != 0>(rv, (uint32_t) ((hk * hd + r_pos + 64 * dd) * n_ctx + t * 64 + e * 8) * 2u);
                 BAMD_PV_BLOCK(t * 64, dd, vv);
             }
         }
@@ -189,7 +191,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
     for (int b0 = 256; b0 < n_kv; b0 += 64) {
 #pragma unroll
         for (int dd = 0; dd < LG; ++dd) {
-            const uint4 vv = *(const uint4 *) (a.vc + (size_t) (hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8);
+            const uint4 vv = ik_ld128_if<BAMD_IK_VLD != 0>(rv, (uint32_t) ((hk * hd + r_pos + 64 * dd) * n_ctx + b0 + e * 8) * 2u);
             BAMD_PV_BLOCK(b0, dd, vv);
         }
     }
@@ -200,7 +202,7 @@ __device__ __forceinline__ void attn_fused_body(bamd_attn_args a, int gq, const 
         if (e == 0) {
             if (COLAUNCH) __hip_atomic_store((unsigned long long *) done_flags + (size_t) h * hd + r_pos + 64 * dd, ((unsigned long long) tag << 32) | __float_as_uint(v),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else a.out[(size_t) h * hd + r_pos + 64 * dd] = v;
+            else ik_st(a.out + (size_t) h * hd + r_pos + 64 * dd, v);
         }
     }
     TL_STAMP(a.tl, 7);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void wo_role(const bamd_mv_args & a, const ProArgs & 
     const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
     const int crow = (j + (wave < M ? wave : 0) * G) * 8 + r8;          // the row whose chain this wave replays
     float resv = 0.f;
-    if (crow < nv) resv = a.res[crow];                                   // the residual: written two launches ago, plain load
+    if (crow < nv) resv = ik_ld(a.res + crow);                            // the residual: written two launches ago
     // what the terms need from the weights alone — nibbles, scales, mins, d — while the attention role works (the records have landed long before its granules)
     PreTerms<TYPE> pre[M * NBW];
 #pragma unroll
@@ -57,7 +57,7 @@ __device__ __forceinline__ void wo_role(const bamd_mv_args & a, const ProArgs & 
     //      this launch's; then Q8_K into LDS (no workgroup barrier: the wave consumes only what it quantised itself) ----
     ActPro<false> ap; ap.tl = pa.tl; ap.okmask = (1 << NBW) - 1;
     {
-        const uint32_t tag = ((uint32_t) st->serial << 20) | (((uint32_t) st->step & 0xfffu) << 8) | (uint32_t) il;
+        const uint32_t tag = ((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->serial) << 20) | (((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->step) & 0xfffu) << 8) | (uint32_t) il;
         const bamd_rsrc gr = weight_rsrc(gran);
         unsigned spins = 0;
         for (;;) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void wo_role(const bamd_mv_args & a, const ProArgs & 
             for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
         }
         const float val = finish_row<TYPE>(A);
-        if ((lane & 7) == 0 && crow < nv) a.seg[0].out[crow] = val + resv;
+        if ((lane & 7) == 0 && crow < nv) ik_st(a.seg[0].out + crow, val + resv);
         TL_STAMP(pa.tl, 5);
     }
 }
@@ -121,7 +121,7 @@ __device__ __forceinline__ void wo_role_batched(const bamd_mv_args & a, const Pr
     for (int d = 0; d < ring_delay; ++d) __builtin_amdgcn_s_sleep(8);
     ActPro<false> ap, ap2; ap.tl = pa.tl; ap.okmask = (1 << NBW) - 1;
     auto wait_for_attention = [&]() {
-        const uint32_t tag = ((uint32_t) st->serial << 20) | (((uint32_t) st->step & 0xfffu) << 8) | (uint32_t) il;
+        const uint32_t tag = ((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->serial) << 20) | (((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->step) & 0xfffu) << 8) | (uint32_t) il;
         const bamd_rsrc gr = weight_rsrc(gran);
         unsigned spins = 0;
         for (;;) {
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int H = at.Hkv * gq;
     if ((int) blockIdx.x < H) {
         const bamd_step_state * st = at.st;
-        const uint32_t tag = ((uint32_t) st->serial << 20) | (((uint32_t) st->step & 0xfffu) << 8) | (uint32_t) il;
+        const uint32_t tag = ((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->serial) << 20) | (((uint32_t) ik_ld_if<BAMD_IK_ST != 0>(&st->step) & 0xfffu) << 8) | (uint32_t) il;
         attn_fused_body<LG, true>(at, gq, (int) blockIdx.x, 0, smem, (uint32_t *) gran, tag);
         return;
     }
@@ -194,7 +194,7 @@ int bamd_launch_attn_wo(const bamd_attn_args & t, int gq, const bamd_mv_args & w
     const size_t lds_wo = act_lds_bytes(wo.K) + 16 + (nb == 32 ? (size_t) 2 * 2 * nb * 256 * 4 : (size_t) 3 * nb * 256 * 4), lds_at = (size_t) ld * 8;
     const size_t lds = lds_wo > lds_at ? lds_wo : lds_at;
     const dim3 grid(n_cu), block(512);
-#define BAMD_CL(LG_, T_) hipLaunchKernelGGL((attn_wo_kernel<LG_, T_>), grid, block, lds, s, t, gq, wo, gran, il, extra, g_ring_delay, err)
+#define BAMD_CL(LG_, T_) BAMD_LAUNCH((attn_wo_kernel<LG_, T_>), grid, block, lds, s, t, gq, wo, gran, il, extra, g_ring_delay, err)
 #define BAMD_CL_T(LG_) do { if (type == BAMD_Q4_K) BAMD_CL(LG_, BAMD_Q4_K); else if (type == BAMD_Q5_K) BAMD_CL(LG_, BAMD_Q5_K); else if (type == BAMD_Q6_K) BAMD_CL(LG_, BAMD_Q6_K); else return 1; } while (0)
     switch (t.hd >> 6) {
         case 1: BAMD_CL_T(1); break;

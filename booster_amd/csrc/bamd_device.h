@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include "bamd_formats.h"
 #include "bamd_kernels.h"
+#include "bamd_aql.h"
 
 #define WAVE 64
 #ifndef BAMD_SCHED_GROUP
@@ -96,6 +97,75 @@ __device__ __forceinline__ const uint8_t * uniform_ptr(const uint8_t * p) {     
     return (const uint8_t *) (((uint64_t) hi << 32) | lo);
 }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+
+// ===========================================================================================================
+// Inter-kernel data.  Everything one launch of a decode step writes for another launch to read — activation vectors, residuals, q | k | v, the
+// attention output, logits, the arg-max key, the device-side step state, the KV cache rows — is stored write-through (sc1) and loaded with sc1
+// loads, which bypass this CU's vector L1 and are coherent across the eight XCD L2s.  A decode step replayed from the context's own AQL queue
+// (bamd_aql.cpp) runs its packets with acquire / release fence scope NONE: no L2 write-back at a kernel's end, no L1 / L2 / scalar-cache invalidate
+// at the next one's start (−0.4 us per launch, profiles/r03_aql_probe.txt), so nothing but these accesses carries data from launch to launch.
+// Rules for a kernel of the decode graph: (1) mutable data is never read through a scalar load or a plain vector load — ik_* only; (2) every
+// global store is ik_*; (3) constants (weights, norm weights, the RoPE table, token_embd) keep their plain / nt loads: nobody rewrites them.
+// Under ordinary HIP launches (agent-scope fences at every boundary) the same instructions are merely redundant.  BAMD_IK_SC1=0 compiles the
+// plain forms back in (A/B: profiles/r06_levers.txt).
+// ===========================================================================================================
+#ifndef BAMD_IK_SC1
+#define BAMD_IK_SC1 1
+#endif
+#define BAMD_IK_AUX (BAMD_IK_SC1 ? 16 : 0)          /* aux bits of the raw buffer loads / stores: 16 = sc1 */
+typedef __amdgpu_buffer_rsrc_t bamd_ik_rsrc;
+typedef uint32_t ik_u32x4 __attribute__((ext_vector_type(4)));
+// base must be wave-uniform; offsets are 32-bit byte offsets below 2 GiB (an activation vector, one layer's K or V^T cache)
+__device__ __forceinline__ bamd_ik_rsrc ik_rsrc(const void * base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 ik_ld128(bamd_ik_rsrc r, uint32_t voff, int soff = 0) {
+    const ik_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) voff, soff, BAMD_IK_AUX); return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ik_ld128f(bamd_ik_rsrc r, uint32_t voff, int soff = 0) {
+    const ik_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) voff, soff, BAMD_IK_AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void ik_st128f(bamd_ik_rsrc r, uint32_t voff, const float4 v) {
+    const ik_u32x4 u = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int) voff, 0, BAMD_IK_AUX);
+}
+#if BAMD_IK_SC1
+template <typename T> __device__ __forceinline__ T ik_ld(const T * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void ik_st(T * p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+template <typename T> __device__ __forceinline__ T ik_ld(const T * p) { return *p; }
+template <typename T> __device__ __forceinline__ void ik_st(T * p, T v) { *p = v; }
+#endif
+// experiment switches (timing under HIP launches only — a plain access is NOT coherent on the own queue): which class of access of the attention kernels
+// costs what (profiles/r06_levers.txt)
+#ifndef BAMD_IK_ST
+#define BAMD_IK_ST BAMD_IK_SC1       /* step-state loads (pos, n_kv, serial, step) */
+#endif
+#ifndef BAMD_IK_QKV
+#define BAMD_IK_QKV BAMD_IK_SC1      /* this token's q / k / v */
+#endif
+#ifndef BAMD_IK_KVLD
+#define BAMD_IK_KVLD BAMD_IK_SC1     /* KV cache loads */
+#endif
+#ifndef BAMD_IK_KLD
+#define BAMD_IK_KLD BAMD_IK_KVLD     /* K rows only */
+#endif
+#ifndef BAMD_IK_VLD
+#define BAMD_IK_VLD BAMD_IK_KVLD     /* V^T rows only */
+#endif
+#ifndef BAMD_IK_KVST
+#define BAMD_IK_KVST BAMD_IK_SC1     /* KV cache stores */
+#endif
+template <bool SC1, typename T> __device__ __forceinline__ T ik_ld_if(const T * p) { if (SC1) return ik_ld(p); return *p; }
+template <bool SC1, typename T> __device__ __forceinline__ void ik_st_if(T * p, T v) { if (SC1) ik_st(p, v); else *p = v; }
+template <bool SC1> __device__ __forceinline__ uint4 ik_ld128_if(bamd_ik_rsrc r, uint32_t voff) {
+    const ik_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) voff, 0, SC1 ? 16 : 0); return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ik_ld2f(const float * p) {                // 8-byte aligned pair
+    const unsigned long long u = ik_ld((const unsigned long long *) p);
+    return make_float2(__uint_as_float((uint32_t) u), __uint_as_float((uint32_t) (u >> 32)));
+}
 
 // ggml-quants.c:1632-1637
 __device__ __forceinline__ int nearest_int(float fval) {
@@ -199,13 +269,14 @@ struct ActPro {
         // never used): a conditional load becomes a branch around the request with a full s_waitcnt at the join, which serialised the
         // batches into one memory round trip each — and held back the weight ring that is issued after them
         okmask = 0;
+        const bamd_ik_rsrc rx = ik_rsrc(x);              // the activation vector is another launch's output: sc1 loads ("Inter-kernel data" above)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int i = i0 + b * bstride;
             const bool ok = i < blimit;
             okmask |= ok ? 1 << b : 0;
             const int ic = ok ? i : blimit - 1;          // past the end: the last block again; its values are never used (okmask, i < nb below)
-            v[b] = *(const float4 *) (x + ic * 256 + lane * 4);
+            v[b] = ik_ld128f(rx, (uint32_t) lane * 16u, ic * 1024);
             if (NORM) w[b] = *(const float4 *) (nw + ic * 256 + lane * 4);
         }
     }
@@ -347,7 +418,7 @@ struct ActPro {
                 __syncthreads();                                            // everybody has read red[]
                 if (threadIdx.x == 0) {                                     // the reference's order, one lane (ggml.c:11874-11877)
                     double sq = 0.0;
-                    for (int i = 0; i < K; ++i) { const float xv = x[i]; sq += (double) (xv * xv); }
+                    for (int i = 0; i < K; ++i) { const float xv = ik_ld(x + i); sq += (double) (xv * xv); }
                     red[0] = sq;
                 }
                 __syncthreads();
@@ -696,10 +767,10 @@ __device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, i
     // get_rows: ggml.c:13186-13228 -> dequantize_row_*
     if (embd_type == BAMD_F32) {
         const float * src = (const float *) embd + (size_t) tok * E;
-        for (int i = threadIdx.x; i < E; i += blockDim.x) x[i] = src[i];
+        for (int i = threadIdx.x; i < E; i += blockDim.x) ik_st(x + i, src[i]);
     } else if (embd_type == BAMD_F16) {
         const unsigned short * src = (const unsigned short *) embd + (size_t) tok * E;
-        for (int i = threadIdx.x; i < E; i += blockDim.x) x[i] = h2f(src[i]);
+        for (int i = threadIdx.x; i < E; i += blockDim.x) ik_st(x + i, h2f(src[i]));
     } else {
         const int nb = E >> 8;
         const int bb = bamd_block_bytes(embd_type);
@@ -735,7 +806,7 @@ __device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, i
                 const float t = d * (float) sc[is + 2 * cc];
                 y = t * (float) q;
             }
-            x[i] = y;
+            ik_st(x + i, y);
         }
     }
 }
@@ -745,12 +816,16 @@ __device__ __forceinline__ void embed_row(const uint8_t * embd, int embd_type, i
 // ===========================================================================================================
 // KV cache, "chain-major" physical order (logically the reference's K [n_ctx][Hkv*hd] f16 and V^T [Hkv*hd][n_ctx] f16,
 // llama.cpp:7845-7875; bamd_op_attention converts at the boundary):
-//   K : inside each head row, element n = 8l + e is stored at index e*(hd/8) + l
+//   K : inside each head row, element n = 8l + e (lane e, chain step l) is stored at index (l >> 3)*64 + e*8 + (l & 7): the 16-byte group g = l >> 3 of
+//       the eight lanes is ONE 128-byte line, so a wave's load instruction for group g covers whole lines (round 6; rounds 1-5 kept a lane's L = hd/8
+//       halves contiguous — e*L + l — and every load instruction touched HALF of two lines per position: harmless while the vector L1 caught the second
+//       half, 1.4 us per attention launch once the loads had to bypass it — sc1, "Inter-kernel data" above; profiles/r06_levers.txt)
 //   V^T: inside each row, position p = 64B + 8l + e is stored at index 64B + 8e + l
 // The reference's attention mat-muls (tinyBLAS, sgemm.cpp:405-431) keep 8 SIMD lanes e, each a sequential f32 chain over
 // the steps l.  With this order the wave lane that stands for SIMD lane e finds the operands of consecutive steps
-// CONTIGUOUS: 16-byte loads straight from HBM/L2, no LDS staging, no gather.
-__device__ __forceinline__ int kperm(int n, int L) { return (n & 7) * L + (n >> 3); }
+// in 16-byte runs: 16-byte loads straight from HBM/L2, no LDS staging, no gather.  The LDS copies of q / k (qt, q16t, k16t) use the same order.
+__device__ __forceinline__ int kperm(int n, int L) { (void) L; const int l = n >> 3; return ((l >> 3) << 6) + ((n & 7) << 3) + (l & 7); }
+#define BAMD_KGRP 64                 /* halves (or floats) between consecutive 16-byte groups of one lane's chain */
 __device__ __forceinline__ int vperm(int p) { return (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3); }
 
 // eight steps of ggml_vec_dot_f16's four interleaved accumulators on f16 pairs: v_fma_mix_f32 extends both halves and fuses the
@@ -793,7 +868,8 @@ __device__ __forceinline__ float fma_mix_chain(float acc, const uint32_t (&w)[4]
             : "+v"(acc) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
     return acc;
 }
-// dot of up to 32 steps for lane e: k8 = this lane's L halves of the K row (L <= 32), q = this lane's L floats / halves
+// dot of up to 32 steps for lane e: kv = this lane's L halves of the K row (L <= 32), qf / qh = this lane's floats / halves of group 0 (base + e * 8),
+// group g another BAMD_KGRP elements on (kperm)
 template <bool PREFILL>
 __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const float * qf, const unsigned short * qh) {
     if (!PREFILL) {
@@ -802,7 +878,7 @@ __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const flo
         for (int g = 0; g < 4; ++g) {
             if (g * 8 < L) {
                 const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
-                const float4 qa = *(const float4 *) (qf + g * 8), qb = *(const float4 *) (qf + g * 8 + 4);
+                const float4 qa = *(const float4 *) (qf + g * BAMD_KGRP), qb = *(const float4 *) (qf + g * BAMD_KGRP + 4);
                 const float qv[8] = { qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w };
                 acc = fma_mix_chain<8>(acc, w, qv);              // acc = fmaf((float) k_u, q_u, acc), u = 0..7 (hipcc: a v_cvt_f32_f16 per step beside the fma)
             }
@@ -814,7 +890,7 @@ __device__ __forceinline__ float kq_chain(const uint4 (&kv)[4], int L, const flo
         for (int g = 0; g < 4; ++g) {
             if (g * 8 < L) {
                 const uint32_t w[4] = { kv[g].x, kv[g].y, kv[g].z, kv[g].w };
-                const uint4 qq = *(const uint4 *) (qh + g * 8);
+                const uint4 qq = *(const uint4 *) (qh + g * BAMD_KGRP);
                 const uint32_t qw[4] = { qq.x, qq.y, qq.z, qq.w };
                 fma_mix8(a4, w, qw);                               // a4[u & 3] = fmaf((float) k_u, (float) q_u, a4[u & 3]), u = 0..7
             }

@@ -10,6 +10,7 @@
 #include "bamd_formats.h"
 #include "bamd_gguf.h"
 #include "bamd_kernels.h"
+#include "bamd_aql.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -37,6 +38,10 @@ extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_version(
 static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
 static int fail(const std::string & m) { g_err = m; return 1; }
+// BAMD_AQL=0: the device-side greedy loop replays one hipGraph per step on the context's HIP stream (rounds 1-5) instead of AQL packets with fence scope
+// NONE on the library's own queue (bamd_aql.h).  Same kernels, same bits; BAMD_AQL_VERBOSE=1 says why when the own queue is not used
+static int g_aql = [] { const char * e = getenv("BAMD_AQL"); return (e && e[0] == '0') ? 0 : 1; }();
+extern "C" __attribute__((visibility("default"))) void bamd_set_aql(int on) { g_aql = on ? 1 : 0; }
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define HIPP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
 
@@ -143,6 +148,7 @@ struct bamd_context {
     int32_t * out_tokens = nullptr; int out_cap = 0;
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr; int graph_fused = -1;
+    bamd_aql_graph * aql = nullptr; int aql_key = -1; bool aql_failed = false; int aql_runs = 0;    // the same step as AQL packets for the own queue (bamd_aql.h)
     unsigned long long * co_gran = nullptr;   // co-launch granules [H * hd] {value, tag} + give-up counter behind them (bamd_colaunch.hip), zero-initialised
     uint32_t * co_err = nullptr;
     int32_t * slots = nullptr; int slots_cap = 0;   // device-side greedy loop after a context shift: {cell, padded KV length} of every step (bamd_generate_greedy)
@@ -408,6 +414,7 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     if (!c) return;
     if (c->m) hipSetDevice(c->m->device);
     if (c->graph) hipGraphExecDestroy(c->graph);
+    bamd_aql_free(c->aql);
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
     if (c->logits_host) hipHostFree(c->logits_host);
@@ -1053,14 +1060,40 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
         HIPC(hipStreamSynchronize(s));                                    // (hs is a host temporary)
     } else c->n_cached = std::max(c->n_cached, n_past + n_steps);
     const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0));     // 2: the shifted-cell kernels and the slot table (other arguments: recapture)
-    if (c->graph && c->graph_fused != fused) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-    if (!c->graph && build_graph(c, attn_hi)) return 1;
-    c->graph_fused = fused;
-    if (set_state(c, n_past, s, true)) return 1;
-    EventPair ev; HIPC(ev.create());
-    HIPC(hipEventRecord(ev.a, s));
-    for (int t = 0; t < n_steps; ++t) HIPC(hipGraphLaunch(c->graph, s));
-    HIPC(hipEventRecord(ev.b, s));
+    float ms_steps = 0.f;
+    EventPair ev; bool timed_by_events = false;
+    // the step as AQL packets on the library's own queue (bamd_aql.h): the launch sequence of the single-launch attention path, whose kernels keep the
+    // inter-kernel rules of bamd_device.h; anything else (long sequences, shifted cells) replays the hipGraph
+    const bool want_aql = g_aql && fused == 1 && !c->aql_failed;
+    if (c->aql && (c->aql_key != fused || !want_aql)) { bamd_aql_free(c->aql); c->aql = nullptr; }
+    if (want_aql && !c->aql) {
+        bamd_aql_recording rec;
+        bamd_aql_rec = &rec;
+        enqueue_begin(c, 0, 1, s, false);
+        const int rc = enqueue_layers(c, 0, s, nullptr, attn_hi);
+        enqueue_lm_head(c, s, nullptr);
+        bamd_aql_rec = nullptr;
+        const char * why = "recording failed";
+        if (!rc) c->aql = bamd_aql_build(m->device, rec, &why);
+        if (!c->aql) { c->aql_failed = true; if (getenv("BAMD_AQL_VERBOSE")) fprintf(stderr, "bamd: own AQL queue not used: %s\n", why ? why : "?"); }
+        c->aql_key = fused;
+    }
+    if (c->aql) {
+        if (set_state(c, n_past, s, true)) return 1;
+        HIPC(hipStreamSynchronize(s));                                // the state and everything before it is in memory: the first packet acquires at system scope
+        double sec = 0.0; const char * why = nullptr;
+        if (bamd_aql_run(c->aql, n_steps, &sec, &why)) return fail(std::string("own AQL queue: ") + (why ? why : "?"));
+        ms_steps = (float) (sec * 1e3); c->aql_runs += 1;
+    } else {
+        if (c->graph && c->graph_fused != fused) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+        if (!c->graph && build_graph(c, attn_hi)) return 1;
+        c->graph_fused = fused;
+        if (set_state(c, n_past, s, true)) return 1;
+        HIPC(ev.create()); timed_by_events = true;
+        HIPC(hipEventRecord(ev.a, s));
+        for (int t = 0; t < n_steps; ++t) HIPC(hipGraphLaunch(c->graph, s));
+        HIPC(hipEventRecord(ev.b, s));
+    }
     enqueue_begin(c, 0, 0, s);                                        // flush the last arg-max into out_tokens
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(out_tokens, c->out_tokens, (size_t) (n_steps + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -1069,9 +1102,12 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     HIPC(hipStreamSynchronize(s));
     c->logits_host_valid = true;
     if (co_gave_up(c)) return 1;
-    if (elapsed_ms) HIPC(hipEventElapsedTime(elapsed_ms, ev.a, ev.b));
+    if (timed_by_events) HIPC(hipEventElapsedTime(&ms_steps, ev.a, ev.b));
+    if (elapsed_ms) *elapsed_ms = ms_steps;
     return 0;
 }
+// how many bamd_generate_greedy calls of this context ran on the own AQL queue so far (tests, bench: which path produced the number)
+extern "C" __attribute__((visibility("default"))) int bamd_aql_runs(const bamd_context * c) { return c->aql_runs; }
 
 // ---- layer-split stage ---------------------------------------------------------------------------------
 extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev,
@@ -1387,19 +1423,20 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_rope_row(int pos, 
     rope_row(row, pos, n_dims, freq_base, freq_scale, freq_factors, 0.0f, 1.0f, 8192, 32.0f, 1.0f);
     return 0;
 }
-// reference layout <-> chain-major device layout of the KV cache (bamd_device.h, "Attention")
+// reference layout <-> chain-major device layout of the KV cache (bamd_device.h, "Attention": kperm / vperm)
+static inline int kperm_host(int n) { const int l = n >> 3; return ((l >> 3) << 6) + ((n & 7) << 3) + (l & 7); }
 static void kv_to_device_order(const uint16_t * k_ref, const uint16_t * v_ref, int n_ctx, int n_ctx_pad, int Hkv, int hd, std::vector<uint16_t> & kd, std::vector<uint16_t> & vd) {
-    const int Ekv = Hkv * hd, L = hd / 8;
+    const int Ekv = Hkv * hd;
     kd.assign((size_t) n_ctx_pad * Ekv, 0); vd.assign((size_t) Ekv * n_ctx_pad, 0);
     for (int i = 0; i < n_ctx; ++i) for (int h = 0; h < Hkv; ++h) for (int n = 0; n < hd; ++n)
-        kd[(size_t) i * Ekv + h * hd + (n & 7) * L + (n >> 3)] = k_ref[(size_t) i * Ekv + h * hd + n];
+        kd[(size_t) i * Ekv + h * hd + kperm_host(n)] = k_ref[(size_t) i * Ekv + h * hd + n];
     for (int r = 0; r < Ekv; ++r) for (int p = 0; p < n_ctx; ++p)
         vd[(size_t) r * n_ctx_pad + (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3)] = v_ref[(size_t) r * n_ctx + p];
 }
 static void kv_from_device_order(uint16_t * k_ref, uint16_t * v_ref, int n_ctx, int n_ctx_pad, int Hkv, int hd, const std::vector<uint16_t> & kd, const std::vector<uint16_t> & vd) {
-    const int Ekv = Hkv * hd, L = hd / 8;
+    const int Ekv = Hkv * hd;
     for (int i = 0; i < n_ctx; ++i) for (int h = 0; h < Hkv; ++h) for (int n = 0; n < hd; ++n)
-        k_ref[(size_t) i * Ekv + h * hd + n] = kd[(size_t) i * Ekv + h * hd + (n & 7) * L + (n >> 3)];
+        k_ref[(size_t) i * Ekv + h * hd + n] = kd[(size_t) i * Ekv + h * hd + kperm_host(n)];
     for (int r = 0; r < Ekv; ++r) for (int p = 0; p < n_ctx; ++p)
         v_ref[(size_t) r * n_ctx + p] = vd[(size_t) r * n_ctx_pad + (p & ~63) + ((p & 7) << 3) + ((p & 63) >> 3)];
 }

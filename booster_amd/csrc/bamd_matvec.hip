@@ -203,29 +203,33 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
                                                          float * x, int do_embed, const int32_t * slots, int32_t * cellpos) {
     __shared__ int tok_s;
     if (threadIdx.x == 0) {
-        bamd_step_state h = *st;                              // ONE round trip for the whole state (field by field: a dependent load each)
+        // the state is inter-kernel data (bamd_device.h): sc1 loads, issued together (ONE round trip for the fields this step needs), sc1 stores
+        bamd_step_state h;
+        h.pos_base = ik_ld(&st->pos_base); h.step = ik_ld(&st->step); h.n_ctx = ik_ld(&st->n_ctx); h.n_out = ik_ld(&st->n_out);
+        h.cell_plus1 = ik_ld(&st->cell_plus1); h.n_kv_fixed = ik_ld(&st->n_kv_fixed); h.best_key = ik_ld(&st->best_key);
         const int step = h.step;
-        const int ftok = step < n_forced ? forced[step] : 0;
+        const int ftok = step < n_forced ? ik_ld(forced + step) : 0;
         int tok = 0;
         if (h.best_key != 0ull) {                             // arg-max of the previous lm_head, 0 = none ran
             tok = (int) (0xffffffffu - (uint32_t) (h.best_key & 0xffffffffull));
-            out_tokens[h.n_out] = tok; h.n_out += 1;
+            ik_st(out_tokens + h.n_out, tok); h.n_out += 1;
+            ik_st(&st->n_out, h.n_out);
         }
         if (step < n_forced) tok = ftok;
         if (tok < 0 || tok >= V) tok = 0;
         tok_s = tok;
-        h.token = tok;
+        ik_st(&st->token, tok);
         if (do_embed) {
             h.pos = h.pos_base + step;
             h.cell = h.cell_plus1 ? h.cell_plus1 - 1 + step : h.pos;
             int n_kv = (h.pos + 1 + 31) / 32 * 32;
             if (n_kv > h.n_ctx) n_kv = h.n_ctx;
             h.n_kv = h.n_kv_fixed ? h.n_kv_fixed : n_kv;
-            if (slots) { h.cell = slots[2 * step]; h.n_kv = slots[2 * step + 1]; cellpos[h.cell] = h.pos; }
-            h.step = step + 1;
-            h.best_key = 0ull;                                // a flush-only call leaves the key for the next generate call
+            if (slots) { h.cell = ik_ld(slots + 2 * step); h.n_kv = ik_ld(slots + 2 * step + 1); ik_st(cellpos + h.cell, h.pos); }
+            ik_st(&st->pos, h.pos); ik_st(&st->cell, h.cell); ik_st(&st->n_kv, h.n_kv);
+            ik_st(&st->step, step + 1);
+            ik_st(&st->best_key, 0ull);                       // a flush-only call leaves the key for the next generate call
         }
-        *st = h;
     }
     __syncthreads();
     if (!do_embed) return;
@@ -246,21 +250,21 @@ int bamd_timing_enabled(void) {
 void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K, hipStream_t s) {
     const int nb = K >> 8;
     const int64_t n = (int64_t) nrows * nb;
-    hipLaunchKernelGGL(repack_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *) raw, (uint8_t *) dst, type, nrows, nb);
+    BAMD_LAUNCH(repack_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *) raw, (uint8_t *) dst, type, nrows, nb);
 }
 
 void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s) {
-    hipLaunchKernelGGL(quantize_q8k_test_kernel, dim3(1), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, norm, (uint8_t *) out);
+    BAMD_LAUNCH(quantize_q8k_test_kernel, dim3(1), dim3(512), act_lds_bytes(K), s, x, nw, eps, K, norm, (uint8_t *) out);
 }
 
 template <int PRO>
 static void launch_mv_epi(const bamd_mv_args & a, int epi, int grid, hipStream_t s) {
     const size_t lds = act_lds_bytes(a.K);
     switch (epi) {
-        case BAMD_EPI_STORE:    hipLaunchKernelGGL((matvec_kernel<PRO, BAMD_EPI_STORE>),    dim3(grid), dim3(512), lds, s, a); break;
-        case BAMD_EPI_ADD:      hipLaunchKernelGGL((matvec_kernel<PRO, BAMD_EPI_ADD>),      dim3(grid), dim3(512), lds, s, a); break;
-        case BAMD_EPI_SILU_MUL: hipLaunchKernelGGL((matvec_kernel<PRO, BAMD_EPI_SILU_MUL>), dim3(grid), dim3(512), lds, s, a); break;
-        case BAMD_EPI_ARGMAX:   hipLaunchKernelGGL((matvec_kernel<PRO, BAMD_EPI_ARGMAX>),   dim3(grid), dim3(512), lds, s, a); break;
+        case BAMD_EPI_STORE:    BAMD_LAUNCH((matvec_kernel<PRO, BAMD_EPI_STORE>),    dim3(grid), dim3(512), lds, s, a); break;
+        case BAMD_EPI_ADD:      BAMD_LAUNCH((matvec_kernel<PRO, BAMD_EPI_ADD>),      dim3(grid), dim3(512), lds, s, a); break;
+        case BAMD_EPI_SILU_MUL: BAMD_LAUNCH((matvec_kernel<PRO, BAMD_EPI_SILU_MUL>), dim3(grid), dim3(512), lds, s, a); break;
+        case BAMD_EPI_ARGMAX:   BAMD_LAUNCH((matvec_kernel<PRO, BAMD_EPI_ARGMAX>),   dim3(grid), dim3(512), lds, s, a); break;
     }
 }
 template <int PRO>
@@ -269,8 +273,8 @@ static void launch_mv_split(const bamd_mv_args & a, int epi, int grid, hipStream
     const int nbw = nb >> 3;
     const int M = (nb & 7) ? (nbw == 2 ? 2 : 1) : nbw == 2 ? 4 : nbw == 7 ? 1 : nbw == 4 ? 2 : 8, NBUF = 2;   // must match split_dispatch
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) NBUF * M * nb * 256 * 4;   // 112..128 KiB of term buffers
-    if (epi == BAMD_EPI_ADD) hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_ADD>),   dim3(grid), dim3(512), lds, s, a);
-    else                     hipLaunchKernelGGL((matvec_split_kernel<PRO, BAMD_EPI_STORE>), dim3(grid), dim3(512), lds, s, a);
+    if (epi == BAMD_EPI_ADD) BAMD_LAUNCH((matvec_split_kernel<PRO, BAMD_EPI_ADD>),   dim3(grid), dim3(512), lds, s, a);
+    else                     BAMD_LAUNCH((matvec_split_kernel<PRO, BAMD_EPI_STORE>), dim3(grid), dim3(512), lds, s, a);
 }
 
 // K / 256 a multiple of 8 with 1, 2, 4 or 7 records per wave; or uneven shares of 2-3, 5-6, 6-7 records (17..23, 41..47, 49..55 super-blocks:
@@ -310,7 +314,7 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
                             int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots, int32_t * cellpos) {
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed, slots, cellpos);
+    BAMD_LAUNCH(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed, slots, cellpos);
 }
 
 

@@ -98,7 +98,7 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             const int after_off = (PAIR && part == 0) ? rowoff : (last ? rowoff + (nb - 1) * RECB : rowoff + rg_step);
             // residual fetched at the START of the row: by the epilogue it is the oldest outstanding load
             float resv = 0.f;
-            if (EPI == BAMD_EPI_ADD && row < nvalid) resv = res[row];
+            if (EPI == BAMD_EPI_ADD && row < nvalid) resv = ik_ld(res + row);
             RowAcc A = { 0.f, 0.f };
             for (int c = 0; c < chunks; ++c) {
                 const bool inrow = c + 1 < chunks;
@@ -120,11 +120,11 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             const float val = finish_row<TYPE>(A);
             if (PAIR) {
                 if (part == 0) gate_val = val;
-                else if ((lane & 7) == 0 && row < nvalid) out[row] = v_silu(gate_val) * val;
+                else if ((lane & 7) == 0 && row < nvalid) ik_st(out + row, v_silu(gate_val) * val);
             } else if ((lane & 7) == 0 && row < nvalid) {
                 float o = val;
                 if (EPI == BAMD_EPI_ADD) o = val + resv;
-                out[row] = o;
+                ik_st(out + row, o);
                 if (EPI == BAMD_EPI_ARGMAX) { const unsigned long long k = argmax_key(o, row); best = k > best ? k : best; }
             }
         }
@@ -198,7 +198,7 @@ __device__ __forceinline__ void stream_pair_short(const uint8_t * __restrict__ w
         for (int u = 0; u < Q; ++u) chain_step<TYPE>(Au, tu[u].x, tu[u].y, tu[u].z, tu[u].w);
         const float gate_val = finish_row<TYPE>(Ag), up_val = finish_row<TYPE>(Au);
         const int row = rg0 * 8 + (lane >> 3);
-        if ((lane & 7) == 0 && row < nvalid) out[row] = v_silu(gate_val) * up_val;
+        if ((lane & 7) == 0 && row < nvalid) ik_st(out + row, v_silu(gate_val) * up_val);
     }
 #undef BAMD_GU7_UP
 #undef BAMD_GU7_SB
@@ -298,7 +298,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         // the wave that will run the chain of row-group r0+wave fetches its residual now (old by chain time)
         const int crow = (first + (r0 + (wave < nbatch ? wave : 0)) * stride) * 8 + r8;
         float resv = 0.f;
-        if (EPI == BAMD_EPI_ADD && crow < nvalid) resv = res[crow];
+        if (EPI == BAMD_EPI_ADD && crow < nvalid) resv = ik_ld(res + crow);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             if (m < nbatch) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         if (r0 == 0) TL_STAMP(pa.tl, 3);
 #if BAMD_CEILING & 2
         // TIMING-ONLY ceiling build: no barrier, no chain replay — every wave stores from its own first parked term (garbage results)
-        if (wave < nbatch) { const float4 t = ((const float4 *) (B0 + (size_t) wave * rg_floats))[i0 * 64 + lane]; if ((lane & 7) == 0 && crow < nvalid) out[crow] = t.x + t.y + resv; }
+        if (wave < nbatch) { const float4 t = ((const float4 *) (B0 + (size_t) wave * rg_floats))[i0 * 64 + lane]; if ((lane & 7) == 0 && crow < nvalid) ik_st(out + crow, t.x + t.y + resv); }
         batchctr += 1; bbase += M * rg_step;
         continue;
 #endif
@@ -349,7 +349,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
             }
             if (UNEVEN) for (; i < nb; ++i) { const float4 t = P[i * 64 + lane]; chain_step<TYPE>(A, t.x, t.y, t.z, t.w); }
             const float val = finish_row<TYPE>(A);
-            if ((lane & 7) == 0 && crow < nvalid) out[crow] = EPI == BAMD_EPI_ADD ? val + resv : val;
+            if ((lane & 7) == 0 && crow < nvalid) ik_st(out + crow, EPI == BAMD_EPI_ADD ? val + resv : val);
             if (r0 == 0) TL_STAMP(pa.tl, 5);
         }
         batchctr += 1;

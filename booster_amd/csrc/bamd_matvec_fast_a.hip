@@ -96,8 +96,8 @@ static const bool g_gateup7 = [] { const char * e = getenv("BAMD_GATEUP7"); retu
 // ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
 template <int PRO, int EPI, int T0, int T1>
 static void launch_fast_a_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
-    if ((a.K >> 8) <= 16) hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI, 2>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
-    else                  hipLaunchKernelGGL((matvec_fast_kernel<T0, T1, PRO, EPI, 4>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
+    if ((a.K >> 8) <= 16) BAMD_LAUNCH((matvec_fast_kernel<T0, T1, PRO, EPI, 2>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
+    else                  BAMD_LAUNCH((matvec_fast_kernel<T0, T1, PRO, EPI, 4>), dim3(grid), dim3(512), act_lds_bytes(a.K), s, BAMD_LEAD_ARGS(a), a);
 }
 template <int PRO, int EPI>
 static bool launch_fast_a_types(const bamd_mv_args & a, int t0, int t1, int grid, hipStream_t s) {
@@ -125,7 +125,7 @@ bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t 
     a.cnt_q = nrg0 / slots; a.cnt_r = nrg0 % slots;
     if (g_gateup7 && pro == BAMD_PRO_NORM && epi == BAMD_EPI_SILU_MUL && nb == 16 && nrg0 == 7 * grid && (a.mode & 15) == 0) {
         const size_t lds = act_lds_bytes(a.K) + BAMD_GU7_PARK_BYTES(16) + 16;
-#define BAMD_G7(T_) if (t0 == T_) { hipLaunchKernelGGL((matvec_gateup7_kernel<T_, 2>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
+#define BAMD_G7(T_) if (t0 == T_) { BAMD_LAUNCH((matvec_gateup7_kernel<T_, 2>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
         BAMD_G7(BAMD_Q4_K) BAMD_G7(BAMD_Q5_K) BAMD_G7(BAMD_Q6_K)
 #undef BAMD_G7
     }

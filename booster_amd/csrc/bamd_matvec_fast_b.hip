@@ -137,7 +137,7 @@ __device__ __forceinline__ void split_mixed_body(const bamd_mv_args & a, const P
         const int row = in1 ? (g_last - nrg0) * 8 + r8 : ((lastw ? g_last : b + wave * grid) * 8 + r8);
         const bamd_mv_seg & sg = a.seg[in1 ? 1 : 0];
         const int nv = sg.nvalid > 0 ? sg.nvalid : sg.nrows;
-        if ((lane & 7) == 0 && row < nv) sg.out[row] = val;
+        if ((lane & 7) == 0 && row < nv) ik_st(sg.out + row, val);
         TL_STAMP(pa.tl, 5);
     }
 }
@@ -160,7 +160,7 @@ template <int TA, int TB, int NBW, int MA, bool COMPACT = false, int NW = 8>
 static void launch_mixed_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (MA + 1) * nb * (COMPACT ? 576 : 1024);
-    hipLaunchKernelGGL((matvec_split_mixed_kernel<TA, TB, NBW, MA, COMPACT, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
+    BAMD_LAUNCH((matvec_split_mixed_kernel<TA, TB, NBW, MA, COMPACT, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 // fused QKV launch with two differently typed segments; false: shape not covered (mode A takes it)
 bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s) {
@@ -193,7 +193,7 @@ template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false, int NW = 8
 static void launch_fast_b_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (NBW * M > 8 ? 1 : 2) * M * nb * 256 * 4;
-    hipLaunchKernelGGL((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
+    BAMD_LAUNCH((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 static const bool g_down14 = [] { const char * e = getenv("BAMD_DOWN14"); return !(e && e[0] == '0'); }();
 template <int PRO, int EPI>

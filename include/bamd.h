@@ -74,9 +74,13 @@ int bamd_kv_seq_div(bamd_context * c, int p0, int p1, int d);
 
 /* Greedy decode entirely on the device: n_steps single-token steps starting at position n_past; step 0 consumes
  * the arg-max of the logits left by the previous bamd_decode/bamd_generate_greedy call.  out_tokens receives
- * n_steps+1 ids: the token fed to each step, then the arg-max after the last step.  One hipGraph per step,
- * no host round trip between steps.  *elapsed_ms (optional) = HIP-event time of the n_steps steps. */
+ * n_steps+1 ids: the token fed to each step, then the arg-max after the last step.  No host round trip between
+ * steps: the steps are replayed as AQL packets with fence scope NONE from the library's own HSA queue (round 6; csrc/bamd_aql.h) where
+ * the step's kernels allow it, else as one hipGraph per step on the context's stream (bamd_set_aql(0) / BAMD_AQL=0 forces that).
+ * *elapsed_ms (optional) = time of the n_steps steps (HIP events; host clock from submission to completion on the own queue). */
 int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * out_tokens, float * elapsed_ms);
+void bamd_set_aql(int on);                 /* process-wide: 1 (default, also env BAMD_AQL) = own AQL queue where possible; 0 = hipGraph replays */
+int bamd_aql_runs(const bamd_context * c); /* bamd_generate_greedy calls of this context that ran on the own queue so far */
 
 /* ---- layer-split stage interface (one process per GPU; hidden state moves between stages) ---- */
 /* Run this stage's layers on one token.  The token id comes from `token`, or — when token_dev is non-NULL — from that
