@@ -9,47 +9,77 @@
 // holds a position <= pos (llama_set_inputs' mask, llama.cpp:14152-14200) — in CELL order, as the reference's soft_max and P.V run over the cache
 template <int GQ, int LG, bool SH>       // LG = head_dim / 64 = 16-byte groups of a K row per lane
 __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
+    // Round 6: the launch is a chain of latencies, not bytes — 16 MB of K at 8000 positions are 2.7 us at the HBM rate and the kernel took 7.9.
+    // A wave's loads return in order, so the q / k / RoPE requests that rounds 2-5 issued BEHIND the K prefetch (the prefetch clamp needed the position first)
+    // came back behind 64 KB of K rows per CU, and the prologue's barrier stood at 4.7 us.  Now: (1) the small requests go out first — this token's q / k / v pairs
+    // and the cos / sin row of the current position, which step_begin_kernel leaves at a FIXED address (a.rope_cur: no dependent load of the position in front of
+    // them); (2) the K rows of the first BAMD_QK_NT tiles right behind, unclamped (rows past the sequence are masked by a select; the cache is finite everywhere);
+    // (3) the scores leave through LDS as 16-byte write-through stores instead of scattered 4-byte ones.  All cross-launch data by the rules of bamd_device.h
+    // ("Inter-kernel data"): the step can be replayed from the own AQL queue.
+    constexpr int hd = 64 * LG, L = 8 * LG, hp = hd / 2;
+    constexpr int NPAIR = (GQ + 1) * hp, IT = (NPAIR + 511) / 512;      // adjacent pairs of the GQ query heads, then of the k head; pairs per thread
     __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
+    __shared__ __attribute__((aligned(16))) float scs[BAMD_QK_NT][GQ][64];   // scores of this workgroup's tiles in the V^T position order, on their way out
     const bamd_step_state * st = a.st;
-    const int pos = st->pos, n_kv = st->n_kv, cell = SH ? st->cell : pos;
-    constexpr int hd = 64 * LG, L = 8 * LG;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
-    const int hk = blockIdx.x;
-    // The K rows of this workgroup's first BAMD_QK_NT tiles are requested BEFORE the RoPE prologue, unconditionally (positions past
-    // the sequence read row 0): one memory latency for all of them, overlapped with the prologue.  (With the request inside the
-    // tile loop every tile cost a full HBM round trip: 10.2 us per layer at 8000 positions for 16 MB of K.)
+    const int hk = blockIdx.x, by = (int) blockIdx.y, gy = (int) gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), e = lane & 7, r = lane >> 3;
+    // ---- 1. the small requests ----
+    float2 xin[IT], cs[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 512, idc = idx < NPAIR ? idx : 0, hh = idc / hp, p = idc - hh * hp;
+        const float * src = hh < GQ ? a.q + (size_t) (hk * GQ + hh) * hd : a.k + (size_t) hk * hd;
+        xin[it] = ik_ld2f(src + 2 * p);
+        cs[it] = ik_ld2f(a.rope_cur + 2 * p);                    // (the launcher refuses a null rope_cur: no conditional request, no join in front of the prefetch)
+    }
+    const float vst = ik_ld(a.v + hk * hd + (tid < hd ? tid : 0));
+    const int pos = ik_ld(&st->pos), n_kv = ik_ld(&st->n_kv), cell = SH ? ik_ld(&st->cell) : pos;
+    // ---- 2. the K rows of this workgroup's first BAMD_QK_NT tiles: one memory latency for all of them, overlapped with the prologue ----
+    const bamd_ik_rsrc rk = ik_rsrc(a.kc);
     uint4 kpre[BAMD_QK_NT][LG];
 #define BAMD_QK_PREFETCH(t0_) do { \
         _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) { \
-            int i_ = ((t0_) + j * (int) gridDim.y) * 64 + (int) (threadIdx.x >> 6) * 8 + (int) ((threadIdx.x & 63) >> 3); i_ = i_ < (SH ? n_kv : pos) ? i_ : 0; \
-            const unsigned short * kr_ = a.kc + (size_t) i_ * Ekv + hk * hd + (int) (threadIdx.x & 7) * 8; \
-            _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = *(const uint4 *) (kr_ + g * BAMD_KGRP); \
+            int i_ = ((t0_) + j * gy) * 64 + wave * 8 + r; i_ = i_ < n_ctx ? i_ : 0; \
+            _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = ik_ld128(rk, (uint32_t) (i_ * Ekv + hk * hd + g * BAMD_KGRP + e * 8) * 2u); \
         } } while (0)
-    BAMD_QK_PREFETCH((int) blockIdx.y);
-    const float * rope = a.rope + (size_t) pos * hd;
-    rope_heads(a.q + (size_t) hk * GQ * hd, rope, hd, GQ, qt, q16t, nullptr);
-    rope_heads(a.k + (size_t) hk * hd, rope, hd, 1, nullptr, nullptr, k16t);
-    __syncthreads();
-    // KV store by the block that owns the tile of `pos` — llm_build_kv_store, llama.cpp:7830-7875
-    if ((int) blockIdx.y == ((cell >> 6) % (int) gridDim.y)) {
-        for (int i = threadIdx.x; i < hd; i += blockDim.x) {
-            a.kc[(size_t) cell * Ekv + hk * hd + i] = k16t[i];
-            a.vc[(size_t) (hk * hd + i) * n_ctx + vperm(cell)] = f2h(a.v[hk * hd + i]);
+#ifndef BAMD_QK_KNOCK
+#define BAMD_QK_KNOCK 0              /* timing-only experiment builds (results wrong): 1 = no K requests, 2 = no chains, 4 = no score stores, 8 = no RoPE prologue loads */
+#endif
+    if (!(BAMD_QK_KNOCK & 1)) BAMD_QK_PREFETCH(by);
+    else { _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = make_uint4(tid, j, g, 1); }
+    // ---- 3. RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143 — rope_heads' arithmetic) into the chain-major LDS copies ----
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 512;
+        if (idx < NPAIR) {
+            const int hh = idx / hp, p = idx - hh * hp;
+            const float t0 = xin[it].x * cs[it].x, t1 = xin[it].y * cs[it].y, t2 = xin[it].x * cs[it].y, t3 = xin[it].y * cs[it].x;
+            const float r0 = t0 - t1, r1 = t2 + t3;
+            const int i0 = kperm(2 * p, L), i1 = kperm(2 * p + 1, L);
+            if (hh < GQ) { qt[hh * hd + i0] = r0; qt[hh * hd + i1] = r1; q16t[hh * hd + i0] = f2h(r0); q16t[hh * hd + i1] = f2h(r1); }
+            else { k16t[i0] = f2h(r0); k16t[i1] = f2h(r1); }
         }
     }
-    const int lane = threadIdx.x & 63, wave = wave_id(), e = lane & 7;
+    __syncthreads();
+    // KV store by the block that owns the tile of `pos` — llm_build_kv_store, llama.cpp:7830-7875
+    if (by == ((cell >> 6) % gy) && tid < hd) {
+        ik_st(a.kc + (size_t) cell * Ekv + hk * hd + tid, k16t[tid]);
+        ik_st(a.vc + (size_t) (hk * hd + tid) * n_ctx + vperm(cell), f2h(vst));
+    }
+    const bamd_ik_rsrc rs = ik_rsrc(a.scores);
     const int tiles = (n_kv + 63) >> 6;
-    for (int tile0 = blockIdx.y; tile0 < tiles; tile0 += BAMD_QK_NT * gridDim.y) {
-        float sc[BAMD_QK_NT][GQ];
+    for (int tile0 = by; tile0 < tiles; tile0 += BAMD_QK_NT * gy) {
 #pragma unroll
         for (int j = 0; j < BAMD_QK_NT; ++j) {
-            const int i = (tile0 + j * (int) gridDim.y) * 64 + wave * 8 + (lane >> 3);        // position
+            const int i = (tile0 + j * gy) * 64 + wave * 8 + r;         // position
+            float sc[GQ];
 #pragma unroll
-            for (int g = 0; g < GQ; ++g) sc[j][g] = -INFINITY;  // masked (KQ_mask, llama.cpp:14152-14200)
+            for (int g = 0; g < GQ; ++g) sc[g] = -INFINITY;     // masked (KQ_mask, llama.cpp:14152-14200)
             bool live = i <= pos;                                // (i <= pos < n_kv)
-            if (SH) live = i < n_kv && (i == cell || (uint32_t) a.cellpos[i < n_kv ? i : 0] <= (uint32_t) pos);
+            if (SH) live = i < n_kv && (i == cell || (uint32_t) ik_ld(a.cellpos + (i < n_kv ? i : 0)) <= (uint32_t) pos);
             if (live) {
                 uint4 kreg[4];
 #pragma unroll
@@ -59,16 +89,23 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
                 }
 #pragma unroll
                 for (int g = 0; g < GQ; ++g) {
+                    if (BAMD_QK_KNOCK & 2) { sc[g] = __uint_as_float(kreg[0].x ^ kreg[1 < LG ? 1 : 0].w) + qt[g * hd + e * 8]; continue; }
                     const float v = a.prefill_mode ? kq_chain<true>(kreg, L, nullptr, q16t + g * hd + e * 8) : kq_chain<false>(kreg, L, qt + g * hd + e * 8, nullptr);
-                    sc[j][g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
+                    sc[g] = a.prefill_mode ? hsum8_vecdot(v) : hsum8_tinyblas(v);
                 }
             }
-            if (e == 0 && i < n_kv) {
+            if (e == 0) {
 #pragma unroll
-                for (int g = 0; g < GQ; ++g) a.scores[(size_t) (hk * GQ + g) * n_ctx + vperm(i)] = sc[j][g];     // V^T position order (the softmax passes read 16 bytes at a time)
+                for (int g = 0; g < GQ; ++g) scs[j][g][r * 8 + wave] = sc[g];      // position 8 w + r of a tile sits at 8 r + w (vperm)
             }
         }
-        if (tile0 + BAMD_QK_NT * (int) gridDim.y < tiles) BAMD_QK_PREFETCH(tile0 + BAMD_QK_NT * (int) gridDim.y);   // (n_ctx > 64 x BAMD_QK_NT x gridDim.y only)
+        __syncthreads();
+        // the tiles' scores in the V^T position order (the softmax passes read 16 bytes at a time), 16 bytes per thread, write-through
+        for (int q4 = tid; q4 < BAMD_QK_NT * GQ * 16; q4 += 512) {
+            const int j = q4 / (GQ * 16), g = (q4 >> 4) % GQ, c4 = q4 & 15, tile = tile0 + j * gy;
+            if (tile < tiles && (!(BAMD_QK_KNOCK & 4) || scs[j][g][c4 * 4] == 12345.f)) ik_st128f(rs, (uint32_t) ((hk * GQ + g) * n_ctx + tile * 64 + c4 * 4) * 4u, *(const float4 *) &scs[j][g][c4 * 4]);
+        }
+        if (tile0 + BAMD_QK_NT * gy < tiles) { __syncthreads(); BAMD_QK_PREFETCH(tile0 + BAMD_QK_NT * gy); }   // (n_ctx > 64 x BAMD_QK_NT x gridDim.y only)
     }
 #undef BAMD_QK_PREFETCH
 }
@@ -236,7 +273,7 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
     const bamd_rsrc vr = __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) a.vc), 0, (int) vc_bytes, 0x00020000);
     const uint32_t voff = (uint32_t) (((size_t) (hk * hd + d) * n_ctx + e * 8) * 2);
     uint4 ring[BAMD_SPV_R];
-#define BAMD_SPV_VLOAD(blk_) ({ const u32x4_t t_ = __builtin_amdgcn_raw_buffer_load_b128(vr, (int) voff, (blk_) * 128, 0); make_uint4(t_.x, t_.y, t_.z, t_.w); })
+#define BAMD_SPV_VLOAD(blk_) ({ const u32x4_t t_ = __builtin_amdgcn_raw_buffer_load_b128(vr, (int) voff, (blk_) * 128, BAMD_IK_AUX); make_uint4(t_.x, t_.y, t_.z, t_.w); })   /* V^T rows: inter-kernel data (bamd_device.h) */
     if (wave < NH) {
 #pragma unroll
         for (int u = 0; u < BAMD_SPV_R; ++u) ring[u] = BAMD_SPV_VLOAD(u);
@@ -249,7 +286,8 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
     float mx[NH];
 #pragma unroll
     for (int g = 0; g < NH; ++g) mx[g] = -INFINITY;
-    const int n_kv = st->n_kv;
+    const int n_kv = ik_ld(&st->n_kv);
+    const bamd_ik_rsrc rsc = ik_rsrc(a.scores);                  // the score rows: the previous launch's output
     // n_kv is a multiple of 32 (llama.cpp:14693-14701): nfull blocks of 64 positions and possibly half a block (attn_pv_kernel)
     const int nfull = n_kv >> 6, half = (n_kv >> 5) & 1, last = nfull - 1 + half;
     for (int B = B0; B <= last; B += 128) {                      // two blocks per thread and head requested together (one latency, not four)
@@ -260,7 +298,7 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
             for (int k = 0; k < 2; ++k) {
                 const int Bk = B + 64 * k;
                 w[g][k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                if (BAMD_SPV_VALID(Bk)) w[g][k] = *(const float4 *) (a.scores + (size_t) (h0 + g) * n_ctx + Bk * 64 + foff);
+                if (BAMD_SPV_VALID(Bk)) w[g][k] = ik_ld128f(rsc, (uint32_t) ((h0 + g) * n_ctx + Bk * 64 + foff) * 4u);
             }
 #pragma unroll
         for (int g = 0; g < NH; ++g)
@@ -368,7 +406,7 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
 #undef BAMD_SPV_VLOAD
 #undef BAMD_SPV_STEPS
     const float v = hsum8_tinyblas(acc);
-    if (e == 0) a.out[(size_t) (h0 + wave) * hd + d] = v;
+    if (e == 0) ik_st(a.out + (size_t) (h0 + wave) * hd + d, v);
 }
 
 #include "bamd_attn_fused.h"
@@ -598,6 +636,16 @@ template <int G> static bool spv_launch(const bamd_attn_args & a, hipStream_t s)
     BAMD_LAUNCH((attn_spv_kernel<(NH == 1 || NH == 2 || NH == 4) ? NH : 1>), dim3(a.Hkv, a.hd / 8, Z), dim3(1024), lds, s, a, G, (uint32_t) vcb);
     return true;
 }
+// 1 when the long-sequence path of this shape launches only kernels that keep the inter-kernel rules of bamd_device.h (scores | softmax + P.V in LDS): the step may be
+// replayed from the own AQL queue; the fallback pair attn_softmax_kernel + attn_pv_kernel (score rows beyond the LDS: n_ctx > ~19 K at four heads per KV head) may not
+int bamd_attention_split_is_ik_clean(const bamd_attn_args & a, int gq) {
+    switch (gq) {
+#define CASE(G) case G: return spv_ok<G>(a) ? 1 : 0;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return 0;
+}
 int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s) {
     if (a.hd > 256 || (a.hd & 63)) return 1;           // chain-major K rows are read in 16-byte (8-step) groups
     if (gq < 1 || gq > 8) return 1;
@@ -608,6 +656,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
         launch_attn_fused(a, gq, dim3(a.Hkv * gq), (size_t) ld * 8, s);
         return 0;
     }
+    if (!a.rope_cur) return 1;                                  // the score kernel takes the cos / sin row of the position from a fixed address (step_begin_kernel)
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;
     if (ty < 1) ty = 1;
     dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);

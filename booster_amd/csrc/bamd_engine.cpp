@@ -132,7 +132,7 @@ struct bamd_context {
     bamd_model * m = nullptr;
     int n_ctx = 0;
     std::vector<unsigned short *> kc, vc;
-    float * rope = nullptr;
+    float * rope = nullptr, * rope_cur = nullptr;   // rope_cur [hd]: the cos / sin row of the current step's position (step_begin_kernel -> attn_qk_kernel)
     float * x = nullptr, * x2 = nullptr, * q = nullptr, * k = nullptr, * v = nullptr, * att = nullptr, * h = nullptr, * scores = nullptr, * probs = nullptr;
     int n_ctx_pad = 0;              // KV row stride: n_ctx rounded up to 64 (V^T rows are stored in 64-position blocks)
     float * logits = nullptr;        // device
@@ -149,6 +149,8 @@ struct bamd_context {
     hipStream_t stream = nullptr;
     hipGraphExec_t graph = nullptr; int graph_fused = -1;
     bamd_aql_graph * aql = nullptr; int aql_key = -1; bool aql_failed = false; int aql_runs = 0;    // the same step as AQL packets for the own queue (bamd_aql.h)
+    bamd_aql_graph * aql_step = nullptr; int aql_step_key = -1; int aql_steps = 0;                 // bamd_stage_step's single-token step on the own queue
+    bamd_step_state * inbox = nullptr;           // pinned host memory: the state of that step, read by step_begin_kernel itself (no copy in front of the step)
     unsigned long long * co_gran = nullptr;   // co-launch granules [H * hd] {value, tag} + give-up counter behind them (bamd_colaunch.hip), zero-initialised
     uint32_t * co_err = nullptr;
     int32_t * slots = nullptr; int slots_cap = 0;   // device-side greedy loop after a context shift: {cell, padded KV length} of every step (bamd_generate_greedy)
@@ -386,6 +388,8 @@ static int context_init(bamd_context * c, bamd_model * m, int n_ctx) {
                      m->rope_ext_factor, m->rope_attn_factor, m->rope_n_ctx_orig, 32.0f, 1.0f);
         if (dev_alloc(c->allocs, (void **) &c->rope, tab.size() * 4)) return 1;
         HIPC(hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        if (dev_alloc(c->allocs, (void **) &c->rope_cur, (size_t) m->hd * 4)) return 1;
+        HIPC(hipMemcpy(c->rope_cur, tab.data(), (size_t) m->hd * 4, hipMemcpyHostToDevice));
     }
     if (dev_alloc(c->allocs, (void **) &c->x, (size_t) m->E * 4) || dev_alloc(c->allocs, (void **) &c->x2, (size_t) m->E * 4) ||
         dev_alloc(c->allocs, (void **) &c->q, (size_t) (m->E + 2 * Ekv) * 4) || dev_alloc(c->allocs, (void **) &c->att, (size_t) m->E * 4) ||
@@ -414,7 +418,8 @@ extern "C" __attribute__((visibility("default"))) void bamd_context_free(bamd_co
     if (!c) return;
     if (c->m) hipSetDevice(c->m->device);
     if (c->graph) hipGraphExecDestroy(c->graph);
-    bamd_aql_free(c->aql);
+    bamd_aql_free(c->aql); bamd_aql_free(c->aql_step);
+    if (c->inbox) hipHostFree(c->inbox);
     for (auto & row : c->sgraph) for (auto & g : row) if (g.exec) hipGraphExecDestroy(g.exec);
     for (void * p : c->allocs) hipFree(p);
     if (c->logits_host) hipHostFree(c->logits_host);
@@ -476,7 +481,7 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         if (tm) tm->end(s);
         // 2. RoPE, KV store, softmax(QK^T) V                               (llama.cpp:8837-8849, :8318-8353)
         bamd_attn_args t; memset(&t, 0, sizeof t);
-        t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
+        t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.rope_cur = c->rope_cur; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
         // single-launch kernel below 448 positions, three kernels (scores | softmax | P.V) above (attn_fused_for)
         t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances
@@ -531,7 +536,7 @@ static void enqueue_lm_head(bamd_context * c, hipStream_t s, StepTimer * tm) {
 static void enqueue_begin(bamd_context * c, int n_forced, int do_embed, hipStream_t s, bool with_slots = false) {
     bamd_model * m = c->m;
     bamd_launch_step_begin(c->st, c->forced, n_forced, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, do_embed, s,
-                           with_slots ? c->slots : nullptr, with_slots ? c->cellpos : nullptr);
+                           with_slots ? c->slots : nullptr, with_slots ? c->cellpos : nullptr, c->rope, c->rope_cur, m->hd);
 }
 
 // The tag of a granule hand-over (bamd_colaunch.hip) is (host serial : 12, device step : 12, layer : 8); a word must never already hold the tag a
@@ -1062,9 +1067,14 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     const int fused = (attn_fused_for(c, attn_hi) ? 1 : (c->cells.active ? 2 : 0));     // 2: the shifted-cell kernels and the slot table (other arguments: recapture)
     float ms_steps = 0.f;
     EventPair ev; bool timed_by_events = false;
-    // the step as AQL packets on the library's own queue (bamd_aql.h): the launch sequence of the single-launch attention path, whose kernels keep the
-    // inter-kernel rules of bamd_device.h; anything else (long sequences, shifted cells) replays the hipGraph
-    const bool want_aql = g_aql && fused == 1 && !c->aql_failed;
+    // the step as AQL packets on the library's own queue (bamd_aql.h): the launch sequences whose kernels keep the inter-kernel rules of bamd_device.h — the
+    // single-launch attention path and the scores | softmax + P.V path of long sequences; anything else (shifted cells, score rows beyond the LDS) replays the hipGraph
+    bool aql_path_ok = fused == 1;
+    if (fused == 0) {                                                 // long sequences: scores | softmax + P.V, when its kernels are the inter-kernel-clean ones
+        bamd_attn_args t; memset(&t, 0, sizeof t); t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad;
+        aql_path_ok = bamd_attention_split_is_ik_clean(t, m->H / m->Hkv) != 0;
+    }
+    const bool want_aql = g_aql && aql_path_ok && !c->aql_failed;
     if (c->aql && (c->aql_key != fused || !want_aql)) { bamd_aql_free(c->aql); c->aql = nullptr; }
     if (want_aql && !c->aql) {
         bamd_aql_recording rec;
@@ -1107,7 +1117,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_generate_greedy(bamd_
     return 0;
 }
 // how many bamd_generate_greedy calls of this context ran on the own AQL queue so far (tests, bench: which path produced the number)
-extern "C" __attribute__((visibility("default"))) int bamd_aql_runs(const bamd_context * c) { return c->aql_runs; }
+extern "C" __attribute__((visibility("default"))) int bamd_aql_runs(const bamd_context * c) { return c->aql_runs + c->aql_steps; }
 
 // ---- layer-split stage ---------------------------------------------------------------------------------
 extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_context * c, int32_t token, const void * token_dev, int pos, const void * hidden_in_dev,
@@ -1116,6 +1126,43 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     HIPC(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t) hip_stream;            // NULL = the HIP default (null) stream, as for any HIP API
     if (pos < 0 || pos >= c->n_ctx) return fail("position out of range");
+    // ---- own AQL queue (bamd_aql.h): the whole single-stage step — state from a pinned host inbox, layers, lm_head — as packets with fence scope NONE, one host
+    //      wait at its end.  For the caller that owns embedding and output, feeds host tokens on the context's own stream and wants the logits (bamd_decode from
+    //      the bridge's token loop); layer-split stages, device-side tokens, shifted cells and prefill-mode steps keep the stage graphs below ----
+    if (g_aql && !c->aql_failed && m->with_embd && m->with_output && !token_dev && !hidden_in_dev && !hidden_out_dev && want_logits && !prefill_mode &&
+        !c->cells.active && s == c->stream && s != nullptr) {
+        const int fused = attn_fused_for(c, pos) ? 1 : 0;
+        bool ok = fused == 1;
+        if (!ok) { bamd_attn_args t; memset(&t, 0, sizeof t); t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; ok = bamd_attention_split_is_ik_clean(t, m->H / m->Hkv) != 0; }
+        if (ok && !c->inbox && hipHostMalloc((void **) &c->inbox, sizeof(bamd_step_state)) != hipSuccess) { (void) hipGetLastError(); c->inbox = nullptr; ok = false; }
+        if (ok) {
+            if (c->aql_step && c->aql_step_key != fused) { bamd_aql_free(c->aql_step); c->aql_step = nullptr; }
+            if (!c->aql_step) {
+                bamd_aql_recording rec;
+                bamd_aql_rec = &rec;
+                bamd_launch_step_begin(c->st, c->forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, s, nullptr, nullptr, c->rope, c->rope_cur, m->hd, c->inbox);
+                const int rc = enqueue_layers(c, 0, s, nullptr, pos);
+                enqueue_lm_head(c, s, nullptr);
+                bamd_aql_rec = nullptr;
+                const char * why = "recording failed";
+                if (!rc) c->aql_step = bamd_aql_build(m->device, rec, &why);
+                if (!c->aql_step) { c->aql_failed = true; if (getenv("BAMD_AQL_VERBOSE")) fprintf(stderr, "bamd: own AQL queue not used: %s\n", why ? why : "?"); }
+                c->aql_step_key = fused;
+            }
+        }
+        if (ok && c->aql_step) {
+            if (next_serial(c, s)) return 1;
+            c->n_cached = std::max(c->n_cached, pos + 1);
+            HIPC(hipStreamSynchronize(s));                               // whatever this context enqueued before (a prompt micro-batch nobody waited for) is done
+            bamd_step_state * in = c->inbox;
+            memset(in, 0, sizeof *in);
+            in->pos_base = pos; in->n_ctx = c->n_ctx; in->serial = c->host_serial; in->token = token;
+            const char * why = nullptr;
+            if (bamd_aql_run(c->aql_step, 1, nullptr, &why)) return fail(std::string("own AQL queue: ") + (why ? why : "?"));
+            c->aql_steps += 1;
+            return 0;
+        }
+    }
     // state for exactly this token: pos_base = pos, step = 0, one forced token (from the host, or from a device int32)
     if (next_serial(c, s)) return 1;
     bamd_step_state h; memset(&h, 0, sizeof h); h.pos_base = pos; h.n_ctx = c->n_ctx; h.serial = c->host_serial;
@@ -1134,10 +1181,10 @@ extern "C" __attribute__((visibility("default"))) int bamd_stage_step(bamd_conte
     // everything after the two small host copies is a fixed launch sequence for given pointers: replay it as one hipGraph
     // (a stage of 4 layers is ~22 launches at ~8 us of host time each; the layer-split pipeline is host-bound without this)
     auto enqueue = [&](hipStream_t q) -> int {
-        if (m->with_embd) bamd_launch_step_begin(c->st, forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, q);
+        if (m->with_embd) bamd_launch_step_begin(c->st, forced, 1, c->out_tokens, m->tok_embd.raw, m->tok_embd.type, m->E, m->V, c->x, 1, q, nullptr, nullptr, c->rope, c->rope_cur, m->hd);
         else {
             // no embedding on this stage: still advance the device state (pos, n_kv), then take the hidden state
-            bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, q);
+            bamd_launch_step_begin(c->st, c->forced, 0, c->out_tokens, nullptr, BAMD_F32, 0, m->V, c->x, 1, q, nullptr, nullptr, c->rope, c->rope_cur, m->hd);
             HIPC(hipMemcpyAsync(c->x, hidden_in_dev, (size_t) m->E * 4, hipMemcpyDeviceToDevice, q));
         }
         if (enqueue_layers(c, prefill_mode, q, nullptr, attn_hi)) return 1;
@@ -1458,7 +1505,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_attention(const fl
     a.st = (bamd_step_state *) t.up(&h, sizeof h);
     a.q = (float *) t.up(q, (size_t) H * hd * 4); a.k = (float *) t.up(k, (size_t) Ekv * 4); a.v = (float *) t.up(v, (size_t) Ekv * 4);
     a.kc = (unsigned short *) t.up(kd.data(), kvb); a.vc = (unsigned short *) t.up(vd.data(), kvb);
-    a.rope = (float *) t.up(rope.data(), rope.size() * 4); a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4);
+    a.rope = (float *) t.up(rope.data(), rope.size() * 4); if (a.rope) a.rope_cur = a.rope + (size_t) pos * hd; a.scores = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4);
     a.probs = (float *) t.up(nullptr, (size_t) H * n_ctx_pad * 4); a.out = (float *) t.up(nullptr, (size_t) H * hd * 4);
     if (!a.st || !a.q || !a.k || !a.v || !a.kc || !a.vc || !a.rope || !a.scores || !a.probs || !a.out) return fail("device alloc/copy failed");
     a.hd = hd; a.Hkv = Hkv; a.n_ctx = n_ctx_pad; a.kq_scale = 1.0f / sqrtf((float) hd); a.prefill_mode = prefill_mode;

@@ -40,6 +40,8 @@ struct bamd_attn_args {
     const float * q, * k, * v;     // f32 [H*hd], [Hkv*hd], [Hkv*hd] of this token (pre-RoPE)
     unsigned short * kc, * vc;     // f16 caches of this layer, chain-major order (bamd_device.h): K [n_ctx][Hkv*hd], V^T [Hkv*hd][n_ctx]; n_ctx % 64 == 0
     const float * rope;            // [n_ctx][hd] (cos,sin) pairs
+    const float * rope_cur;        // [hd]: the row of the CURRENT position, left at this fixed address by step_begin_kernel (the long-sequence score kernel requests it
+                                   // without a dependent load of the position in front); null = take the row from `rope` (op-level tests, batched prefill)
     float * scores;                // [H][n_ctx] scratch: scores (long-context path)
     float * probs;                 // [H][n_ctx] scratch: probabilities in V^T position order (long-context path)
     float * out;                   // [H*hd]
@@ -73,8 +75,10 @@ void bamd_launch_repack(const void * raw, void * dst, int type, int nrows, int K
 void bamd_launch_quantize_q8k_test(const float * x, const float * nw, float eps, int K, int norm, void * out, hipStream_t s);
 void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipStream_t s);
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
-                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots = nullptr, int32_t * cellpos = nullptr);
+                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots = nullptr, int32_t * cellpos = nullptr,
+                            const float * rope = nullptr, float * rope_cur = nullptr, int hd = 0, const bamd_step_state * inbox = nullptr);
 int  bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipStream_t s);
+int  bamd_attention_split_is_ik_clean(const bamd_attn_args & a, int gq);      // the long-sequence path of this shape keeps the inter-kernel rules (bamd_device.h): own-queue replay allowed
 // single-launch attention and the wo projection (+ residual) behind it in ONE launch (bamd_colaunch.hip); gran: [H * hd] zero-initialised 8-byte
 // granules of the context (the attention output travels through them), il: layer index (part of the tag), err: give-up counter.
 // 1 = this shape has no co-launch kernel: issue the two launches

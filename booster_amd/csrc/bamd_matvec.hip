@@ -200,15 +200,31 @@ __global__ void __launch_bounds__(512) matvec_split_kernel(bamd_mv_args a) {
 // the tokens, so the host runs it for all steps ahead (bamd_generate_greedy) — and records the position in the cell's mask entry (cellpos)
 __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, const int32_t * forced, int n_forced,
                                                          int32_t * out_tokens, const uint8_t * embd, int embd_type, int E, int V,
-                                                         float * x, int do_embed, const int32_t * slots, int32_t * cellpos) {
-    __shared__ int tok_s;
+                                                         float * x, int do_embed, const int32_t * slots, int32_t * cellpos,
+                                                         const float * rope, float * rope_cur, int hd, const bamd_step_state * inbox) {
+    __shared__ int tok_s, pos_s;
     if (threadIdx.x == 0) {
         // the state is inter-kernel data (bamd_device.h): sc1 loads, issued together (ONE round trip for the fields this step needs), sc1 stores
         bamd_step_state h;
-        h.pos_base = ik_ld(&st->pos_base); h.step = ik_ld(&st->step); h.n_ctx = ik_ld(&st->n_ctx); h.n_out = ik_ld(&st->n_out);
-        h.cell_plus1 = ik_ld(&st->cell_plus1); h.n_kv_fixed = ik_ld(&st->n_kv_fixed); h.best_key = ik_ld(&st->best_key);
-        const int step = h.step;
-        const int ftok = step < n_forced ? ik_ld(forced + step) : 0;
+        int step, ftok;
+        if (inbox) {
+            // the host left this step's state in pinned host memory (bamd_stage_step on the own AQL queue: no copy engine, no HIP stream in front of the step):
+            // system-scope loads, then the device state is initialised as the host's copy of the whole struct would have left it
+            h.pos_base = __hip_atomic_load(&inbox->pos_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            h.n_ctx = __hip_atomic_load(&inbox->n_ctx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            h.cell_plus1 = __hip_atomic_load(&inbox->cell_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            h.n_kv_fixed = __hip_atomic_load(&inbox->n_kv_fixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            h.serial = __hip_atomic_load(&inbox->serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ftok = __hip_atomic_load(&inbox->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            h.step = 0; h.n_out = 0; h.best_key = 0ull; step = 0;
+            ik_st(&st->pos_base, h.pos_base); ik_st(&st->n_ctx, h.n_ctx); ik_st(&st->cell_plus1, h.cell_plus1); ik_st(&st->n_kv_fixed, h.n_kv_fixed);
+            ik_st(&st->serial, h.serial); ik_st(&st->n_out, 0);
+        } else {
+            h.pos_base = ik_ld(&st->pos_base); h.step = ik_ld(&st->step); h.n_ctx = ik_ld(&st->n_ctx); h.n_out = ik_ld(&st->n_out);
+            h.cell_plus1 = ik_ld(&st->cell_plus1); h.n_kv_fixed = ik_ld(&st->n_kv_fixed); h.best_key = ik_ld(&st->best_key);
+            step = h.step;
+            ftok = step < n_forced ? ik_ld(forced + step) : 0;
+        }
         int tok = 0;
         if (h.best_key != 0ull) {                             // arg-max of the previous lm_head, 0 = none ran
             tok = (int) (0xffffffffu - (uint32_t) (h.best_key & 0xffffffffull));
@@ -221,6 +237,7 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
         ik_st(&st->token, tok);
         if (do_embed) {
             h.pos = h.pos_base + step;
+            pos_s = h.pos;
             h.cell = h.cell_plus1 ? h.cell_plus1 - 1 + step : h.pos;
             int n_kv = (h.pos + 1 + 31) / 32 * 32;
             if (n_kv > h.n_ctx) n_kv = h.n_ctx;
@@ -233,6 +250,8 @@ __global__ void __launch_bounds__(1024) step_begin_kernel(bamd_step_state * st, 
     }
     __syncthreads();
     if (!do_embed) return;
+    // the cos / sin row of this step's position at a fixed address (bamd_attn_args::rope_cur)
+    if (rope_cur && (int) threadIdx.x < hd) ik_st(rope_cur + threadIdx.x, rope[(size_t) pos_s * hd + threadIdx.x]);
     embed_row(embd, embd_type, E, tok_s, x);
 }
 
@@ -313,8 +332,10 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
 }
 
 void bamd_launch_step_begin(bamd_step_state * st, const int32_t * forced, int n_forced, int32_t * out_tokens, const void * embd,
-                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots, int32_t * cellpos) {
-    BAMD_LAUNCH(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed, slots, cellpos);
+                            int embd_type, int E, int V, float * x, int do_embed, hipStream_t s, const int32_t * slots, int32_t * cellpos,
+                            const float * rope, float * rope_cur, int hd, const bamd_step_state * inbox) {
+    BAMD_LAUNCH(step_begin_kernel, dim3(1), dim3(1024), 0, s, st, forced, n_forced, out_tokens, (const uint8_t *) embd, embd_type, E, V, x, do_embed, slots, cellpos,
+                rope, rope_cur, hd, inbox);
 }
 
 

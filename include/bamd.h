@@ -80,7 +80,7 @@ int bamd_kv_seq_div(bamd_context * c, int p0, int p1, int d);
  * *elapsed_ms (optional) = time of the n_steps steps (HIP events; host clock from submission to completion on the own queue). */
 int bamd_generate_greedy(bamd_context * c, int n_past, int n_steps, int32_t * out_tokens, float * elapsed_ms);
 void bamd_set_aql(int on);                 /* process-wide: 1 (default, also env BAMD_AQL) = own AQL queue where possible; 0 = hipGraph replays */
-int bamd_aql_runs(const bamd_context * c); /* bamd_generate_greedy calls of this context that ran on the own queue so far */
+int bamd_aql_runs(const bamd_context * c); /* bamd_generate_greedy calls + single-token bamd_decode steps of this context that ran on the own queue so far */
 
 /* ---- layer-split stage interface (one process per GPU; hidden state moves between stages) ---- */
 /* Run this stage's layers on one token.  The token id comes from `token`, or — when token_dev is non-NULL — from that
