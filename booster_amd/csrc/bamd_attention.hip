@@ -7,13 +7,14 @@
 #define BAMD_QK_NT 4                     /* tiles of 64 positions per workgroup whose K rows are in flight together */
 // SH: cells no longer follow positions (a context shift happened: a.cellpos).  The token's K / V go to cell st->cell, a cell is attended when it
 // holds a position <= pos (llama_set_inputs' mask, llama.cpp:14152-14200) — in CELL order, as the reference's soft_max and P.V run over the cache
-template <int GQ, int LG, bool SH>       // LG = head_dim / 64 = 16-byte groups of a K row per lane
+template <int GQ, int LG, bool SH, int NT = BAMD_QK_NT>       // LG = head_dim / 64 = 16-byte groups of a K row per lane; NT = tiles of 64 positions per workgroup in flight together
+// (the launcher picks 2 when the context has no more than two tiles per workgroup: no request for a tile that cannot exist)
 __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     // Round 6: the launch is a chain of latencies, not bytes — 16 MB of K at 8000 positions are 2.7 us at the HBM rate and the kernel took 7.9.
     // A wave's loads return in order, so the q / k / RoPE requests that rounds 2-5 issued BEHIND the K prefetch (the prefetch clamp needed the position first)
     // came back behind 64 KB of K rows per CU, and the prologue's barrier stood at 4.7 us.  Now: (1) the small requests go out first — this token's q / k / v pairs
     // and the cos / sin row of the current position, which step_begin_kernel leaves at a FIXED address (a.rope_cur: no dependent load of the position in front of
-    // them); (2) the K rows of the first BAMD_QK_NT tiles right behind, unclamped (rows past the sequence are masked by a select; the cache is finite everywhere);
+    // them); (2) the K rows of the first NT tiles right behind, unclamped (rows past the sequence are masked by a select; the cache is finite everywhere);
     // (3) the scores leave through LDS as 16-byte write-through stores instead of scattered 4-byte ones.  All cross-launch data by the rules of bamd_device.h
     // ("Inter-kernel data"): the step can be replayed from the own AQL queue.
     constexpr int hd = 64 * LG, L = 8 * LG, hp = hd / 2;
@@ -21,7 +22,7 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     __shared__ __attribute__((aligned(16))) float qt[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short q16t[GQ * 256];
     __shared__ __attribute__((aligned(16))) unsigned short k16t[256];
-    __shared__ __attribute__((aligned(16))) float scs[BAMD_QK_NT][GQ][64];   // scores of this workgroup's tiles in the V^T position order, on their way out
+    __shared__ __attribute__((aligned(16))) float scs[NT][GQ][64];   // scores of this workgroup's tiles in the V^T position order, on their way out
     const bamd_step_state * st = a.st;
     const int Hkv = a.Hkv, Ekv = Hkv * hd, n_ctx = a.n_ctx;
     const int hk = blockIdx.x, by = (int) blockIdx.y, gy = (int) gridDim.y;
@@ -37,11 +38,11 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     }
     const float vst = ik_ld(a.v + hk * hd + (tid < hd ? tid : 0));
     const int pos = ik_ld(&st->pos), n_kv = ik_ld(&st->n_kv), cell = SH ? ik_ld(&st->cell) : pos;
-    // ---- 2. the K rows of this workgroup's first BAMD_QK_NT tiles: one memory latency for all of them, overlapped with the prologue ----
+    // ---- 2. the K rows of this workgroup's first NT tiles: one memory latency for all of them, overlapped with the prologue ----
     const bamd_ik_rsrc rk = ik_rsrc(a.kc);
-    uint4 kpre[BAMD_QK_NT][LG];
+    uint4 kpre[NT][LG];
 #define BAMD_QK_PREFETCH(t0_) do { \
-        _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) { \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) { \
             int i_ = ((t0_) + j * gy) * 64 + wave * 8 + r; i_ = i_ < n_ctx ? i_ : 0; \
             _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = ik_ld128(rk, (uint32_t) (i_ * Ekv + hk * hd + g * BAMD_KGRP + e * 8) * 2u); \
         } } while (0)
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
 #define BAMD_QK_KNOCK 0              /* timing-only experiment builds (results wrong): 1 = no K requests, 2 = no chains, 4 = no score stores, 8 = no RoPE prologue loads */
 #endif
     if (!(BAMD_QK_KNOCK & 1)) BAMD_QK_PREFETCH(by);
-    else { _Pragma("unroll") for (int j = 0; j < BAMD_QK_NT; ++j) _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = make_uint4(tid, j, g, 1); }
+    else { _Pragma("unroll") for (int j = 0; j < NT; ++j) _Pragma("unroll") for (int g = 0; g < LG; ++g) kpre[j][g] = make_uint4(tid, j, g, 1); }
     // ---- 3. RoPE (NORM mode, adjacent pairs; ggml.c:14130-14143 — rope_heads' arithmetic) into the chain-major LDS copies ----
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -71,9 +72,9 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
     }
     const bamd_ik_rsrc rs = ik_rsrc(a.scores);
     const int tiles = (n_kv + 63) >> 6;
-    for (int tile0 = by; tile0 < tiles; tile0 += BAMD_QK_NT * gy) {
+    for (int tile0 = by; tile0 < tiles; tile0 += NT * gy) {
 #pragma unroll
-        for (int j = 0; j < BAMD_QK_NT; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int i = (tile0 + j * gy) * 64 + wave * 8 + r;         // position
             float sc[GQ];
 #pragma unroll
@@ -101,11 +102,11 @@ __global__ void __launch_bounds__(512) attn_qk_kernel(bamd_attn_args a) {
         }
         __syncthreads();
         // the tiles' scores in the V^T position order (the softmax passes read 16 bytes at a time), 16 bytes per thread, write-through
-        for (int q4 = tid; q4 < BAMD_QK_NT * GQ * 16; q4 += 512) {
+        for (int q4 = tid; q4 < NT * GQ * 16; q4 += 512) {
             const int j = q4 / (GQ * 16), g = (q4 >> 4) % GQ, c4 = q4 & 15, tile = tile0 + j * gy;
             if (tile < tiles && (!(BAMD_QK_KNOCK & 4) || scs[j][g][c4 * 4] == 12345.f)) ik_st128f(rs, (uint32_t) ((hk * GQ + g) * n_ctx + tile * 64 + c4 * 4) * 4u, *(const float4 *) &scs[j][g][c4 * 4]);
         }
-        if (tile0 + BAMD_QK_NT * gy < tiles) { __syncthreads(); BAMD_QK_PREFETCH(tile0 + BAMD_QK_NT * gy); }   // (n_ctx > 64 x BAMD_QK_NT x gridDim.y only)
+        if (tile0 + NT * gy < tiles) { __syncthreads(); BAMD_QK_PREFETCH(tile0 + NT * gy); }   // (n_ctx > 64 x NT x gridDim.y only)
     }
 #undef BAMD_QK_PREFETCH
 }
@@ -660,6 +661,7 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
     int ty = max_tiles < 0 ? -max_tiles : max_tiles;
     if (ty < 1) ty = 1;
     dim3 g1(a.Hkv, ty), g3(a.Hkv, a.hd / 8);
+    const bool nt2 = (a.n_ctx / 64 + ty - 1) / ty <= 2;         // at most two tiles per score workgroup in this context: the two-slot instance
     switch (gq) {
 #define CASE(G) case G: \
         if (a.cellpos) switch (a.hd >> 6) { \
@@ -667,6 +669,11 @@ int bamd_launch_attention(const bamd_attn_args & a, int gq, int max_tiles, hipSt
             case 2: BAMD_LAUNCH((attn_qk_kernel<G, 2, true>), g1, dim3(512), 0, s, a); break; \
             case 3: BAMD_LAUNCH((attn_qk_kernel<G, 3, true>), g1, dim3(512), 0, s, a); break; \
             default: BAMD_LAUNCH((attn_qk_kernel<G, 4, true>), g1, dim3(512), 0, s, a); break; \
+        } else if (nt2) switch (a.hd >> 6) { \
+            case 1: BAMD_LAUNCH((attn_qk_kernel<G, 1, false, 2>), g1, dim3(512), 0, s, a); break; \
+            case 2: BAMD_LAUNCH((attn_qk_kernel<G, 2, false, 2>), g1, dim3(512), 0, s, a); break; \
+            case 3: BAMD_LAUNCH((attn_qk_kernel<G, 3, false, 2>), g1, dim3(512), 0, s, a); break; \
+            default: BAMD_LAUNCH((attn_qk_kernel<G, 4, false, 2>), g1, dim3(512), 0, s, a); break; \
         } else switch (a.hd >> 6) { \
             case 1: BAMD_LAUNCH((attn_qk_kernel<G, 1, false>), g1, dim3(512), 0, s, a); break; \
             case 2: BAMD_LAUNCH((attn_qk_kernel<G, 2, false>), g1, dim3(512), 0, s, a); break; \
