@@ -56,7 +56,6 @@ def lib():
         L.bamd_profile_step.argtypes = [vp, ci, vp, vp, vp]; L.bamd_profile_step_kinds.argtypes = [vp, ci, vp, vp, vp]
         L.bamd_timeline_step.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
         L.bamd_set_prefill_batch.argtypes = [ci]; L.bamd_set_prefill_batch.restype = None
-        L.bamd_set_prefill_version.argtypes = [ci]; L.bamd_set_prefill_version.restype = None
         L.bamd_bench_matvec.argtypes = [ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)]
         L.bamd_op_quantize_q8_K.argtypes = [vp, i64, vp, cf, vp]
         L.bamd_op_mul_mat_vec.argtypes = [ci, vp, ci, ci, vp, vp, cf, vp, vp, ci]
@@ -83,11 +82,6 @@ def _p(a):
 def set_prefill_batch(on):
     """True (default): prompts of 2..512 tokens go through the batched prefill kernels; False: token by token (same bits)."""
     lib().bamd_set_prefill_batch(int(on))      # 2: batched without the MFMA kernel
-
-
-def set_prefill_version(v):
-    """2 (default): the round-5 matrix-core prefill kernels (bamd_prefill2.hip, load-time side tables); 1: the round-2 kernels (bamd_prefill.hip).  Same bits."""
-    lib().bamd_set_prefill_version(int(v))
 
 
 def set_aql(on):

@@ -30,10 +30,10 @@ static thread_local std::string g_err;
 static int g_prefill_batch = [] { const char * e = getenv("BAMD_PREFILL_BATCH"); return (e && e[0] == '0') ? 0 : 1; }();
 // BAMD_PREFILL_MFMA=0: Q4_K mat-muls of the batched prefill on the integer-dot kernel instead of the MFMA kernel (same bits)
 static int g_prefill_mfma = [] { const char * e = getenv("BAMD_PREFILL_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();
-// BAMD_PREFILL_V=1: the round-2 MFMA kernels (bamd_prefill.hip: every wave expands its own 16 rows); default 2: bamd_prefill2.hip (fragments built once per
-// workgroup, load-time side tables).  Same bits; a matrix without a side table (allocation failed) takes the round-2 kernel
-static int g_prefill_v = [] { const char * e = getenv("BAMD_PREFILL_V"); return (e && e[0] == '1') ? 1 : 2; }();
-extern "C" __attribute__((visibility("default"))) void bamd_set_prefill_version(int v) { g_prefill_v = v == 1 ? 1 : 2; }   // tests: the same fixture through both kernel generations
+// The matrix-core kernels need a side table per matrix (bamd_prefill2.hip): built at MODEL LOAD, all matrices or none, against an explicit memory budget — after the
+// weights are resident the tables (+ 78 % of the Q4_K / Q5_K bytes, + 63 % of the Q6_K bytes) must leave BAMD_PREFILL_AUX_RESERVE_GB (default 8) GiB of the device free,
+// else the model runs its prompts on the integer-dot kernel (token by token where that has no instance).  BAMD_PREFILL_AUX=0 skips them (decode-only deployments).
+static const int g_prefill_aux = [] { const char * e = getenv("BAMD_PREFILL_AUX"); return (e && e[0] == '0') ? 0 : 1; }();
 // BAMD_STAGE_GRAPH=0: bamd_stage_step enqueues its kernels one by one instead of replaying a captured hipGraph
 static const int g_stage_graph = [] { const char * e = getenv("BAMD_STAGE_GRAPH"); return (e && e[0] == '0') ? 0 : 1; }();
 static const bool g_attn_fused = [] { const char * e = getenv("BAMD_ATTN_FUSED"); return !(e && e[0] == '0'); }();   // default: fused single-launch attention (BAMD_ATTN_FUSED=0: three-kernel path)
@@ -125,7 +125,7 @@ struct bamd_model {
     int n_cu = 256;
     std::unique_ptr<GgufFile> file;  // stays mapped (bamd_model_tensor_raw)
     std::vector<void *> allocs;
-    std::mutex aux_mu; bool aux_tried = false; int64_t aux_bytes = 0;
+    bool aux_ok = false; int64_t aux_bytes = 0; std::string aux_why;      // prefill side tables: all matrices or none (build_prefill_aux)
 };
 
 struct bamd_context {
@@ -223,6 +223,7 @@ static int upload_f32(bamd_model * m, const GgufTensor * t, float ** p, int n, h
     return 0;
 }
 
+static void build_prefill_aux(bamd_model * m, hipStream_t s);
 static int model_load_impl(bamd_model * m, const char * path, int device, int lf, int ll, int with_embd, int with_output) {
     // the file is read and its header validated before any device is touched: a bad file is reported as such on any machine
     m->file.reset(new GgufFile());
@@ -336,6 +337,10 @@ static int model_load_impl(bamd_model * m, const char * path, int device, int lf
     } while (0);
     hipStreamSynchronize(s);
     hipFree(staging);
+    if (!rc) {
+        build_prefill_aux(m, s);
+        if (!m->aux_ok && getenv("BAMD_PREFILL_VERBOSE")) fprintf(stderr, "bamd: prompts run without the matrix-core kernels: %s\n", m->aux_why.c_str());
+    }
     hipStreamDestroy(s);
     return rc;
 }
@@ -714,43 +719,60 @@ static bool prefill_batch_supported(const bamd_context * c, int pos_hi) {
     const bamd_model * m = c->m;
     const int gq = m->H / m->Hkv;
     if (!(g_prefill_batch && g_attn_fused && (size_t) attn_lds_ld(c, pos_hi) * 8 <= 144 * 1024 && m->hd <= 256 && (m->hd & 63) == 0 && gq >= 1 && gq <= 8)) return false;
-    // every mat-mul needs a kernel: the MFMA kernels take every K-quant at any K; the integer-dot kernel takes any
-    // K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
-    auto ok = [&](int type, int K) { return (g_prefill_mfma && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
+    // every mat-mul needs a kernel: the matrix-core kernels take every K-quant at any K when the model has its side tables; the integer-dot kernel
+    // takes any K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
+    auto ok = [&](int type, int K) { return (g_prefill_mfma && m->aux_ok && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
     for (const DevLayer & ly : m->layers)
         if (!ok(ly.wq.type, m->E) || !ok(ly.wk.type, m->E) || !ok(ly.wv.type, m->E) || !ok(ly.wo.type, m->E) || !ok(ly.wg.type, m->E) || !ok(ly.wu.type, m->E) || !ok(ly.wd.type, m->F)) return false;
     return true;
 }
-// prefill side tables of every layer matrix (bamd_prefill2.hip), built once per model at the first batched evaluation.  The QKV segments are the ones
-// enqueue_prefill_batch forms (equal-typed neighbours of the fused wq | wk | wv stream merge into one matrix).  An allocation that fails leaves that
-// pointer null: the matrix then runs on the round-2 kernel.
-static void ensure_prefill_aux(bamd_model * m, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(m->aux_mu);
-    if (m->aux_tried || g_prefill_v != 2 || !g_prefill_mfma) return;
-    m->aux_tried = true;
-    auto make = [&](const void * stream, int type, int nrows_pad, int K) -> void * {
-        const size_t b = bamd_prefill_aux_bytes(type, nrows_pad, K);
-        void * p = nullptr;
-        if (!b || hipMalloc(&p, b) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
-        m->allocs.push_back(p); m->aux_bytes += (int64_t) b;
-        bamd_launch_prefill_aux(stream, type, nrows_pad, K, p, s);
-        return p;
-    };
+// prefill side tables of every layer matrix (bamd_prefill2.hip), built at model load (round 6; round 5 built them lazily inside the first batched evaluation — a
+// multi-gigabyte allocation after the contexts existed, and a partial failure mixed kernel generations: ADVICE r5).  The QKV segments are the ones
+// enqueue_prefill_batch forms (equal-typed neighbours of the fused wq | wk | wv stream merge into one matrix).  All or nothing.
+static void build_prefill_aux(bamd_model * m, hipStream_t s) {
+    if (!g_prefill_aux) { m->aux_why = "switched off (BAMD_PREFILL_AUX=0)"; return; }
+    if (!bamd_prefill_mfma_supported()) { m->aux_why = "the device refuses the matrix-core kernels' LDS size"; return; }
+    struct Item { const void * w; int type, nrows, K; void ** slot; };
+    std::vector<Item> items;
     for (DevLayer & ly : m->layers) {
         struct Seg { const void * w; int type, nrows; } seg[3]; int n = 1;
         seg[0] = { ly.wq.stream, ly.wq.type, ly.wq.nrows_pad };
         if (ly.wk.type == ly.wq.type) seg[0].nrows += ly.wk.nrows_pad; else seg[n++] = { ly.wk.stream, ly.wk.type, ly.wk.nrows_pad };
         if (ly.wv.type == ly.wk.type) seg[n - 1].nrows += ly.wv.nrows_pad; else seg[n++] = { ly.wv.stream, ly.wv.type, ly.wv.nrows_pad };
-        for (int i = 0; i < n; ++i) ly.aux_qkv[i] = make(seg[i].w, seg[i].type, seg[i].nrows, m->E);
-        ly.aux_o = make(ly.wo.stream, ly.wo.type, ly.wo.nrows_pad, m->E);
-        ly.aux_g = make(ly.wg.stream, ly.wg.type, ly.wg.nrows_pad, m->E);
-        ly.aux_u = make(ly.wu.stream, ly.wu.type, ly.wu.nrows_pad, m->E);
-        ly.aux_d = make(ly.wd.stream, ly.wd.type, ly.wd.nrows_pad, m->F);
+        for (int i = 0; i < n; ++i) items.push_back({ seg[i].w, seg[i].type, seg[i].nrows, m->E, &ly.aux_qkv[i] });
+        items.push_back({ ly.wo.stream, ly.wo.type, ly.wo.nrows_pad, m->E, &ly.aux_o });
+        items.push_back({ ly.wg.stream, ly.wg.type, ly.wg.nrows_pad, m->E, &ly.aux_g });
+        items.push_back({ ly.wu.stream, ly.wu.type, ly.wu.nrows_pad, m->E, &ly.aux_u });
+        items.push_back({ ly.wd.stream, ly.wd.type, ly.wd.nrows_pad, m->F, &ly.aux_d });
     }
+    size_t need = 0;
+    for (const Item & it : items) { const size_t b = bamd_prefill_aux_bytes(it.type, it.nrows, it.K); if (!b) { m->aux_why = "a matrix type / shape without a matrix-core kernel"; return; } need += b + 4096; }
+    if (items.empty()) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); m->aux_why = "hipMemGetInfo failed"; return; }
+    double reserve_gb = 8.0; if (const char * e = getenv("BAMD_PREFILL_AUX_RESERVE_GB")) reserve_gb = atof(e);
+    const size_t reserve = (size_t) (reserve_gb * 1073741824.0);
+    if (need + reserve > free_b) {
+        char b[256]; snprintf(b, sizeof b, "side tables need %.2f GiB, %.2f GiB free, %.1f GiB must stay free (BAMD_PREFILL_AUX_RESERVE_GB)", need / 1073741824.0, free_b / 1073741824.0, reserve_gb);
+        m->aux_why = b; return;
+    }
+    std::vector<void *> got;
+    for (const Item & it : items) {
+        void * p = nullptr;
+        if (hipMalloc(&p, bamd_prefill_aux_bytes(it.type, it.nrows, it.K)) != hipSuccess) {
+            (void) hipGetLastError();
+            for (void * q : got) hipFree(q);
+            for (const Item & jt : items) *jt.slot = nullptr;
+            m->aux_why = "allocation failed"; m->aux_bytes = 0; return;
+        }
+        got.push_back(p); *it.slot = p; m->aux_bytes += (int64_t) bamd_prefill_aux_bytes(it.type, it.nrows, it.K);
+        bamd_launch_prefill_aux(it.w, it.type, it.nrows, it.K, p, s);
+    }
+    for (void * q : got) m->allocs.push_back(q);
     hipStreamSynchronize(s);
+    m->aux_ok = true;
 }
 static int ensure_batch_buffers(bamd_context * c) {
-    ensure_prefill_aux(c->m, c->stream);
     if (c->bcap) return 0;
     bamd_model * m = c->m;
     const size_t T = BAMD_PREFILL_CAP, Ekv = (size_t) m->Hkv * m->hd;
@@ -762,31 +784,30 @@ static int ensure_batch_buffers(bamd_context * c) {
     c->bcap = (int) T;
     return 0;
 }
-// one batched mat-mul: K-quant segments on the matrix-core kernels (round-5 kernel where the segment has a side table), the rest on the integer-dot kernel
-// (identical bits either way).  aux[i]: side table of segment i (null: none)
-static int mm_mfma(const bamd_mv_seg & sg, const void * aux, int nv, int K, const void * blob16, int T, float * out, const float * res, int epi, int ldo, hipStream_t s) {
-    if (aux && g_prefill_v == 2) return bamd_launch_matmul_mfma2(sg.w, aux, sg.type, nv, sg.nrows, K, blob16, T, out, res, epi, ldo, s);
-    return bamd_launch_matmul_mfma(sg.w, sg.type, nv, sg.nrows, K, blob16, T, out, res, epi, ldo, s);
-}
+// one batched mat-mul: K-quant segments with a side table on the matrix-core kernels, the rest on the integer-dot kernel (identical bits either way).
+// aux[i]: side table of segment i (null: none)
 static int batch_mm(bamd_context * c, bamd_mm_args a, int epi, int T, hipStream_t s, const void * const * aux) {
     bamd_model * m = c->m;
-    const bool mfma_ok = g_prefill_mfma;
+    auto on_mfma = [&](int i) { return g_prefill_mfma && aux[i] && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q5_K || a.seg[i].type == BAMD_Q6_K); };
+    auto mm_mfma = [&](const bamd_mv_seg & sg, const void * ax, int nv, float * out, const float * res, int e) {
+        return bamd_launch_matmul_mfma2(sg.w, ax, sg.type, nv, sg.nrows, a.K, c->bblob16, T, out, res, e, a.ldo, s);
+    };
     if (epi == BAMD_EPI_SILU_MUL) {
-        if (mfma_ok && (a.seg[0].type == BAMD_Q4_K || a.seg[0].type == BAMD_Q5_K || a.seg[0].type == BAMD_Q6_K) && a.seg[1].type == a.seg[0].type) {
+        if (on_mfma(0) && on_mfma(1) && a.seg[1].type == a.seg[0].type) {
             const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
-            if (mm_mfma(a.seg[0], aux[0], nv, a.K, c->bblob16, T, a.seg[0].out, nullptr, BAMD_EPI_STORE, a.ldo, s)) return 1;   // gate -> h
+            if (mm_mfma(a.seg[0], aux[0], nv, a.seg[0].out, nullptr, BAMD_EPI_STORE)) return 1;   // gate -> h
             // up, with h = silu(gate) * up as its epilogue (every element is read and rewritten by the one lane that owns it)
-            if (mm_mfma(a.seg[1], aux[1], nv, a.K, c->bblob16, T, a.seg[0].out, a.seg[0].out, BAMD_EPI_SILU_MUL, a.ldo, s)) return 1;
+            if (mm_mfma(a.seg[1], aux[1], nv, a.seg[0].out, a.seg[0].out, BAMD_EPI_SILU_MUL)) return 1;
             return 0;
         }
         return bamd_launch_matmul_batch(a, epi, m->n_cu, s);
     }
     bamd_mm_args rest = a; rest.nseg = 0;
     for (int i = 0; i < a.nseg; ++i) {
-        if (mfma_ok && (a.seg[i].type == BAMD_Q4_K || a.seg[i].type == BAMD_Q5_K || a.seg[i].type == BAMD_Q6_K)) {
+        if (on_mfma(i)) {
             const int nv = a.seg[i].nvalid > 0 ? a.seg[i].nvalid : a.seg[i].nrows;
             const float * res = epi == BAMD_EPI_ADD ? a.res + (a.seg[i].out - a.seg[0].out) : nullptr;
-            if (mm_mfma(a.seg[i], aux[i], nv, a.K, c->bblob16, T, a.seg[i].out, res, res ? BAMD_EPI_ADD : BAMD_EPI_STORE, a.ldo, s)) return 1;
+            if (mm_mfma(a.seg[i], aux[i], nv, a.seg[i].out, res, res ? BAMD_EPI_ADD : BAMD_EPI_STORE)) return 1;
         } else rest.seg[rest.nseg++] = a.seg[i];
     }
     if (rest.nseg) {
@@ -1409,7 +1430,7 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_vec(int ty
                                    const float * residual, float * y, int mode) {
     return op_matvec(type, w_raw, nullptr, nrows, k, x, norm_w, eps, residual, y, residual ? BAMD_EPI_ADD : BAMD_EPI_STORE, mode);
 }
-// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 1 = round-2 MFMA kernel, 2 = round-5 MFMA kernel (3: its eight-wave Q4_K / Q5_K layout)
+// batched mat-mul of T activation rows against one matrix through the prefill kernels: impl 0 = integer-dot kernel, 2 = matrix-core kernel (1 and 3 were the generations removed in round 6)
 extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int type, const void * w_raw, int nrows, int k, const float * x, int T, const float * norm_w,
                                                                               float eps, const float * residual, float * y, int impl) {
     if (need_device()) return 1;
@@ -1424,16 +1445,11 @@ extern "C" __attribute__((visibility("default"))) int bamd_op_mul_mat_batch(int 
     HIPC(hipMemset(str, 0, wbp));
     bamd_launch_repack(raw, str, type, nrows, k, nullptr);
     bamd_launch_quantize_batch(dx, dw, eps, k, T, blob, blob16, nullptr);
-    if (impl == 2 || impl == 3) {                                   // round-5 kernels (3: the eight-wave Q4_K / Q5_K layout): side table built here, as the engine builds it at the first batched evaluation
-        bamd_launch_prefill_waves(impl == 3 ? 8 : 16);
+    if (impl == 2) {                                                // the matrix-core kernel: side table built here, as the engine builds it at model load
         void * aux = t.up(nullptr, bamd_prefill_aux_bytes(type, nrows_pad, k));
         if (!aux) return fail("device alloc failed");
         bamd_launch_prefill_aux(str, type, nrows_pad, k, aux, nullptr);
-        const int rc2 = bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr);
-        bamd_launch_prefill_waves(16);
-        if (rc2) return fail("MFMA path: unsupported type/shape");
-    } else if (impl == 1) {
-        if (bamd_launch_matmul_mfma(str, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
+        if (bamd_launch_matmul_mfma2(str, aux, type, nrows, nrows_pad, k, blob16, T, dy, dres, dres ? BAMD_EPI_ADD : BAMD_EPI_STORE, nrows, nullptr)) return fail("MFMA path: unsupported type/shape");
     } else {
         bamd_mm_args a; memset(&a, 0, sizeof a);
         a.seg[0].w = str; a.seg[0].out = dy; a.seg[0].type = type; a.seg[0].nrows = nrows_pad; a.seg[0].nvalid = nrows; a.nseg = 1;

@@ -90,17 +90,14 @@ size_t bamd_blob_bytes(int K);
 size_t bamd_blob16_bytes(int K);
 // blob: int8 activations for matmul_batch_kernel (may be null); blob16: f16 copy for the MFMA kernel (may be null)
 void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, int K, int T, void * blob, void * blob16, hipStream_t s);
-// K-quant matrices on the matrix cores (exact): y[t][row] = W[row,:] . Q8_K(a_t); epi BAMD_EPI_STORE: out = y; BAMD_EPI_ADD: out = y + res;
-// BAMD_EPI_SILU_MUL: out = silu(res) * y (res = the gate projection, may alias out).  1 = type / shape not supported
-int  bamd_launch_matmul_mfma(const void * w_stream, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res, int epi,
-                             int ldo, hipStream_t s);
-// round 5 (bamd_prefill2.hip): the same mat-mul with the A fragments built once per 64-row x 64-token workgroup; aux = the matrix's load-time side
-// table (bamd_prefill_aux_bytes bytes, filled by bamd_launch_prefill_aux from the wave-stream copy).  1 = type / shape not supported or no table
+// K-quant matrices on the matrix cores, exact (bamd_prefill2.hip): y[t][row] = W[row,:] . Q8_K(a_t); epi BAMD_EPI_STORE: out = y; BAMD_EPI_ADD: out = y + res;
+// BAMD_EPI_SILU_MUL: out = silu(res) * y (res = the gate projection, may alias out).  The A fragments are built once per 64-row x 64-token workgroup from the
+// wave-stream copy and the matrix's load-time side table (aux: bamd_prefill_aux_bytes bytes, filled by bamd_launch_prefill_aux).  1 = type / shape not supported or no table
+int  bamd_prefill_mfma_supported(void);      // the current device accepts the kernels' LDS size (asked at model load)
 size_t bamd_prefill_aux_bytes(int type, int nrows_pad, int K);
 void bamd_launch_prefill_aux(const void * w_stream, int type, int nrows_pad, int K, void * aux, hipStream_t s);
 int  bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res,
                               int epi, int ldo, hipStream_t s);
-void bamd_launch_prefill_waves(int waves);        // Q4_K / Q5_K workgroup layout of bamd_launch_matmul_mfma2: 16 (default) or 8 waves
 int  bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s);      // 1 = shape not supported
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s);
 int  bamd_launch_attention_batch(const bamd_attn_args & a, int gq, int T, hipStream_t s);     // 1 = shape not supported

@@ -1,7 +1,7 @@
 // bamd_prefill2.hip — round 5: the exact matrix-core prefill mat-mul with the A fragments BUILT ONCE PER WORKGROUP (Q4_K / Q5_K / Q6_K x Q8_K).
 //
 // Reference: ggml_compute_forward_mul_mat with ne11 = T (ggml.c:12277-12492) over ggml_vec_dot_q{4,5,6}_K_q8_K (ggml-quants.c:6832 / :7400 / :8037);
-// arithmetic contract and operand layouts as in bamd_prefill.hip (whose kernels stay as the second implementation, BAMD_PREFILL_V=1): ONE
+// the second implementation it is tested against is the integer-dot kernel of bamd_prefill.hip (matmul_batch_kernel): ONE
 // v_mfma_f32_16x16x32_f16 per SIMD lane e of the reference gives the exact integer sums isum_e of a 16-row x 16-token tile, the f32 chains
 // acc_e = fma(d_x d_y, isum_e, acc_e), the min terms and the final hsum tree follow on the VALU in the reference's order.
 //
@@ -16,9 +16,9 @@
 //     super-block for Q4_K / Q5_K, 72 B for Q6_K: the MI355X has the HBM for it): the builders' per-(row, sub-block pair) scale operands
 //     {s, -1024 s, s'/16, -64 s'} as packed f16 pairs, and the consumers' d, dmin as f32 plus the min-term MFMA operands {2 m_a, 2 m_b, m_a, m_b}, which
 //     travel global -> LDS by DMA with the activation records;
-//   * three layouts: sixteen waves with one 16 x 16 tile each (matmul_mfma3_q4k_kernel, the default for Q4_K / Q5_K), eight waves with 16 x 32 each
-//     (matmul_mfma2_q4k_kernel, BAMD_PREFILL_WAVES=8; matmul_mfma2_q6k_kernel for Q6_K).
-// Same bits as bamd_prefill.hip, a third fewer vector instructions per MFMA — and the same time: DESIGN 4c has the measurements of what bounds it.
+//   * two layouts: sixteen waves with one 16 x 16 tile each (matmul_mfma3_q4k_kernel: Q4_K / Q5_K), eight waves with 16 x 32 each (matmul_mfma2_q6k_kernel: Q6_K).
+// Same bits as the round-2 kernels (removed in round 6), a third fewer vector instructions per MFMA — and the same time: DESIGN 4c has the measurements of what
+// bounds it, profiles/r06_prefill_ceiling.txt the timing-only ceiling builds (-DBAMD_PREFILL_CEILING).
 #include "bamd_device.h"
 #include "bamd_mfma_common.h"
 #include <type_traits>
@@ -135,186 +135,9 @@ struct XStage {
     }
 };
 
-// ---- Q4_K / Q5_K ----------------------------------------------------------------------------------------------------------------------
-// MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) = (sub-block 2g + (i >> 2), u = i & 3); C/D rows 4g + i, token m.
-template <int EPI, bool Q5>
-__global__ void __launch_bounds__(512) matmul_mfma2_q4k_kernel(bamd_mma2_args a) {
-    constexpr uint32_t RECB = Q5 ? BAMD_RECB_Q5K : BAMD_RECB_Q4K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), m = lane & 15, g = lane >> 4;
-    const int rt = wave >> 1, tp = wave & 1;
-    const int nb = a.K >> 8;
-    const int rb = blockIdx.y, t0 = blockIdx.x * 64;
-    const int rtg = rb * 4 + rt;                                    // row tile: rows rtg*16 .. +15 = record groups 2 rtg, 2 rtg + 1
-    const bool live = rtg * 16 < a.nrows_pad;
-    const size_t b16 = BAMD_BLOB16_BYTES(nb);
-    const uint32_t lds0 = (uint32_t) (size_t) (bamd_lds_vp) smem;
-    XStage<160> stg; stg.plan(tid, wave, lane, t0, a.T, b16, nb);
-    const uint8_t * chb = a.ch + (size_t) rb * nb * X3_CHS;
-#define X_STAGE(ci_, b_) stg.issue(a.blob16 + (size_t) (ci_) * BAMD_B16_REC, chb + (size_t) (ci_) * X3_CHS, a.blob16 + (size_t) (ci_) * 4, lds0 + X_BLK0 + (uint32_t) (b_) * X_BLK, wave, lane)
-    // builder, in the wave-stream's own lane order: wave (rt, q = tp) takes record group q of the row tile — lane (r = lane >> 3, e = lane & 7) loads the
-    // 16 bytes of (row 8q + r, chunk e) with ONE coalesced 1-KiB request per wave and super-block; its dword g holds sub-blocks 2g / 2g+1 = the eight
-    // halves of MFMA lane (m = 8q + r, g) of fragment e.  Four 16-byte stores per lane and super-block, scale operands of (row, g) from the side table.
-    const int br = lane >> 3, be = lane & 7;
-    const int rgq = 2 * (live ? rtg : rb * 4) + tp;
-    const int rgc = rgq * 8 < a.nrows_pad ? rgq : rgq - 1;          // a last tile of 8 (padded) rows: its first record group twice (rows 8..15 are never stored)
-    const uint8_t * wrec = a.w + (size_t) rgc * nb * RECB + (size_t) lane * 16;
-    const uint8_t * wqh = a.w + (size_t) rgc * nb * RECB + 1024 + (size_t) lane * 4;
-    const uint8_t * phb = a.ph + (size_t) rb * nb * 4096 + (size_t) rt * 1024 + (size_t) (8 * tp + br) * 16;
-    uint4 raw[2]; uint32_t qh[2]; uint4 sc[2][4];
-    auto load_set = [&](int ci, auto set_tag) {
-        constexpr int S = decltype(set_tag)::value;
-        raw[S] = *(const uint4 *) (wrec + (size_t) ci * RECB);
-        if (Q5) qh[S] = *(const uint32_t *) (wqh + (size_t) ci * RECB);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sc[S][g] = *(const uint4 *) (phb + (size_t) ci * 4096 + g * 256);
-    };
-    // one fragment piece = two halves of work: (1) nibbles -> f16 images 1024 + n, (2) x scale, store
-    bamd_h2u c0, c1, c2, c3;
-    auto build_a = [&](uint32_t wq, uint32_t q, int g) {
-        uint32_t lo = wq & 0x0f0f0f0fu, hi = Q5 ? (wq >> 4) & 0x0f0f0f0fu : wq & 0xf0f0f0f0u;      // Q4_K: the high nibbles stay in place (16 n; the scale operand is s / 16)
-        if (Q5) { lo |= ((q >> (2 * g)) & 0x01010101u) << 4; hi |= ((q >> (2 * g + 1)) & 0x01010101u) << 4; }  // bit c of byte u of the row's high-bit dword e: element 4e+u of sub-block c
-        c0.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04010400u); c1.u = __builtin_amdgcn_perm(0x64646464u, lo, 0x04030402u);
-        c2.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04010400u); c3.u = __builtin_amdgcn_perm(0x64646464u, hi, 0x04030402u);
-    };
-    auto build_b = [&](const uint4 & s, unsigned char * dst) {
-        bamd_h2u s0, n0, s1, n1, a0, a1, a2, a3; s0.u = s.x; n0.u = s.y; s1.u = s.z; n1.u = s.w;
-        a0.h = __builtin_elementwise_fma(c0.h, s0.h, n0.h); a1.h = __builtin_elementwise_fma(c1.h, s0.h, n0.h);     // (1024 + n) s - 1024 s = n s, one rounding, exact
-        a2.h = __builtin_elementwise_fma(c2.h, s1.h, n1.h); a3.h = __builtin_elementwise_fma(c3.h, s1.h, n1.h);
-        *(uint4 *) dst = (uint4) { a0.u, a1.u, a2.u, a3.u };
-    };
-    auto rawg = [&](const uint4 & v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; };
-    // per-lane LDS addresses (first copy of each region)
-    unsigned char * afw = smem + X_AF0 + (rt * 8 + be) * X_FR + (8 * tp + br) * 16;                // where this lane writes: fragment be, MFMA lane (8 tp + br, g) at + g * 256
-    const unsigned char * afr = smem + X_AF0 + rt * 8 * X_FR + lane * 16;                          // where the wave reads the tile's eight fragments
-    const unsigned char * bop = smem + X_BLK0 + (size_t) ((2 * tp) * 16 + m) * BAMD_B16_REC + g * 16;      // B operands of token tile 0 (tile 1: + 16 records)
-    const unsigned char * bmn = smem + X_BLK0 + (size_t) ((2 * tp) * 16 + m) * BAMD_B16_REC + 512 + (Q5 ? g * 8 : 0);
-    const unsigned char * chd = smem + X_BLK0 + X_CH_OFF + rt * X_CH4_RT + g * 16;                 // d of rows 4g .. 4g+3; their dmin 64 bytes on
-    const unsigned char * cmn = Q5 ? smem + X_BLK0 + X_CH_OFF + rt * X_CH4_RT + 128 + m * 32 + g * 8
-                                   : (g == 0 ? smem + X_BLK0 + X_CH_OFF + rt * X_CH4_RT + 128 + m * 32 : smem + X_BLK0 + X_Z_OFF);
-    const unsigned char * ydp = smem + X_BLK0 + X_YD_OFF + ((2 * tp) * 16 + m) * 4;
-    bamd_f4 acc[2][8], accm[2][4];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[n][e] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int l = 0; l < 4; ++l) accm[n][l] = (bamd_f4) { 0.f, 0.f, 0.f, 0.f };
-    }
-    // prologue: stage 0 in flight, fragments of super-block 0 built, operands of super-block 1 requested
-    if (tid < 16) *(uint32_t *) (smem + X_BLK0 + X_Z_OFF + (tid >> 3) * X_BLK + (tid & 7) * 4) = 0u;
-    X_STAGE(0, 0);
-    load_set(0, std::integral_constant<int, 0>());
-    load_set(nb > 1 ? 1 : 0, std::integral_constant<int, 1>());
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { build_a(rawg(raw[0], g), Q5 ? qh[0] : 0u, g); build_b(sc[0][g], afw + g * 256); }
-    lds_dma_wait();
-    __syncthreads();
-    auto step = [&](const int ci, auto cur_tag) {
-        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
-        // the next stage (records, headers, d_y of ci + 1) and the builder operands of ci + 2; at the end: the last super-block again
-        X_STAGE(ci + 1 < nb ? ci + 1 : nb - 1, NXT);
-        load_set(ci + 2 < nb ? ci + 2 : nb - 1, std::integral_constant<int, CUR>());
-        __builtin_amdgcn_sched_barrier(0);
-        float D[2][4], Dm[2][4];
-        {
-            const bamd_f4 h0 = *(const bamd_f4 *) (chd + CUR * X_BLK), h1 = *(const bamd_f4 *) (chd + CUR * X_BLK + 64);
-            const float dw[4] = { h0[0], h0[1], h0[2], h0[3] }, dmw[4] = { h1[0], h1[1], h1[2], h1[3] };
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float ydv = *(const float *) (ydp + CUR * X_BLK + n * 64);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { D[n][i] = ydv * dw[i]; Dm[n][i] = (-ydv) * dmw[i]; }
-            }
-        }
-        {
-            // software pipeline over e: the LDS operands of e + 2 are requested at the top of iteration e, the MFMA results of e - 1 are folded
-            // into the chains in iteration e, and half a fragment of the NEXT super-block is built in every iteration
-            bamd_h8 Aq[3], Bq[3][2]; bamd_f4 sprev[2];
-#define X_LDA(e_) (*(const bamd_h8 *) (afr + CUR * X_AF_BYTES + (e_) * X_FR))
-#define X_LDB(e_, n_) (*(const bamd_h8 *) (bop + CUR * X_BLK + (n_) * (16 * BAMD_B16_REC) + (e_) * 64))
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { Aq[e] = X_LDA(e); Bq[e][0] = X_LDB(e, 0); Bq[e][1] = X_LDB(e, 1); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e + 2 < 8) { Aq[(e + 2) % 3] = X_LDA(e + 2); Bq[(e + 2) % 3][0] = X_LDB(e + 2, 0); Bq[(e + 2) % 3][1] = X_LDB(e + 2, 1); }
-                if ((e & 1) == 0) build_a(rawg(raw[NXT], e >> 1), Q5 ? qh[NXT] : 0u, e >> 1);
-                bamd_f4 si[2];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
-                    si[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[e % 3], Bq[e % 3][n], z, 0, 0, 0);
-                    if (e > 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[n][e - 1][i] = fmaf(D[n][i], sprev[n][i], acc[n][e - 1][i]);
-                    }
-                }
-                if (e & 1) build_b(sc[NXT][e >> 1], afw + NXT * X_AF_BYTES + (e >> 1) * 256);
-                sprev[0] = si[0]; sprev[1] = si[1];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[n][7][i] = fmaf(D[n][i], sprev[n][i], acc[n][7][i]);
-            }
-#undef X_LDA
-#undef X_LDB
-        }
-        // min terms (ggml-quants.c:6937-6941 / :7515-7518): exact integer products on the matrix core, operands precomputed
-        if (Q5) {
-            union { uint2 u; bamd_h4 h; } av; av.u = *(const uint2 *) (cmn + CUR * X_BLK);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                union { uint2 u; bamd_h4 h; } bv; bv.u = *(const uint2 *) (bmn + CUR * X_BLK + n * (16 * BAMD_B16_REC));
-                const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
-                const bamd_f4 pm = __builtin_amdgcn_mfma_f32_16x16x16f16(av.h, bv.h, z, 0, 0, 0);              // sum_j m_j S_j of rows 4g + i, token m
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const float t = Dm[n][i] * pm[i]; accm[n][0][i] = accm[n][0][i] + t; }
-            }
-        } else {
-            const uint4 ma = *(const uint4 *) (cmn + CUR * X_BLK), mb = *(const uint4 *) (cmn + CUR * X_BLK + 16);
-            const uint2 al[4] = { { ma.x, ma.y }, { ma.z, ma.w }, { mb.x, mb.y }, { mb.z, mb.w } };
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const uint4 sfa = *(const uint4 *) (bmn + CUR * X_BLK + n * (16 * BAMD_B16_REC)), sfb = *(const uint4 *) (bmn + CUR * X_BLK + n * (16 * BAMD_B16_REC) + 16);
-                const uint2 bl[4] = { { sfa.x, sfa.y }, { sfa.z, sfa.w }, { sfb.x, sfb.y }, { sfb.z, sfb.w } };
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    union { uint2 u; bamd_h4 h; } av4, bv4; av4.u = al[l]; bv4.u = bl[l];
-                    const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
-                    const bamd_f4 pm = __builtin_amdgcn_mfma_f32_16x16x16f16(av4.h, bv4.h, z, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) accm[n][l][i] = fmaf(Dm[n][i], pm[i], accm[n][l][i]);
-                }
-            }
-        }
-        lds_dma_wait();
-        __syncthreads();                                     // stage and fragments of ci + 1 visible; those of ci free
-    };
-    for (int ci = 0; ci < nb; ci += 2) {
-        step(ci, std::integral_constant<int, 0>());
-        if (ci + 1 < nb) step(ci + 1, std::integral_constant<int, 1>());
-    }
-#undef X_STAGE
-    if (!live) return;
-    // hsum_float_8 over e and the acc_m folds, in the reference's order (finish_row), then the epilogue
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int t = t0 + (2 * tp + n) * 16 + m;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = ((acc[n][0][i] + acc[n][4][i]) + (acc[n][2][i] + acc[n][6][i])) + ((acc[n][1][i] + acc[n][5][i]) + (acc[n][3][i] + acc[n][7][i]));
-            const float mm = Q5 ? accm[n][0][i] : (accm[n][0][i] + accm[n][2][i]) + (accm[n][1][i] + accm[n][3][i]);
-            const float val = v + mm;
-            const int row = rtg * 16 + 4 * g + i;
-            if (t < a.T && row < a.nrows) {
-                const size_t o = (size_t) t * a.ldo + row;
-                a.out[o] = EPI == BAMD_EPI_ADD ? val + a.res[o] : EPI == BAMD_EPI_SILU_MUL ? v_silu(a.res[o]) * val : val;   // SILU_MUL: res = the gate projection
-            }
-        }
-    }
-}
+// ---- Q4_K / Q5_K: the sixteen-wave kernel further down (matmul_mfma3_q4k_kernel).  MFMA lane l = (m = l & 15, g = l >> 4): A row m, B token m, k-slots (g, i) =
+//      (sub-block 2g + (i >> 2), u = i & 3); C/D rows 4g + i, token m.  (An eight-wave layout of the same arithmetic — 16 x 32 per wave, 96 accumulators, two waves
+//      per SIMD — lived here in round 5: 27.4 vs 25.4 ms per 512-token micro-batch; removed in round 6, profiles/r06_prefill_ceiling.txt.)
 
 // ---- Q6_K: a step is HALF a super-block (four e: 16 MFMAs per wave, two per e and token tile) -----------------------------------------------
 // scale x (q - 32) reaches 4096: the scale is split sc = sa + sl (prefill_aux_q6k_kernel), both fragments come from one f16 image v = (1024 + q) - 1056
@@ -486,6 +309,9 @@ __device__ __forceinline__ void x3_dma(const void * sbase, uint32_t voff, uint32
 #ifndef X_TIMING
 #define X_TIMING 0
 #endif
+#ifndef BAMD_PREFILL_CEILING
+#define BAMD_PREFILL_CEILING 0
+#endif
 #if X_TIMING
 #define X_T(i_) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i_] += now_ - tlast; tlast = now_; } while (0)
 #else
@@ -594,6 +420,11 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
             // super-block are built beside e = 4..7
             // the chain FMAs of e follow the MFMA of e + 2 (one iteration behind, the compiler pads every MFMA -> VALU read with s_nop 1..6: ten issue slots per step)
             bamd_h8 Aq[3], Bq[3]; bamd_f4 sp[2];
+#if BAMD_PREFILL_CEILING
+            bamd_f4 csum = { 0.f, 0.f, 0.f, 0.f }, csum2 = { 0.f, 0.f, 0.f, 0.f };
+            const unsigned char * afr2 = smem + X_AF0 + (rt ^ 1) * 8 * X_FR + lane * 16;
+            (void) afr2; (void) csum2;
+#endif
 #define X_LDA(e_) (*(const bamd_h8 *) (afr + CUR * X_AF_BYTES + (e_) * X_FR))
 #define X_LDB(e_) (*(const bamd_h8 *) (bop + CUR * X3_BLK + (e_) * 64))
             Aq[0] = X_LDA(0); Bq[0] = X_LDB(0); Aq[1] = X_LDA(1); Bq[1] = X_LDB(1);
@@ -602,22 +433,40 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
                 if (e + 2 < 8) { Aq[(e + 2) % 3] = X_LDA(e + 2); Bq[(e + 2) % 3] = X_LDB(e + 2); }
                 if (e >= 4 && (e & 1) == 0) build_a(e == 4 ? raw[NXT].x : raw[NXT].y, Q5 ? qh[NXT] : 0u, (e >> 1) & 1);
                 const bamd_f4 z = { 0.f, 0.f, 0.f, 0.f };
+#if BAMD_PREFILL_CEILING
+                // TIMING-ONLY ceiling builds (tools/prefill_ceiling.sh; never shipped, results are garbage): what the exact arithmetic's EIGHT separate per-lane sums per
+                // super-block cost.  1: the eight MFMAs of a step accumulate into ONE accumulator (K = 256) and ONE chain FMA per super-block and tile follows — same
+                // operand traffic, same staging, same fragment build.  2: the same, and every B operand read serves the MFMAs of TWO row tiles (this wave's and its
+                // neighbour's A fragments: 1.5 KB of LDS reads per MFMA instead of 2; the launcher halves the row blocks so that the MFMA count stays what it was)
+                csum = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[e % 3], Bq[e % 3], e == 0 ? z : csum, 0, 0, 0);
+                if (BAMD_PREFILL_CEILING == 2) csum2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const bamd_h8 *) (afr2 + CUR * X_AF_BYTES + e * X_FR), Bq[e % 3], e == 0 ? z : csum2, 0, 0, 0);
+                const bamd_f4 si = z;
+#else
                 const bamd_f4 si = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[e % 3], Bq[e % 3], z, 0, 0, 0);
+#endif
                 if (e == 0) x3_dma(p01, so0, CUR ? d0_odd : d0_even);
                 if (e == 1) x3_dma(p01, so1, (CUR ? d0_odd : d0_even) + 16384u);
                 if (e == 2) { x3_dma(p2, so2, CUR ? d2_odd : d2_even); so0 += BAMD_B16_REC; so1 += BAMD_B16_REC; so2 += st2; }
                 if (e == 3) load_set(ci + 2, std::integral_constant<int, CUR>());
+#if !BAMD_PREFILL_CEILING
                 if (e > 1) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[e - 2][i] = fmaf(D[i], sp[e & 1][i], acc[e - 2][i]);
                 }
+#endif
                 if (e >= 4 && (e & 1)) build_b(*(const uint4 *) (phl + NXT * X3_BLK + ((e >> 1) & 1) * 256), afw + NXT * X_AF_BYTES + ((e >> 1) & 1) * 256);
                 sp[e & 1] = si;
                 __builtin_amdgcn_sched_barrier(0);
                 if (e == 3) X_T(1);
             }
+#if BAMD_PREFILL_CEILING
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[0][i] = fmaf(D[i], csum[i], acc[0][i]); if (BAMD_PREFILL_CEILING == 2) acc[1][i] = fmaf(D[i], csum2[i], acc[1][i]); }
+            (void) sp;
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[6][i] = fmaf(D[i], sp[0][i], acc[6][i]); acc[7][i] = fmaf(D[i], sp[1][i], acc[7][i]); }
+#endif
 #undef X_LDA
 #undef X_LDB
         }
@@ -695,9 +544,6 @@ __global__ void __launch_bounds__(1024) matmul_mfma3_q4k_kernel(bamd_mma2_args a
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------------------
 static inline int x_row_blocks(int nrows_pad) { return (nrows_pad + 63) / 64; }
-// Q4_K / Q5_K: the sixteen-wave kernel (default) or the eight-wave one (BAMD_PREFILL_WAVES=8, bamd_launch_prefill_waves: the tests run both)
-static int g_prefill_waves16 = [] { const char * e = getenv("BAMD_PREFILL_WAVES"); return (e && e[0] == '8') ? 0 : 1; }();
-void bamd_launch_prefill_waves(int waves) { g_prefill_waves16 = waves == 8 ? 0 : 1; }
 static unsigned long long * g_prefill_dbg = nullptr;      // -DX_TIMING builds: where the kernels of the next launches leave their phase clocks (bamd_prefill_dbg)
 extern "C" __attribute__((visibility("default"))) void bamd_prefill_dbg(void * dev_buf) { g_prefill_dbg = (unsigned long long *) dev_buf; }
 // bytes of the side table of a K-quant matrix [nrows_pad][K]: builder part first, the consumer part behind it (both 16-byte aligned)
@@ -716,6 +562,16 @@ void bamd_launch_prefill_aux(const void * w_stream, int type, int nrows_pad, int
     else if (type == BAMD_Q5_K) hipLaunchKernelGGL((prefill_aux_q4k_kernel<true>), grid, dim3(64), 0, s, (const uint8_t *) w_stream, nrows_pad, nb, ph, ch);
     else                        hipLaunchKernelGGL((prefill_aux_q4k_kernel<false>), grid, dim3(64), 0, s, (const uint8_t *) w_stream, nrows_pad, nb, ph, ch);
 }
+// 1 when the current device takes the matrix-core kernels' launches (158 784 B of dynamic LDS at 1024 threads): asked once per model load, before any side table is
+// built (a rejected launch would otherwise leave stale output behind a success code)
+int bamd_prefill_mfma_supported(void) {
+    int dev = 0, lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    if ((size_t) lds < (size_t) X3_LDS_BYTES || (size_t) lds < (size_t) X_LDS_BYTES) return 0;
+    if (hipFuncSetAttribute((const void *) matmul_mfma3_q4k_kernel<BAMD_EPI_STORE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) X3_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *) matmul_mfma2_q6k_kernel<BAMD_EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) X_LDS_BYTES) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return 1;
+}
 int bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, int nrows, int nrows_pad, int K, const void * blob16, int T, float * out, const float * res,
                              int epi, int ldo, hipStream_t s) {
     if ((type != BAMD_Q4_K && type != BAMD_Q5_K && type != BAMD_Q6_K) || (nrows_pad & 7) || (K & 255) || !aux) return 1;
@@ -729,14 +585,14 @@ int bamd_launch_matmul_mfma2(const void * w_stream, const void * aux, int type, 
         if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(512), X_LDS_BYTES, s, a); \
         else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(512), X_LDS_BYTES, s, a); \
         else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(512), X_LDS_BYTES, s, a); } while (0)
-    const int waves16 = g_prefill_waves16;
+    const dim3 grid3(grid.x, BAMD_PREFILL_CEILING == 2 ? (grid.y + 1) / 2 : grid.y);     // (ceiling build 2: every workgroup issues the MFMAs of two; timing only)
 #define X3_LAUNCH(KERNEL, ...) do { \
-        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid, dim3(1024), X3_LDS_BYTES, s, a); \
-        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid, dim3(1024), X3_LDS_BYTES, s, a); \
-        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid, dim3(1024), X3_LDS_BYTES, s, a); } while (0)
+        if (epi == BAMD_EPI_ADD)           hipLaunchKernelGGL((KERNEL<BAMD_EPI_ADD __VA_ARGS__>),      grid3, dim3(1024), X3_LDS_BYTES, s, a); \
+        else if (epi == BAMD_EPI_SILU_MUL) hipLaunchKernelGGL((KERNEL<BAMD_EPI_SILU_MUL __VA_ARGS__>), grid3, dim3(1024), X3_LDS_BYTES, s, a); \
+        else                               hipLaunchKernelGGL((KERNEL<BAMD_EPI_STORE __VA_ARGS__>),    grid3, dim3(1024), X3_LDS_BYTES, s, a); } while (0)
     if (type == BAMD_Q6_K)      X_LAUNCH(matmul_mfma2_q6k_kernel);
-    else if (type == BAMD_Q5_K) { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , true); else X_LAUNCH(matmul_mfma2_q4k_kernel, , true); }
-    else                        { if (waves16) X3_LAUNCH(matmul_mfma3_q4k_kernel, , false); else X_LAUNCH(matmul_mfma2_q4k_kernel, , false); }
+    else if (type == BAMD_Q5_K) X3_LAUNCH(matmul_mfma3_q4k_kernel, , true);
+    else                        X3_LAUNCH(matmul_mfma3_q4k_kernel, , false);
 #undef X3_LAUNCH
 #undef X_LAUNCH
     return 0;

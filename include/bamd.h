@@ -174,8 +174,8 @@ int bamd_bridge_stage_layout(void * ctx, int32_t * out, int cap_stages);
 /* Prompt evaluation mode, process-wide: 1 (default, also env BAMD_PREFILL_BATCH) = bamd_decode with 2..512 tokens runs the batched
  * prefill kernels (every layer once per micro-batch, like llama_decode with n_tokens > 1); 0 = token by token through the decode
  * kernels.  Bit-identical results.  Contexts with n_ctx > 8192 use the token-by-token path regardless (round 1). */
-void bamd_set_prefill_batch(int on);   /* 2 = batched, but Q4_K mat-muls on the integer-dot kernel instead of the MFMA kernel */
-void bamd_set_prefill_version(int v);  /* 2 (default): round-5 matrix-core prefill kernels with load-time side tables; 1: the round-2 kernels.  Same bits */
+void bamd_set_prefill_batch(int on);   /* 2 = batched, but the mat-muls on the integer-dot kernel instead of the matrix-core kernels (the path of a model whose
+                                        * side tables did not fit: they are built at model load, all matrices or none, BAMD_PREFILL_AUX_RESERVE_GB of the device left free) */
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 /* One eager single-token step at position `pos` with a HIP-event pair around every kernel launch.

@@ -188,20 +188,19 @@ def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
 
 
 @pytest.mark.parametrize("t,K,rows,T,impl", [(12, 1024, 64, 5, 0), (14, 2048, 40, 19, 0), (13, 1024, 24, 9, 0),
-                                               (12, 1024, 64, 16, 1), (12, 2048, 40, 21, 1), (12, 4096, 528, 37, 1), (12, 14336, 32, 16, 1),
-                                               (14, 1024, 64, 16, 1), (14, 2048, 40, 21, 1), (14, 4096, 528, 37, 1), (14, 14336, 32, 33, 1),
-                                               (12, 768, 40, 21, 1), (14, 2816, 24, 17, 1), (12, 11008, 32, 16, 1), (14, 256, 16, 3, 1),
-                                               (13, 1024, 64, 16, 1), (13, 2048, 40, 21, 1), (13, 4096, 528, 37, 1), (13, 8192, 48, 33, 1), (13, 768, 24, 9, 1),
-                                               # impl 2: the round-5 kernel (64-row x 64-token workgroups, fragments built once per workgroup, load-time side tables)
+                                               (12, 1024, 64, 16, 0), (12, 2048, 40, 21, 0), (12, 4096, 528, 37, 0), (12, 14336, 32, 16, 0),
+                                               (14, 1024, 64, 16, 0), (14, 2048, 40, 21, 0), (14, 4096, 528, 37, 0), (14, 14336, 32, 33, 0),
+                                               (12, 768, 40, 21, 0), (14, 2816, 24, 17, 0), (12, 11008, 32, 16, 0), (14, 256, 16, 3, 0),
+                                               (13, 1024, 64, 16, 0), (13, 2048, 40, 21, 0), (13, 4096, 528, 37, 0), (13, 8192, 48, 33, 0), (13, 768, 24, 9, 0),
+                                               # impl 2: the matrix-core kernels (64-row x 64-token workgroups, fragments built once per workgroup, load-time side tables)
                                                (12, 1024, 64, 16, 2), (12, 2048, 40, 21, 2), (12, 4096, 528, 37, 2), (12, 14336, 32, 16, 2), (12, 768, 40, 70, 2),
                                                (12, 11008, 32, 16, 2), (12, 256, 8, 1, 2), (12, 4096, 200, 129, 2),
                                                (13, 1024, 64, 16, 2), (13, 2048, 40, 21, 2), (13, 4096, 528, 37, 2), (13, 8192, 48, 33, 2), (13, 768, 24, 65, 2),
                                                (14, 1024, 64, 16, 2), (14, 2048, 40, 21, 2), (14, 4096, 528, 37, 2), (14, 14336, 32, 33, 2), (14, 2816, 24, 17, 2),
                                                (14, 256, 16, 3, 2), (14, 4096, 200, 129, 2),
-                                               # impl 3: the round-5 kernel's eight-wave Q4_K / Q5_K layout
-                                               (12, 1024, 64, 16, 3), (12, 4096, 528, 37, 3), (12, 11008, 32, 16, 3), (12, 4096, 200, 129, 3), (13, 2048, 40, 21, 3), (13, 768, 24, 65, 3)])
+                                               ])
 def test_mul_mat_batch(bamd, po, t, K, rows, T, impl):
-    """batched prefill mat-mul (impl 0: integer-dot kernel, 1: round-2 MFMA kernel, 2: round-5 MFMA kernel, 3: its eight-wave layout) == the reference's mul_mat per activation row, bit for bit;
+    """batched prefill mat-mul (impl 0: integer-dot kernel, 2: matrix-core kernel) == the reference's mul_mat per activation row, bit for bit;
     ragged token tiles, rows % 16 != 0, residual epilogue, K with an odd number of super-blocks (Llama-2's 11008)"""
     rng = np.random.default_rng(77 * t + K + T)
     W = random_kquant_tensor(t, K, rows, rng)
