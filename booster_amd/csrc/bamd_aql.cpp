@@ -233,6 +233,13 @@ int bamd_aql_run(bamd_aql_graph * g, int replays, double * seconds, const char *
             p->completion_signal.handle = last ? d.done.handle : 0;
             const uint16_t h = header(first ? HSA_FENCE_SCOPE_SYSTEM : sc, last ? HSA_FENCE_SCOPE_SYSTEM : sc);
             __atomic_store_n((uint32_t *) p, (uint32_t) h | ((uint32_t) setup << 16), __ATOMIC_RELEASE);
+            // one doorbell never covers packets on both sides of the ring's wrap: under rocprofv3 the queue is the tool's intercept queue, whose handler is
+            // given the run of new packets as ONE pointer + count and reads past the end of the ring (SIGSEGV in librocprofiler-sdk at the 1 MiB boundary,
+            // reproduced with tools/aql_under_profiler.py); the hardware queue does not care, and it is one more doorbell per 16384 packets
+            if (((d.widx + i) & mask) == mask && i + 1 < P) {
+                hsa_queue_store_write_index_screlease(q, d.widx + i + 1);
+                hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t) (d.widx + i));
+            }
         }
         d.widx += P;
         hsa_queue_store_write_index_screlease(q, d.widx);
