@@ -319,6 +319,8 @@ void bamd_launch_matvec(const bamd_mv_args & a, int pro, int epi, int n_cu, hipS
     if (grid > nrg) grid = nrg;
     if (grid < 1) grid = 1;
     const bool generic = g_mv_generic || a.mode >= 16;       // mode bit 4: force the generic kernels (tests)
+    // K = 28672 (the 70B ffn_down): a fast split-K instance only (bamd_matvec_fast_b.hip); the generic split kernel has no table entry for 14 records per wave
+    if (!generic && fmode != 1 && nrg < 8 * cus && bamd_launch_fast_b112_supported(a.K, pro, epi, a.nseg, a.seg[0].type) && bamd_launch_fast_b(a, pro, epi, grid, s)) return;
     if (!generic && mixed && fmode == 0 && can_split && bamd_launch_fast_mixed(a, pro, epi, grid, s)) return;
     if (split) {
         if (!generic && bamd_launch_fast_b(a, pro, epi, grid, s)) return;

@@ -30,6 +30,10 @@ __device__ __forceinline__ ProArgs carve_lds(const bamd_mv_args & a, unsigned ch
 }
 
 
+// device-internal epilogues of stream_segment (matvec_gateup14_kernel): HALF a gate/up pair per wave — the gate row's value goes to the partner wave
+// through LDS (`res` = the slot of 8 floats, `out` reinterpreted: see the kernel), the up row's wave waits for it and stores silu(gate) * up
+#define BAMD_EPI_HALF_GATE 16
+#define BAMD_EPI_HALF_UP 17
 // ---- MODE A: one wave per row-group --------------------------------------------------------------------------
 // The wave walks row-groups rg = first, first+stride, ... (count of them).  A register ring of D records is kept
 // in flight by a LOADER cursor that runs D records ahead of the consumer and crosses row-group boundaries by
@@ -41,7 +45,7 @@ template <int TYPE, typename REC, int D, int EPI, int PRO, bool SMALLK = false, 
 __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb,
                                                int first, int count, int stride, float * __restrict__ out,
                                                const float * __restrict__ res, const ProArgs & pa, ActPro<PRO == BAMD_PRO_NORM> & ap,
-                                               bool issue_here, bool do_pro, unsigned long long & best, int nvalid) {
+                                               bool issue_here, bool do_pro, unsigned long long & best, int nvalid, float * half_slot = nullptr, int * half_flag = nullptr) {
     constexpr int RECB = TYPE == BAMD_Q4_K ? BAMD_RECB_Q4K : TYPE == BAMD_Q5_K ? BAMD_RECB_Q5K : 1680;     // bamd_record_bytes
     constexpr bool PAIR = EPI == BAMD_EPI_SILU_MUL;
     constexpr int NPARTS = PAIR ? 2 : 1;
@@ -121,6 +125,15 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             if (PAIR) {
                 if (part == 0) gate_val = val;
                 else if ((lane & 7) == 0 && row < nvalid) ik_st(out + row, v_silu(gate_val) * val);
+            } else if (EPI == BAMD_EPI_HALF_GATE) {              // the gate row of a pair whose up row another wave streams: hand the value over through LDS
+                if ((lane & 7) == 0) half_slot[lane >> 3] = val;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(half_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (EPI == BAMD_EPI_HALF_UP) {
+                while (__hip_atomic_load(half_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const float g = half_slot[lane >> 3];
+                if ((lane & 7) == 0 && row < nvalid) ik_st(out + row, v_silu(g) * val);
             } else if ((lane & 7) == 0 && row < nvalid) {
                 float o = val;
                 if (EPI == BAMD_EPI_ADD) o = val + resv;
@@ -223,8 +236,11 @@ __device__ __forceinline__ void stream_pair_short(const uint8_t * __restrict__ w
 // PRE: called once between the first ring requests and the activation prologue (default: nothing).  The co-launched attention || wo kernel waits
 // there for its activations (granules of the attention role, bamd_colaunch.hip) and fills ap.v itself: the weights of the first batch are in
 // flight while it waits.
+// COMPACT (K = 28672, the 70B ffn_down: 112 super-blocks): a parked record takes 576 bytes — {fs, pm} per lane, {d, dmin} once per row — instead of a float4 per
+// lane, so that TWO term buffers of a whole row-group fit the LDS beside the activations (2 x 63 KB + 32 KB) and the chain of row-group n overlaps the
+// streaming of row-group n + 1 (with one buffer every batch ends in barrier + 112-step chain + barrier: measured slower than one wave per row-group, round 5)
 struct SplitNoPre { __device__ __forceinline__ void operator()() const { } };
-template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false, bool UNEVEN = false, typename PRE = SplitNoPre>
+template <int TYPE, typename REC, int NBW, int M, int NBUF, int EPI, int PRO, bool SMALLK = false, bool ONEB = false, bool UNEVEN = false, typename PRE = SplitNoPre, bool COMPACT = false>
 __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int nb, int first, int count, int stride,
                                              float * __restrict__ out, const float * __restrict__ res, const ProArgs & pa,
                                              ActPro<PRO == BAMD_PRO_NORM> & ap, ActPro<PRO == BAMD_PRO_NORM> & ap2, bool issue_here, bool do_pro,
@@ -238,7 +254,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     const int rg_step = stride * rgb;
     const int n_w = UNEVEN ? (NBW - 1) + (wave < (nb & 7) ? 1 : 0) : NBW;                  // this wave's records per row-group
     const int i0 = UNEVEN ? wave * (NBW - 1) + (wave < (nb & 7) ? wave : (nb & 7)) : wave * NBW;   // its first super-block inside a row
-    const size_t rg_floats = BAMD_TERM_FLOATS(nb);
+    const size_t rg_floats = COMPACT ? (size_t) nb * 144 : BAMD_TERM_FLOATS(nb);
     // PLAIN prologue: wave w consumes only the activations of its own K-slice (blocks i0 .. i0+NBW-1), so it quantises exactly
     // those — no workgroup barrier, and a wave starts on its records as soon as ITS blocks are done.  (NORM needs the sum of
     // squares of the whole vector: shared prologue as in mode A.)
@@ -302,7 +318,8 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             if (m < nbatch) {
-                float4 * P = (float4 *) (B0 + (size_t) m * rg_floats);
+                float * Pf = B0 + (size_t) m * rg_floats;
+                float4 * P = (float4 *) Pf;
 #pragma unroll
                 for (int j = 0; j < NBW; ++j) {
                     const int s = m * NBW + j;
@@ -310,9 +327,26 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                     pin_rec(ring[s]);
                     if (!UNEVEN || j < n_w) {
                         const Terms T = block_terms(ring[s], ci, lane, q8, S, yd);
-                        P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
+                        if (COMPACT) {
+                            float * rec = Pf + (size_t) ci * 144;
+                            *(float2 *) (rec + lane * 2) = make_float2(T.fs, T.pm);
+                            if ((lane & 7) == 0) *(float2 *) (rec + 128 + r8 * 2) = make_float2(T.d, T.dmin);
+                        } else P[ci * 64 + lane] = make_float4(T.d, T.fs, T.dmin, T.pm);   // every lane owns the terms of its chain: one 16-byte store
                     }
-                    if (!ONEB && r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + (UNEVEN && j >= n_w ? n_w - 1 : j) * RECB, lane);
+#ifndef BAMD_SPLIT_UNCOND_REFILL
+#define BAMD_SPLIT_UNCOND_REFILL 1
+#endif
+                    if (!ONEB) {
+                        const int jj = UNEVEN && j >= n_w ? n_w - 1 : j;
+                        if (BAMD_SPLIT_UNCOND_REFILL && SMALLK) {
+                            // fast kernels: the refill is UNCONDITIONAL — behind the last batch it re-requests the first record of the row-group just consumed
+                            // (one record of redundant L2 traffic per wave, never used).  A branch around the request made the compiler merge the wait counts of
+                            // both paths at every join: the waits of a batch ran down from vmcnt(13) to vmcnt(0), i.e. the last record of every batch waited for
+                            // the six refills issued just before it (a drained ring per batch); now every record waits for exactly its own two loads
+                            const bool more = r0 + M + m < count;
+                            load_rec(ring[s], rs, bbase + (more ? (M + m) * rg_step + jj * RECB : m * rg_step), lane);
+                        } else if (r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + jj * RECB, lane);
+                    }
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1 || s == D - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -328,26 +362,36 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
         if (r0 == 0) TL_STAMP(pa.tl, 4);
         if (wave < nbatch) {
             // the reference's chains, in order, for lane (r, e)   (ggml-quants.c:6937-6941, :6970, :7518, :8219)
-            const float4 * P = (const float4 *) (B0 + (size_t) wave * rg_floats);
+            const float * Pc = B0 + (size_t) wave * rg_floats;
+            const float4 * P = (const float4 *) Pc;
+            auto term = [&](int ib) -> float4 {              // {d, fs, dmin, pm} of super-block ib for this lane
+                if (COMPACT) {
+                    const float * rec = Pc + (size_t) ib * 144;
+                    const float2 fp = *(const float2 *) (rec + lane * 2), dd = *(const float2 *) (rec + 128 + r8 * 2);
+                    return make_float4(dd.x, fp.x, dd.y, fp.y);
+                }
+                return P[ib * 64 + lane];
+            };
             RowAcc A = { 0.f, 0.f };
             int i = 0;
-            if (nb >= 8) {                                   // the 16-byte LDS reads of 8 blocks issued together, the next 8 in flight behind them
-                float4 t[8], tn[8];
+            constexpr int CB = COMPACT ? 4 : 8;              // chain steps per LDS read group (COMPACT runs at 128 VGPRs beside a ring of seven records: 2 x 4 terms in flight)
+            if (nb >= CB) {                                  // the LDS reads of CB blocks issued together, the next CB in flight behind them
+                float4 t[CB], tn[CB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = P[u * 64 + lane];
-                for (; i + 16 <= nb; i += 8) {
+                for (int u = 0; u < CB; ++u) t[u] = term(u);
+                for (; i + 2 * CB <= nb; i += CB) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) tn[u] = P[(i + 8 + u) * 64 + lane];
+                    for (int u = 0; u < CB; ++u) tn[u] = term(i + CB + u);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+                    for (int u = 0; u < CB; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = tn[u];
+                    for (int u = 0; u < CB; ++u) t[u] = tn[u];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
-                i += 8;
+                for (int u = 0; u < CB; ++u) chain_step<TYPE>(A, t[u].x, t[u].y, t[u].z, t[u].w);
+                i += CB;
             }
-            if (UNEVEN) for (; i < nb; ++i) { const float4 t = P[i * 64 + lane]; chain_step<TYPE>(A, t.x, t.y, t.z, t.w); }
+            if (UNEVEN) for (; i < nb; ++i) { const float4 t = term(i); chain_step<TYPE>(A, t.x, t.y, t.z, t.w); }
             const float val = finish_row<TYPE>(A);
             if ((lane & 7) == 0 && crow < nvalid) ik_st(out + crow, EPI == BAMD_EPI_ADD ? val + resv : val);
             if (r0 == 0) TL_STAMP(pa.tl, 5);
@@ -363,3 +407,4 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
 bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);
 bool bamd_launch_fast_b(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s);
 bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, hipStream_t s);
+bool bamd_launch_fast_b112_supported(int K, int pro, int epi, int nseg, int type);

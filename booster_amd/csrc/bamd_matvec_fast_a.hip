@@ -91,6 +91,40 @@ __global__ void __launch_bounds__(512) matvec_gateup7_kernel(BAMD_LEAD_PARAMS, b
 }
 static const bool g_gateup7 = [] { const char * e = getenv("BAMD_GATEUP7"); return !(e && e[0] == '0'); }();
 
+// gate/up launch with FOURTEEN row-group pairs per workgroup (n_ff = 112 x grid, K = 8192: Llama-3-70B on 256 CUs).  One pair or two per wave (the generic
+// dealing: waves 0-5 two, waves 6-7 one) put four pairs on SIMDs 0 and 1 and three on SIMDs 2 and 3, and the launch ended with waves 4 and 5 alone
+// (timeline, round 6: waves 0-3 exit at 37.5 us, waves 6-7 at 30, waves 4-5 at 47).  Here every SIMD streams SEVEN rows: waves 0-3 two pairs each
+// (pairs w, w + 4), waves 4-7 one pair (8 + w - 4) and then HALF of a pair — waves 4 / 6 the gate row of pairs 12 / 13, waves 5 / 7 the up row, the gate
+// value crossing to the up row's wave through LDS for silu(gate) * up.  Whole rows only: every chain is one wave's sequential chain, as everywhere.
+template <int TYPE, int NBP>
+__global__ void __launch_bounds__(512) matvec_gateup14_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
+    BAMD_LEAD_TAKE(a);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TL_STAMP(a.tl, 0);
+    const int nb = a.K >> 8;
+    const ProArgs pa = carve_lds(a, smem);
+    ActPro<true> ap;
+    BAMD_PRO_ISSUE_NB(ap, pa, NBP);
+    const int wave = wave_id(), grid = (int) gridDim.x, b = (int) blockIdx.x;
+    float * slots = (float *) (smem + BAMD_ACT_RED_OFF(nb) + 16 * sizeof(double) + 16 * sizeof(unsigned long long));     // [2 half pairs][8 rows]
+    int * flags = (int *) (slots + 16);
+    if (threadIdx.x < 2) flags[threadIdx.x] = 0;             // ordered before their first use by the prologue's workgroup barriers
+    typedef typename RecOf<TYPE>::type REC;
+    const uint8_t * wG = (const uint8_t *) a.seg[0].w, * wU = (const uint8_t *) a.seg[1].w;
+    const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
+    unsigned long long best = 0ull;
+    if (wave < 4) stream_segment<TYPE, REC, 8, BAMD_EPI_SILU_MUL, BAMD_PRO_NORM, true, NBP>(wG, wU, nb, b + grid * wave, 2, grid * 4, a.seg[0].out, a.res, pa, ap, false, true, best, nv);
+    else {
+        stream_segment<TYPE, REC, 8, BAMD_EPI_SILU_MUL, BAMD_PRO_NORM, true, NBP>(wG, wU, nb, b + grid * (4 + wave), 1, grid, a.seg[0].out, a.res, pa, ap, false, true, best, nv);
+        const int h = (wave - 4) >> 1;                       // half pair 0 (pair 12): waves 4, 5; half pair 1 (pair 13): waves 6, 7
+        const int rg = b + grid * (12 + h);
+        if (((wave - 4) & 1) == 0) stream_segment<TYPE, REC, 8, BAMD_EPI_HALF_GATE, BAMD_PRO_NORM, true, NBP>(wG, wG, nb, rg, 1, grid, a.seg[0].out, a.res, pa, ap, false, false, best, nv, slots + 8 * h, flags + h);
+        else                       stream_segment<TYPE, REC, 8, BAMD_EPI_HALF_UP, BAMD_PRO_NORM, true, NBP>(wU, wU, nb, rg, 1, grid, a.seg[0].out, a.res, pa, ap, false, false, best, nv, slots + 8 * h, flags + h);
+    }
+    TL_STAMP(a.tl, 7);
+}
+static const bool g_gateup14 = [] { const char * e = getenv("BAMD_GATEUP14"); return !(e && e[0] == '0'); }();
+
 // mode B (split-K), one segment of one type, NBW = K / 2048 records per wave and row-group, M row-groups per batch
 
 // ---- host-side dispatch of the fast kernels; false = no instance for this shape (the caller takes the generic kernel) ----
@@ -128,6 +162,12 @@ bool bamd_launch_fast_a(bamd_mv_args a, int pro, int epi, int grid, hipStream_t 
 #define BAMD_G7(T_) if (t0 == T_) { BAMD_LAUNCH((matvec_gateup7_kernel<T_, 2>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
         BAMD_G7(BAMD_Q4_K) BAMD_G7(BAMD_Q5_K) BAMD_G7(BAMD_Q6_K)
 #undef BAMD_G7
+    }
+    if (g_gateup14 && pro == BAMD_PRO_NORM && epi == BAMD_EPI_SILU_MUL && nb == 32 && nrg0 == 14 * grid && (a.mode & 15) == 0) {
+        const size_t lds = act_lds_bytes(a.K) + 16 * 4 + 2 * 4 + 8;
+#define BAMD_G14(T_) if (t0 == T_) { BAMD_LAUNCH((matvec_gateup14_kernel<T_, 4>), dim3(grid), dim3(512), lds, s, BAMD_LEAD_ARGS(a), a); return true; }
+        BAMD_G14(BAMD_Q4_K) BAMD_G14(BAMD_Q5_K) BAMD_G14(BAMD_Q6_K)
+#undef BAMD_G14
     }
     if (pro == BAMD_PRO_NORM) {
         if (epi == BAMD_EPI_STORE)    return launch_fast_a_types<BAMD_PRO_NORM, BAMD_EPI_STORE>(a, t0, t1, grid, s);

@@ -4,7 +4,8 @@
 
 // NW: waves per workgroup (8; 14 for K = 14336 = 14 x 4 super-blocks: the ffn_down launch is not paced by its bytes but by what ONE wave walks
 // between entry and its last store — Q8_K of its blocks, the terms of its records, the chain — at one vector instruction per ~10 clocks)
-template <int TYPE, int NBW, int M, int PRO, int EPI, bool ONEB, int NW = 8>
+// COMPACT (NW = 16, NBW = 7: K = 28672 = 16 x 7 super-blocks, the 70B ffn_down): two compact term buffers (bamd_matvec_core.h)
+template <int TYPE, int NBW, int M, int PRO, int EPI, bool ONEB, int NW = 8, bool COMPACT = false>
 __global__ void __launch_bounds__(64 * NW) matvec_split_fast_kernel(BAMD_LEAD_PARAMS, bamd_mv_args a) {
     BAMD_LEAD_TAKE(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -22,9 +23,9 @@ __global__ void __launch_bounds__(64 * NW) matvec_split_fast_kernel(BAMD_LEAD_PA
     const int count = a.cnt_q + ((int) blockIdx.x < a.cnt_r ? 1 : 0);
     const int nv = a.seg[0].nvalid > 0 ? a.seg[0].nvalid : a.seg[0].nrows;
     typedef typename RecOf<TYPE>::type REC;
-    constexpr int NBUF = NBW * M > 8 ? 1 : 2;                // term buffers: 2 x M x K/256 KiB must fit the LDS
-    split_stream<TYPE, REC, NBW, M, NBUF, EPI, PRO, true, ONEB>((const uint8_t *) a.seg[0].w, nb, (int) blockIdx.x, count, (int) gridDim.x, a.seg[0].out, a.res, pa,
-                                                       ap, ap2, false, true, part0, rgctr, nv);      // the launcher's grid gives every workgroup >= 1 row-group
+    constexpr int NBUF = COMPACT ? 2 : NBW * M > 8 ? 1 : 2;  // term buffers: 2 x M x K/256 KiB must fit the LDS
+    split_stream<TYPE, REC, NBW, M, NBUF, EPI, PRO, true, ONEB, false, SplitNoPre, COMPACT>((const uint8_t *) a.seg[0].w, nb, (int) blockIdx.x, count, (int) gridDim.x, a.seg[0].out, a.res, pa,
+                                                       ap, ap2, false, true, part0, rgctr, nv, SplitNoPre());      // the launcher's grid gives every workgroup >= 1 row-group
     TL_STAMP(a.tl, 7);
 }
 
@@ -189,18 +190,33 @@ bool bamd_launch_fast_mixed(const bamd_mv_args & a, int pro, int epi, int grid, 
     return false;
 }
 
-template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false, int NW = 8>
+template <int PRO, int EPI, int T, int NBW, int M, bool ONEB = false, int NW = 8, bool COMPACT = false>
 static void launch_fast_b_inst(const bamd_mv_args & a, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
-    const size_t lds = act_lds_bytes(a.K) + 16 + (size_t) (NBW * M > 8 ? 1 : 2) * M * nb * 256 * 4;
-    BAMD_LAUNCH((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB, NW>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
+    const size_t lds = act_lds_bytes(a.K) + 16 + (COMPACT ? (size_t) 2 * M * nb * 576 : (size_t) (NBW * M > 8 ? 1 : 2) * M * nb * 256 * 4);
+    BAMD_LAUNCH((matvec_split_fast_kernel<T, NBW, M, PRO, EPI, ONEB, NW, COMPACT>), dim3(grid), dim3(64 * NW), lds, s, BAMD_LEAD_ARGS(a), a);
 }
 static const bool g_down14 = [] { const char * e = getenv("BAMD_DOWN14"); return !(e && e[0] == '0'); }();
+static const bool g_down112 = [] { const char * e = getenv("BAMD_DOWN112"); return !(e && e[0] == '0'); }();
+// K = 28672 (112 super-blocks: the Llama-3-70B ffn_down) as split-K over SIXTEEN waves x seven records, one row-group per batch, two COMPACT term buffers.
+// With one wave per row-group (mode A) this launch is bound by its prologue — every workgroup quantises all 112 blocks behind shared barriers: 22 us of the
+// 30 (tools/mvbench.py 70b, `prologue-only K28672`) — and only four waves per CU have a row-group; here a wave quantises the seven blocks of its own K-slice.
+bool bamd_launch_fast_b112_supported(int K, int pro, int epi, int nseg, int type) {
+    return g_down112 && (K >> 8) == 112 && pro == BAMD_PRO_PLAIN && (epi == BAMD_EPI_STORE || epi == BAMD_EPI_ADD) && nseg == 1 &&
+           (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K);
+}
 template <int PRO, int EPI>
 static bool launch_fast_b_types(const bamd_mv_args & a, int t, int nbw, int grid, hipStream_t s) {
     // row-groups per batch: the largest M of the kernel family that every workgroup can fill (cnt_q = the smallest count)
     // (K = 14336 with both row-groups of a workgroup in flight — M = 2, 14 records per wave — measured no faster, again: the wave that
     // issues 130 KB of requests up front sits in the issue stage until most of them have landed, and its prologue starts that much later)
+    if constexpr (PRO == BAMD_PRO_PLAIN) if ((a.K >> 8) == 112) {                               // bamd_launch_fast_b112_supported
+        if (a.cnt_q < 1) return false;
+#define BAMD_B112(T_) if (t == T_) { launch_fast_b_inst<PRO, EPI, T_, 7, 1, false, 16, true>(a, grid, s); return true; }
+        BAMD_B112(BAMD_Q4_K) BAMD_B112(BAMD_Q5_K) BAMD_B112(BAMD_Q6_K)
+#undef BAMD_B112
+        return false;
+    }
     if (g_down14 && PRO == BAMD_PRO_PLAIN && (a.K >> 8) == 56 && a.cnt_q >= 1) {                // K = 14336 on fourteen waves, four records each (one row-group per batch: 128 VGPRs)
 #define BAMD_B14(T_) if (t == T_) { launch_fast_b_inst<PRO, EPI, T_, 4, 1, false, 14>(a, grid, s); return true; }
         BAMD_B14(BAMD_Q4_K) BAMD_B14(BAMD_Q5_K) BAMD_B14(BAMD_Q6_K)

@@ -48,8 +48,9 @@ def test_rmsnorm_quantize(bamd, po, K):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (768, 13), (2048, 4104), (4096, 512), (4096, 510), (8192, 24), (14336, 64), (14336, 2064)])
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("K,rows", [(256, 8), (768, 40), (768, 13), (2048, 4104), (4096, 512), (4096, 510), (8192, 24), (14336, 64), (14336, 2064),
+                                    (28672, 8192), (28672, 2056), (28672, 8200), (28672, 24)])   # K = 28672: the 70B ffn_down (sixteen-wave split-K with compact term buffers; mode 0 = the launcher's own choice)
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_mul_mat_vec(bamd, po, t, K, rows, mode):
     """mode 1: one wave per row-group; mode 2: split-K over the 8 waves of a workgroup (where the shape allows;
     the launcher falls back to mode 1 otherwise).  Both must give the reference's bits."""
@@ -90,7 +91,7 @@ def test_mul_mat_vec_norm_residual(bamd, po, t):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024), (4096, 14336)])   # 14336 rows on 256 CUs: seven row-group pairs per workgroup (matvec_gateup7_kernel)
+@pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024), (4096, 14336), (8192, 28672)])   # 14336 rows on 256 CUs: seven row-group pairs per workgroup (matvec_gateup7_kernel); 28672 rows at K = 8192: fourteen (matvec_gateup14_kernel: half pairs cross waves through LDS)
 def test_ffn_gate_up(bamd, po, t, K, rows):
     rng = np.random.default_rng(5 * t + K)
     Wg = random_kquant_tensor(t, K, rows, rng, amp=4.0)
