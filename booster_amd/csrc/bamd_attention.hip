@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(1024) attn_spv_kernel(bamd_attn_args a, int gq
                 float4 v = *pp;
                 v.x *= fs; v.y *= fs; v.z *= fs; v.w *= fs;
                 *pp = v;
-                if (blockIdx.y == 0) *(float4 *) (pr + B * 64 + foff) = v;      // the probability rows, once per head (bamd_op_attention hands them to the tests)
+                if (blockIdx.y == 0 && a.probs) *(float4 *) (pr + B * 64 + foff) = v;      // the probability rows, once per head, when asked for (bamd_op_attention hands them to the tests; a decode step passes null)
             }
         }
     }

@@ -65,8 +65,8 @@ struct Pod {
 // moved — when the text outgrows it, a buffer of twice the capacity takes over and the old one stays behind (retired memory <= the
 // final text).  Appending inside a buffer keeps every reader's view NUL-terminated: the new terminator is written first, then the
 // piece from its last byte to its first, which overwrites the old terminator last.  That ordering is what an UNLOCKED reader (Go's
-// C.GoString on the pointer status() returned) relies on: it holds on x86-64, whose stores become visible in program order (the only host the
-// MI355X platform ships with; the reference hands out std::string::c_str() of a string it keeps appending to, with no ordering at all).
+// C.GoString on the pointer status() returned) relies on; the writer enforces it with release stores (append), not with the host's store order
+// (the reference hands out std::string::c_str() of a string it keeps appending to, with no ordering at all).
 // Growth: a job keeps <= 2x its text; the table itself is bounded — beyond BAMD_MAX_JOBS entries the oldest FINISHED jobs are dropped, 1/4 of the
 // table at a time (their status() pointers die with them: a server that polls a job it started tens of thousands of jobs ago gets "").
 #define BAMD_MAX_JOBS 65536
@@ -86,10 +86,12 @@ struct Job {
     void append(const std::string & piece) {
         if (piece.empty()) return;
         if (!cur_buf || len + piece.size() + 1 > cap) grow(len + piece.size() + 1);
-        volatile char * b = cur_buf;
-        b[len + piece.size()] = 0;
-        for (size_t i = piece.size(); i-- > 0; ) b[len + i] = piece[i];
-        std::atomic_thread_fence(std::memory_order_release);
+        // every byte is a RELEASE store (round 6: rounds 3-5 used volatile stores and relied on x86-64's store order): each one is ordered behind the new
+        // terminator and the bytes after it on any host, so a reader that sees byte i also sees a terminator somewhere behind it.  (The reader is
+        // C.GoString on a bare char *: its side of the contract cannot be made atomic from here; the reference does not order anything.)
+        char * b = cur_buf;
+        __atomic_store_n(&b[len + piece.size()], (char) 0, __ATOMIC_RELEASE);
+        for (size_t i = piece.size(); i-- > 0; ) __atomic_store_n(&b[len + i], piece[i], __ATOMIC_RELEASE);
         len += piece.size();
     }
 };

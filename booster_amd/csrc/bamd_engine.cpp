@@ -487,6 +487,10 @@ static int enqueue_layers(bamd_context * c, int prefill_mode, hipStream_t s, Ste
         // 2. RoPE, KV store, softmax(QK^T) V                               (llama.cpp:8837-8849, :8318-8353)
         bamd_attn_args t; memset(&t, 0, sizeof t);
         t.st = c->st; t.q = c->q; t.k = c->k; t.v = c->v; t.kc = c->kc[il]; t.vc = c->vc[il]; t.rope = c->rope; t.rope_cur = c->rope_cur; t.scores = c->scores; t.probs = c->probs; t.out = c->att;
+        t.n_ctx = c->n_ctx_pad; t.hd = m->hd; t.Hkv = m->Hkv;
+        // the probability rows in global memory are the data path of the softmax | P.V PAIR only (score rows beyond the LDS); the one-launch softmax + P.V keeps them in
+        // LDS and wrote them out for the tests' sake — 2 x 31 KB of stores by sixteen of its workgroups, the ones the launch then ended with
+        if (bamd_attention_split_is_ik_clean(t, m->H / m->Hkv)) t.probs = nullptr;
         t.hd = m->hd; t.Hkv = m->Hkv; t.n_ctx = c->n_ctx_pad; t.kq_scale = 1.0f / sqrtf((float) m->hd); t.prefill_mode = prefill_mode;
         // single-launch kernel below 448 positions, three kernels (scores | softmax | P.V) above (attn_fused_for)
         t.lds_ld = std::min(512, c->n_ctx_pad);               // single-launch kernel only (sequences < 448 positions): constant, so captured graphs stay valid as pos advances

@@ -224,11 +224,15 @@ static bool launch_fast_b_types(const bamd_mv_args & a, int t, int nbw, int grid
     }
     const int mmax = nbw == 1 ? 8 : nbw == 2 ? 4 : nbw == 4 ? 2 : 1;
     int m = 1; while (m * 2 <= mmax && m * 2 <= a.cnt_q) m *= 2;
+    // K = 8192 with exactly FOUR row-groups per workgroup behind a plain prologue and a residual add (the 70B wo): all four in one batch — sixteen records per wave
+    // requested at entry, one barrier, four chains side by side, one 128-KB term buffer — instead of two batches of two
+    static const bool wo4 = [] { const char * e = getenv("BAMD_WO4"); return !(e && e[0] == '0'); }();
+    if (wo4 && PRO == BAMD_PRO_PLAIN && EPI == BAMD_EPI_ADD && nbw == 4 && a.cnt_q == 4 && a.cnt_r == 0) m = 4;
     // exactly M row-groups in every workgroup: the single-batch instances (residual-add launches: wo, ffn_down)
     const bool oneb = a.cnt_r == 0 && a.cnt_q == m;
 #define BAMD_B_ONE(T_, NBW_, M_) if (PRO == BAMD_PRO_PLAIN && EPI == BAMD_EPI_ADD && oneb && t == T_ && nbw == NBW_ && m == M_) { launch_fast_b_inst<PRO, EPI, T_, NBW_, M_, true>(a, grid, s); return true; }
 #define BAMD_B_ONES(NBW_, M_) BAMD_B_ONE(BAMD_Q4_K, NBW_, M_) BAMD_B_ONE(BAMD_Q5_K, NBW_, M_) BAMD_B_ONE(BAMD_Q6_K, NBW_, M_)
-    BAMD_B_ONES(2, 2) BAMD_B_ONES(2, 4) BAMD_B_ONES(4, 2) BAMD_B_ONES(1, 8)
+    BAMD_B_ONES(2, 2) BAMD_B_ONES(2, 4) BAMD_B_ONES(4, 2) BAMD_B_ONES(4, 4) BAMD_B_ONES(1, 8)
 #undef BAMD_B_ONES
 #undef BAMD_B_ONE
 #define BAMD_B_CASE(T_, NBW_, M_) if (t == T_ && nbw == NBW_ && m == M_) { launch_fast_b_inst<PRO, EPI, T_, NBW_, M_>(a, grid, s); return true; }
@@ -241,12 +245,21 @@ static bool launch_fast_b_types(const bamd_mv_args & a, int t, int nbw, int grid
 #undef BAMD_B_CASE
     return false;
 }
+static const bool g_qkv3 = [] { const char * e = getenv("BAMD_QKV3"); return !(e && e[0] == '0'); }();
 bool bamd_launch_fast_b(bamd_mv_args a, int pro, int epi, int grid, hipStream_t s) {
     const int nb = a.K >> 8;
     if ((nb & 7) != 0 || a.nseg != 1) return false;
     const int nrg = a.seg[0].nrows >> 3;
     a.cnt_q = nrg / grid; a.cnt_r = nrg % grid;
     const int t = a.seg[0].type, nbw = nb >> 3;
+    // exactly THREE row-groups per workgroup at K = 4096 behind an RMSNorm prologue (the fused QKV launch of a layer whose wq | wk | wv are of one type, 8B / Mistral
+    // widths): all three in ONE batch — six records per wave requested at entry, one barrier, three chains side by side — on the body of the mixed-type kernel with
+    // both types equal, instead of two batches of two and one row-groups
+    if (g_qkv3 && pro == BAMD_PRO_NORM && epi == BAMD_EPI_STORE && nbw == 2 && a.cnt_q == 3 && a.cnt_r == 0 && (a.mode & 15) == 0) {
+#define BAMD_Q3(T_) if (t == T_) { launch_mixed_inst<T_, T_, 2, 2>(a, grid, s); return true; }
+        BAMD_Q3(BAMD_Q4_K) BAMD_Q3(BAMD_Q5_K) BAMD_Q3(BAMD_Q6_K)
+#undef BAMD_Q3
+    }
     if (pro == BAMD_PRO_NORM) { if (epi == BAMD_EPI_STORE && nb <= 8 * BAMD_ACT_BATCH) return launch_fast_b_types<BAMD_PRO_NORM, BAMD_EPI_STORE>(a, t, nbw, grid, s); return false; }
     if (epi == BAMD_EPI_STORE) return launch_fast_b_types<BAMD_PRO_PLAIN, BAMD_EPI_STORE>(a, t, nbw, grid, s);
     if (epi == BAMD_EPI_ADD)   return launch_fast_b_types<BAMD_PRO_PLAIN, BAMD_EPI_ADD>(a, t, nbw, grid, s);

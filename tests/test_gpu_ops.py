@@ -91,6 +91,36 @@ def test_mul_mat_vec_norm_residual(bamd, po, t):
 
 
 @pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_wo_four_row_groups(bamd, po, t, mode):
+    """plain prologue + residual add, K = 8192, 8192 rows = four row-groups per workgroup on 256 CUs (the 70B wo): mode 0 takes all four in one batch"""
+    K, rows = 8192, 8192
+    rng = np.random.default_rng(57 + t)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    res = rng.standard_normal(rows).astype(np.float32)
+    got = bamd.op_mul_mat_vec(t, W, rows, K, x, residual=res, mode=mode)
+    want = po.mul_mat_q(t, W, rows, K, x, nthreads=8)[0] + res
+    assert_bits(got, want, "wo, four row-groups, mode %d" % mode)
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_fused_qkv_one_type(bamd, po, t, mode):
+    """RMSNorm prologue + store, K = 4096, 6144 rows = three row-groups per workgroup on 256 CUs: the fused QKV launch of a layer whose wq | wk | wv share a type
+    (mode 0: all three row-groups in one batch on the mixed-type kernel's body; modes 1 / 2: one wave per row-group / two batches)"""
+    K, rows = 4096, 6144
+    rng = np.random.default_rng(31 + t)
+    W = random_kquant_tensor(t, K, rows, rng)
+    x = (rng.standard_normal(K) * 2).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    got = bamd.op_mul_mat_vec(t, W, rows, K, x, norm_w=w, eps=1e-5, mode=mode)
+    a = (po.rms_norm(x, 1e-5) * w).astype(np.float32)
+    want = po.mul_mat_q(t, W, rows, K, a, nthreads=8)[0]
+    assert_bits(got, want, "fused qkv, one type, mode %d" % mode)
+
+
+@pytest.mark.parametrize("t", TYPES)
 @pytest.mark.parametrize("K,rows", [(512, 768), (4096, 1024), (4096, 14336), (8192, 28672)])   # 14336 rows on 256 CUs: seven row-group pairs per workgroup (matvec_gateup7_kernel); 28672 rows at K = 8192: fourteen (matvec_gateup14_kernel: half pairs cross waves through LDS)
 def test_ffn_gate_up(bamd, po, t, K, rows):
     rng = np.random.default_rng(5 * t + K)
