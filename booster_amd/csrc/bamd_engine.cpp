@@ -724,8 +724,8 @@ static bool prefill_batch_supported(const bamd_context * c, int pos_hi) {
     const int gq = m->H / m->Hkv;
     if (!(g_prefill_batch && g_attn_fused && (size_t) attn_lds_ld(c, pos_hi) * 8 <= 144 * 1024 && m->hd <= 256 && (m->hd & 63) == 0 && gq >= 1 && gq <= 8)) return false;
     // every mat-mul needs a kernel: the matrix-core kernels take every K-quant at any K when the model has its side tables; the integer-dot kernel
-    // takes any K-quant while 8 tokens of Q8_K activations fit the LDS (K <= 17920)
-    auto ok = [&](int type, int K) { return (g_prefill_mfma && m->aux_ok && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 8 * bamd_blob_bytes(K) <= 160 * 1024; };
+    // takes any K-quant while 4 tokens of Q8_K activations fit the LDS (K <= 35840; tiles of 8 tokens up to K = 17920)
+    auto ok = [&](int type, int K) { return (g_prefill_mfma && m->aux_ok && (type == BAMD_Q4_K || type == BAMD_Q5_K || type == BAMD_Q6_K)) || 4 * bamd_blob_bytes(K) <= 160 * 1024; };
     for (const DevLayer & ly : m->layers)
         if (!ok(ly.wq.type, m->E) || !ok(ly.wk.type, m->E) || !ok(ly.wv.type, m->E) || !ok(ly.wo.type, m->E) || !ok(ly.wg.type, m->E) || !ok(ly.wu.type, m->E) || !ok(ly.wd.type, m->F)) return false;
     return true;

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(512) quantize_batch_kernel(const float * __res
 }
 
 
-template <int TYPE, typename REC, int D, int EPI>
+template <int TYPE, typename REC, int D, int EPI, int TT>
 __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, const uint8_t * __restrict__ wB, int nb, int first, int count, int stride,
                                               float * __restrict__ out, const float * __restrict__ res, int ldo, int t0, int nt,
                                               const unsigned char * acts, size_t bb, int nvalid) {
@@ -77,15 +77,15 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
         const int rg = first + r * stride;
         const int row = rg * 8 + (lane >> 3);
         const int rowoff = rg * rgb;
-        float gate_val[BAMD_TT];
+        float gate_val[TT];
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) {
             const bool last = !(PAIR && part == 0) && r + 1 >= count;
             const bool after_b = (PAIR && part == 0) || (last && part == 1);
             const int after_off = (PAIR && part == 0) ? rowoff : (last ? rowoff + (nb - 1) * RECB : rowoff + rg_step);
-            RowAcc A[BAMD_TT];
+            RowAcc A[TT];
 #pragma unroll
-            for (int u = 0; u < BAMD_TT; ++u) { A[u].acc = 0.f; A[u].accm = 0.f; }
+            for (int u = 0; u < TT; ++u) { A[u].acc = 0.f; A[u].accm = 0.f; }
             for (int c = 0; c < chunks; ++c) {
                 const bool inrow = c + 1 < chunks;
                 const bamd_rsrc nrs = (inrow ? part == 1 : after_b) ? rsB : rsA;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
                 for (int s = 0; s < D; ++s) {
                     pin_rec(ring[s]);
 #pragma unroll
-                    for (int u = 0; u < BAMD_TT; ++u) {          // tokens beyond nt read stale-but-valid LDS and are never stored
+                    for (int u = 0; u < TT; ++u) {               // tokens beyond nt read stale-but-valid LDS and are never stored
                         const unsigned char * au = acts + (size_t) u * bb;
                         const uint32_t * q8 = (const uint32_t *) au; const int * S = (const int *) (q8 + nb * 64); const float * yd = (const float *) (S + nb * 8);
                         const Terms T = block_terms(ring[s], c * D + s, lane, q8, S, yd);
@@ -106,7 +106,7 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
                 }
             }
 #pragma unroll
-            for (int u = 0; u < BAMD_TT; ++u) {
+            for (int u = 0; u < TT; ++u) {
                 const float val = finish_row<TYPE>(A[u]);
                 if (PAIR && part == 0) { gate_val[u] = val; continue; }
                 if ((lane & 7) == 0 && row < nvalid && u < nt) {
@@ -125,17 +125,19 @@ __device__ __forceinline__ void batch_segment(const uint8_t * __restrict__ wA, c
 // round 6 measured what bounds them (profiles/r06_prefill_ceiling.txt) and kept ONE: bamd_prefill2.hip.  This file keeps the integer-dot kernel — the second
 // implementation the matrix-core kernels are tested against, and what a matrix without a side table runs on — and the plumbing.)
 
-// grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile
-template <int EPI>
+// grid (token tiles, row slots): consecutive workgroups share the weights (L2) and differ in the token tile.  TT tokens per tile: BAMD_TT = 8 while their Q8_K
+// activations fit the LDS (K <= 17920), 4 beyond (K <= 35840: the 70B ffn_down at K = 28672 — round 6; before, a 70B-width model without side tables had no batched
+// kernel at all and evaluated prompts token by token)
+template <int EPI, int TT>
 __global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nb = a.K >> 8;
     const size_t bb = BAMD_BLOB_BYTES(nb);
-    const int t0 = blockIdx.x * BAMD_TT;
-    const int nt = a.T - t0 < BAMD_TT ? a.T - t0 : BAMD_TT;
+    const int t0 = blockIdx.x * TT;
+    const int nt = a.T - t0 < TT ? a.T - t0 : TT;
     {   // this tile's activations -> LDS (rows past T: repeat the last token; results discarded)
         const int n16 = (int) (bb / 16);
-        for (int i = threadIdx.x; i < n16 * BAMD_TT; i += blockDim.x) {
+        for (int i = threadIdx.x; i < n16 * TT; i += blockDim.x) {
             const int u = i / n16, k = i - u * n16;
             const int tu = t0 + (u < nt ? u : nt - 1);
             ((uint4 *) smem)[(size_t) u * n16 + k] = ((const uint4 *) (a.blob + (size_t) tu * bb))[k];
@@ -159,13 +161,13 @@ __global__ void __launch_bounds__(512) matmul_batch_kernel(bamd_mm_args a) {
             const int nv = a.seg[s].nvalid > 0 ? a.seg[s].nvalid : a.seg[s].nrows;
             // ring depth 4 when it divides the row (it does for every K % 1024 == 0), else 1
             if ((nb & 3) == 0) {
-                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
-                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
-                else                     batch_segment<BAMD_Q6_K, RecQ6K, 4, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 4, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 4, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 4, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
             } else {
-                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
-                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
-                else                     batch_segment<BAMD_Q6_K, RecQ6K, 1, EPI>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                if (t == BAMD_Q4_K)      batch_segment<BAMD_Q4_K, RecQ4K, 1, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else if (t == BAMD_Q5_K) batch_segment<BAMD_Q5_K, RecQ5K, 1, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
+                else                     batch_segment<BAMD_Q6_K, RecQ6K, 1, EPI, TT>(wA, wB, nb, g0 - off, count, stride, a.seg[s].out, a.res, a.ldo, t0, nt, smem, bb, nv);
             }
         }
         off += nrg;
@@ -193,20 +195,23 @@ void bamd_launch_quantize_batch(const float * x, const float * nw, float eps, in
 int bamd_launch_matmul_batch(const bamd_mm_args & a, int epi, int n_cu, hipStream_t s) {
     int nrg = 0;
     if (epi == BAMD_EPI_SILU_MUL) nrg = a.seg[0].nrows >> 3; else for (int i = 0; i < a.nseg; ++i) nrg += a.seg[i].nrows >> 3;
-    const size_t lds = (size_t) BAMD_TT * BAMD_BLOB_BYTES(a.K >> 8);
-    if (lds > 160 * 1024) return 1;                           // K > 17920: would need a K-split of the activation tile
-    const int tiles = (a.T + BAMD_TT - 1) / BAMD_TT;
+    const int tt = (size_t) BAMD_TT * BAMD_BLOB_BYTES(a.K >> 8) <= 160 * 1024 ? BAMD_TT : 4;     // tokens per tile: 8 while their activations fit the LDS, else 4
+    const size_t lds = (size_t) tt * BAMD_BLOB_BYTES(a.K >> 8);
+    if (lds > 160 * 1024) return 1;                           // K > 35840: would need a K-split of the activation tile
+    const int tiles = (a.T + tt - 1) / tt;
     // row slots: enough workgroups to fill the chip a few times over, at least one row-group per wave
     int gy = (4 * (n_cu > 0 ? n_cu : 256) + tiles - 1) / tiles;
     if (gy * 8 > nrg) gy = (nrg + 7) / 8;
     if (gy < 1) gy = 1;
     dim3 grid(tiles, gy);
+#define BAMD_MB(EPI_) do { if (tt == BAMD_TT) hipLaunchKernelGGL((matmul_batch_kernel<EPI_, BAMD_TT>), grid, dim3(512), lds, s, a); else hipLaunchKernelGGL((matmul_batch_kernel<EPI_, 4>), grid, dim3(512), lds, s, a); } while (0)
     switch (epi) {
-        case BAMD_EPI_STORE:    hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_STORE>),    grid, dim3(512), lds, s, a); break;
-        case BAMD_EPI_ADD:      hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_ADD>),      grid, dim3(512), lds, s, a); break;
-        case BAMD_EPI_SILU_MUL: hipLaunchKernelGGL((matmul_batch_kernel<BAMD_EPI_SILU_MUL>), grid, dim3(512), lds, s, a); break;
+        case BAMD_EPI_STORE:    BAMD_MB(BAMD_EPI_STORE); break;
+        case BAMD_EPI_ADD:      BAMD_MB(BAMD_EPI_ADD); break;
+        case BAMD_EPI_SILU_MUL: BAMD_MB(BAMD_EPI_SILU_MUL); break;
         default: return 1;
     }
+#undef BAMD_MB
     return 0;
 }
 void bamd_launch_embed_batch(const int32_t * tokens, int T, const void * embd, int embd_type, int E, int V, float * x, hipStream_t s) {

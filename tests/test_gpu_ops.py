@@ -223,6 +223,8 @@ def test_attention(bamd, po, H, Hkv, hd, prefill, long_path):
                                                (14, 1024, 64, 16, 0), (14, 2048, 40, 21, 0), (14, 4096, 528, 37, 0), (14, 14336, 32, 33, 0),
                                                (12, 768, 40, 21, 0), (14, 2816, 24, 17, 0), (12, 11008, 32, 16, 0), (14, 256, 16, 3, 0),
                                                (13, 1024, 64, 16, 0), (13, 2048, 40, 21, 0), (13, 4096, 528, 37, 0), (13, 8192, 48, 33, 0), (13, 768, 24, 9, 0),
+                                               (12, 28672, 24, 11, 0), (14, 28672, 16, 6, 0), (13, 28672, 8, 5, 0),      # K = 28672 (the 70B ffn_down): token tiles of four
+                                               (12, 28672, 24, 11, 2), (14, 28672, 16, 6, 2),
                                                # impl 2: the matrix-core kernels (64-row x 64-token workgroups, fragments built once per workgroup, load-time side tables)
                                                (12, 1024, 64, 16, 2), (12, 2048, 40, 21, 2), (12, 4096, 528, 37, 2), (12, 14336, 32, 16, 2), (12, 768, 40, 70, 2),
                                                (12, 11008, 32, 16, 2), (12, 256, 8, 1, 2), (12, 4096, 200, 129, 2),
