@@ -485,6 +485,11 @@ typedef __amdgpu_buffer_rsrc_t bamd_rsrc;
 __device__ __forceinline__ bamd_rsrc weight_rsrc(const void * base) {       // base must be wave-uniform; the window is 2 GiB - 1 (offsets are checked by the launcher's shapes)
     return __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) base), 0, 0x7fffffff, 0x00020000);
 }
+// the same base with ZERO records: every load through it is out of range — it returns 0 and fetches nothing.  The requests a streaming loop issues past the end of
+// its work (they stay unconditional so that the compiler's wait counts stay counted) go through this descriptor, chosen by scalar selects: no branch, no bytes
+__device__ __forceinline__ bamd_rsrc null_rsrc(const void * base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) uniform_ptr((const uint8_t *) base), 0, 0, 0x00020000);
+}
 __device__ __forceinline__ uint4 bl128(bamd_rsrc r, uint32_t voff, int soff) { const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int) voff, soff, BAMD_LOAD_NT); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint2 bl64(bamd_rsrc r, uint32_t voff, int soff) { const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int) voff, soff, BAMD_LOAD_NT); return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint32_t bl32(bamd_rsrc r, uint32_t voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int) voff, soff, BAMD_LOAD_NT); }
@@ -492,6 +497,7 @@ __device__ __forceinline__ uint32_t bl16(bamd_rsrc r, uint32_t voff, int soff) {
 #else
 struct bamd_rsrc { const uint8_t * base; };
 __device__ __forceinline__ bamd_rsrc weight_rsrc(const void * base) { bamd_rsrc r; r.base = uniform_ptr((const uint8_t *) base); return r; }
+__device__ __forceinline__ bamd_rsrc null_rsrc(const void * base) { return weight_rsrc(base); }
 __device__ __forceinline__ uint4 bl128(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint4>(r.base + soff, voff); }
 __device__ __forceinline__ uint2 bl64(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint2>(r.base + soff, voff); }
 __device__ __forceinline__ uint32_t bl32(bamd_rsrc r, uint32_t voff, int soff) { return ldnt<uint32_t>(r.base + soff, voff); }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
     constexpr int NPARTS = PAIR ? 2 : 1;
     const int lane = threadIdx.x & 63;
     // records are addressed as (matrix descriptor, 32-bit byte offset): see load_rec.  A matrix stays below 2 GiB (launcher).
-    const bamd_rsrc rsA = weight_rsrc(wA), rsB = PAIR ? weight_rsrc(wB) : rsA;
+    const bamd_rsrc rsA = weight_rsrc(wA), rsB = PAIR ? weight_rsrc(wB) : rsA, rsN = null_rsrc(wA);
     const int rgb = nb * RECB;                           // D divides nb (chosen by the dispatcher below)
     const int rg_step = stride * rgb;
     const int chunks = nb / D;
@@ -106,7 +106,8 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
             RowAcc A = { 0.f, 0.f };
             for (int c = 0; c < chunks; ++c) {
                 const bool inrow = c + 1 < chunks;
-                const bamd_rsrc nrs = (inrow ? part == 1 : after_b) ? rsB : rsA;
+                const bool tail = !inrow && last;                // the requests behind this wave's last chunk: never consumed — the zero-record descriptor
+                const bamd_rsrc nrs = tail ? rsN : (inrow ? part == 1 : after_b) ? rsB : rsA;
                 const int nxt = inrow ? rowoff + (c + 1) * (D * RECB) : after_off;
                 const int step = (inrow || !last) ? RECB : 0;
 #pragma unroll
@@ -249,7 +250,7 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
     constexpr int D = NBW * M;                               // ring depth = one batch (M row-groups) of this wave's records
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int r8 = lane >> 3, l4 = lane & 3;
-    const bamd_rsrc rs = weight_rsrc(w);
+    const bamd_rsrc rs = weight_rsrc(w), rsn = null_rsrc(w);
     const int rgb = nb * RECB;
     const int rg_step = stride * rgb;
     const int n_w = UNEVEN ? (NBW - 1) + (wave < (nb & 7) ? 1 : 0) : NBW;                  // this wave's records per row-group
@@ -339,12 +340,12 @@ __device__ __forceinline__ void split_stream(const uint8_t * __restrict__ w, int
                     if (!ONEB) {
                         const int jj = UNEVEN && j >= n_w ? n_w - 1 : j;
                         if (BAMD_SPLIT_UNCOND_REFILL && SMALLK) {
-                            // fast kernels: the refill is UNCONDITIONAL — behind the last batch it re-requests the first record of the row-group just consumed
-                            // (one record of redundant L2 traffic per wave, never used).  A branch around the request made the compiler merge the wait counts of
+                            // fast kernels: the refill is UNCONDITIONAL — behind the last batch it goes through the zero-record descriptor (null_rsrc: returns 0,
+                            // fetches nothing; a re-request of a real record showed as + 6 % FETCH_SIZE on the 8B ffn_down: nt lines do not stay in the L2).  A branch around the request made the compiler merge the wait counts of
                             // both paths at every join: the waits of a batch ran down from vmcnt(13) to vmcnt(0), i.e. the last record of every batch waited for
                             // the six refills issued just before it (a drained ring per batch); now every record waits for exactly its own two loads
                             const bool more = r0 + M + m < count;
-                            load_rec(ring[s], rs, bbase + (more ? (M + m) * rg_step + jj * RECB : m * rg_step), lane);
+                            load_rec(ring[s], more ? rs : rsn, bbase + (more ? (M + m) * rg_step + jj * RECB : m * rg_step), lane);
                         } else if (r0 + M + m < count) load_rec(ring[s], rs, bbase + (M + m) * rg_step + jj * RECB, lane);
                     }
                     if ((s & (BAMD_SCHED_GROUP - 1)) == BAMD_SCHED_GROUP - 1 || s == D - 1) __builtin_amdgcn_sched_barrier(0);
