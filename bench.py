@@ -285,8 +285,8 @@ def main():
                        note="same K steps over the same positions, back to back; value = the median repetition")
         # roofline of the dominant kernel: HIP events around every launch of eager steps at the same context length, per launch kind
         KINDS = ["qkv", "attention", "other", "wo", "gate_up", "ffn_down", "lm_head"]
-        KERNEL_OF = {"qkv": "matvec_split_fast_kernel / matvec_split_mixed_kernel (fused QKV, RMSNorm prologue)", "wo": "matvec_split_fast_kernel (wo, +residual)",
-                     "gate_up": "matvec_fast_kernel<Q4_K, RMSNorm prologue, silu(gate)*up epilogue> (ffn_gate + ffn_up)", "ffn_down": "matvec_split_fast_kernel (ffn_down, +residual)",
+        KERNEL_OF = {"qkv": "matvec_split_mixed_kernel (fused QKV, RMSNorm prologue, three row-groups per workgroup in one batch)", "wo": "matvec_split_fast_kernel (wo, +residual)",
+                     "gate_up": "matvec_gateup7_kernel<12, 2> at the 8B / Mistral widths (seven row-group pairs per workgroup; matvec_gateup14_kernel at the 70B widths, matvec_fast_kernel<TYPE, 0, RMSNorm prologue, silu(gate)*up epilogue> elsewhere): ffn_gate + ffn_up of one layer in one launch", "ffn_down": "matvec_split_fast_kernel (ffn_down, +residual)",
                      "lm_head": "matvec_fast_kernel<Q6_K, arg-max epilogue> (output)", "attention": "attn_fused_kernel",
                      "attention+wo": "attn_wo_kernel (single-launch attention on H CUs, wo + residual on the others)"}
         # eight eager steps; per launch kind the MEDIAN step's time (one eager step that catches a clock ramp or a neighbour's burst would otherwise move a kind's
