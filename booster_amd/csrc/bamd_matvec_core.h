@@ -95,8 +95,9 @@ __device__ __forceinline__ void stream_segment(const uint8_t * __restrict__ wA, 
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) {
             // after the last chunk of this row-part: the other half of the pair, the next row-group, or — at the very end of the
-            // wave's stream — its own last record again, D times (step 0: one record of redundant traffic, never consumed; the
-            // requests stay unconditional so that the waits stay counted)
+            // wave's stream — D requests through the zero-record descriptor (null_rsrc: they return 0 and fetch nothing; rounds 1-5
+            // re-requested the wave's last record, one record of redundant traffic; the requests stay unconditional so that the
+            // waits stay counted)
             const bool last = !(PAIR && part == 0) && r + 1 >= count;
             const bool after_b = (PAIR && part == 0) || (last && part == 1);
             const int after_off = (PAIR && part == 0) ? rowoff : (last ? rowoff + (nb - 1) * RECB : rowoff + rg_step);
